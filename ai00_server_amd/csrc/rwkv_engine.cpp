@@ -1,0 +1,1108 @@
+// rwkv_engine.cpp — host side of librwkv_hip.so: loader, engine, step planner, C ABI.
+//
+// Replaces, behind include/rwkv_abi.h, the web-rwkv objects ai00-core holds:
+//   Context + ModelBuilder + vN::Bundle + TokioRuntime<Rnn>  (crates/ai00-core/src/lib.rs:391-516)
+//   State {init,load,back,read,write}                         (run.rs:477, 1099-1106)
+//   softmax::softmax                                          (run.rs:1179)
+// No CPU fallback: every entry point that computes needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rwkv_abi.h"
+#include "rwkv_kernels.h"
+#include "safetensors.hpp"
+
+using namespace rwkv;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+struct RwkvError : std::runtime_error {
+    rwkv_status code;
+    RwkvError(rwkv_status c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+#define HIP_CHECK(x)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (x);                                                                           \
+        if (_e != hipSuccess)                                                                          \
+            throw RwkvError(_e == hipErrorOutOfMemory ? RWKV_ERR_OOM : RWKV_ERR_DEVICE,                \
+                            std::string(#x) + ": " + hipGetErrorString(_e));                           \
+    } while (0)
+
+template <class F>
+static rwkv_status guard(F &&f) {
+    try {
+        f();
+        return RWKV_OK;
+    } catch (const RwkvError &e) {
+        g_err = e.what();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        g_err = "host out of memory";
+        return RWKV_ERR_OOM;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return std::strncmp(e.what(), "safetensors:", 12) == 0 ? RWKV_ERR_FORMAT : RWKV_ERR_INVALID;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// model info (Loader::info, lib.rs:587)
+// ------------------------------------------------------------------------------------------------
+static rwkv_model_info detect_info(const SafeTensors &st) {
+    rwkv_model_info i{};
+    if (st.find("blocks.0.att.x_r")) i.version = 7;
+    else if (st.find("blocks.0.att.time_mix_x")) i.version = 6;
+    else if (st.find("blocks.0.att.ln_x.weight") && st.find("blocks.0.att.gate.weight")) {
+        const StTensor &td = st.get("blocks.0.att.time_decay");
+        if (td.shape.size() < 2 || td.shape.back() <= 1)
+            throw RwkvError(RWKV_ERR_UNSUPPORTED, "RWKV v5.0/v5.1 checkpoints are not supported (need v5.2)");
+        i.version = 5;
+    } else
+        throw RwkvError(RWKV_ERR_UNSUPPORTED, "unsupported model version (v4 or unknown tensor naming)");
+    int L = 0;
+    while (st.find("blocks." + std::to_string(L) + ".ln1.weight")) ++L;
+    const StTensor &emb = st.get("emb.weight");
+    if (emb.shape.size() != 2) throw RwkvError(RWKV_ERR_FORMAT, "emb.weight must be 2-D");
+    i.num_layer = L;
+    i.num_vocab = (int)emb.shape[0];
+    i.num_emb = (int)emb.shape[1];
+    i.num_hidden = (int)st.get("blocks.0.ffn.key.weight").shape[0];
+    i.num_head = (int)(i.version == 7 ? st.get("blocks.0.att.r_k").shape[0] : st.get("blocks.0.att.time_first").shape[0]);
+    i.head_size = i.num_emb / std::max(1, i.num_head);
+    if (i.head_size != 64) throw RwkvError(RWKV_ERR_UNSUPPORTED, "head size must be 64");
+    if (i.num_emb % 64 || i.num_hidden % 32 || i.num_vocab % 16)
+        throw RwkvError(RWKV_ERR_UNSUPPORTED, "dims must satisfy C%64==0, F%32==0, V%16==0");
+    if (i.num_emb > 8192) throw RwkvError(RWKV_ERR_UNSUPPORTED, "num_emb > 8192");
+    return i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------------------
+struct Opd {                        // f16 hi/lo activation operand [Tmax][ld]
+    _Float16 *hi = nullptr, *lo = nullptr;
+    int ld = 0;
+};
+
+struct ProbSpec {
+    const DMat *W = nullptr;
+    Opd x;
+    int xoff = 0;                   // column offset into x
+    int act = ACT_NONE, post = POST_NONE;
+    const float *bias = nullptr, *m0 = nullptr, *m1 = nullptr;
+    int ldm = 0;
+    float *out = nullptr;
+    int ldo = 0;
+    bool partial = false;           // out = partial-sum buffer, K may be split across blocks
+    Opd oh;                         // optional operand output
+};
+
+enum Family { FAM_GEMM = 0, FAM_HEAD = 1, FAM_ROW = 2, FAM_WKV = 3, FAM_SAMPLE = 4, FAM_COPY = 5 };
+static const char *kFamilyNames[RWKV_PROFILE_FAMILIES] = {"gemm_layers", "gemm_head", "row_ln_shift", "wkv", "sample", "copy", "", ""};
+
+struct LayerW {
+    const float *ln1w, *ln1b, *ln2w, *ln2b, *lnxw, *lnxb;
+    const float *mu[6];             // att mixes (v5: k,v,r,g; v6: x,w,k,v,r,g; v7: r,w,k,v,a,g)
+    const float *fmu[2];            // ffn mixes (v5/v6: k,r; v7: k)
+    const DMat *Wr, *Wk, *Wv, *Wg, *Wo, *Fk, *Fv, *Fr;
+    // v5/v6
+    const float *wdec;              // v5: exp(-exp(decay)); v6: raw time_decay
+    const float *u;
+    const DMat *W1;                 // v6 time_mix_w1 [5Dm x C]
+    const DMat *W2[5];              // v6 time_mix_w2 [C x Dm] x5
+    const DMat *D1;                 // v6 time_decay_w1 [Dd x C]
+    const _Float16 *D2;             // v6 time_decay_w2 raw [C][Dd]
+    // v7
+    const DMat *w1, *w2, *a1, *a2, *v1, *v2, *g1, *g2;
+    const float *w0, *a0, *v0, *k_k, *k_a, *r_k;
+};
+
+struct StepPlan {
+    int T = 0, n_seq = 0, n_out = 0;
+    std::vector<int> token, slot, prev, last, seq_slot, seq_begin, seq_len, out_rows;
+    std::vector<int> slot_consumed, slot_out_begin, slot_out_rows;   // per slot
+};
+
+struct rwkv_dstate {
+    int device = 0;
+    float *sxa = nullptr, *sxf = nullptr, *wkv = nullptr;
+};
+
+struct rwkv_engine {
+    rwkv_model_info info{};
+    int device = 0;
+    int max_batch = 8, chunk = 128;
+    bool hilo = false;
+    int quant_layers = 0, quant_type = 0;
+    hipStream_t s_main = nullptr, s_soft = nullptr;
+    std::vector<void *> allocs;
+    std::map<std::string, DMat> mats;
+    std::map<std::string, float *> vecs;
+    std::map<std::string, _Float16 *> raws;
+    std::vector<LayerW> layers;
+    const float *ln0w, *ln0b, *lnow, *lnob;
+    const _Float16 *emb = nullptr;
+    const DMat *head = nullptr;
+    uint64_t weight_bytes = 0;
+    int Dm = 0, Dd = 0, Dl = 0;     // LoRA dims (v6: Dm, Dd; v7: max of w/a/v/g dims)
+
+    // state (internal layout)
+    float *sxa = nullptr, *sxf = nullptr, *wkv = nullptr;
+    long sx_slot_stride = 0, wkv_slot_stride = 0;
+    float *slab_dev = nullptr;      // staging for pack/unpack
+    float *slab_host = nullptr;     // pinned
+
+    // scratch
+    float *xA = nullptr, *xB = nullptr, *P = nullptr, *xx = nullptr, *dx = nullptr;
+    float *fr = nullptr, *fk = nullptr, *fv = nullptr, *fg = nullptr, *ftd = nullptr, *frr = nullptr;
+    float *fw7 = nullptr, *fa7 = nullptr, *fvg7 = nullptr, *vfirst = nullptr;
+    float *logits = nullptr, *logits_host = nullptr;
+    float *soft_in = nullptr, *soft_out = nullptr, *soft_host = nullptr;
+    size_t soft_rows_cap = 0;
+    Opd opA[6], opM, opY, opK, opO, opL[4];
+    long pstride = 0;
+    // row meta (device + pinned host)
+    int *d_meta = nullptr, *h_meta = nullptr;
+    size_t meta_cap = 0;
+    int *d_tok_feedback = nullptr, *d_hist = nullptr, *d_counter = nullptr;
+    size_t hist_cap = 0;
+
+    // profiling
+    bool profiling = false;
+    float prof_ms[RWKV_PROFILE_FAMILIES] = {0};
+    int prof_n[RWKV_PROFILE_FAMILIES] = {0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // graph cache for decode-shaped steps
+    struct GraphEntry { hipGraphExec_t exec = nullptr; };
+    std::map<uint64_t, GraphEntry> graphs;
+    bool use_graphs = true;
+
+    template <class T>
+    T *dalloc(size_t n) {
+        void *p = nullptr;
+        HIP_CHECK(hipMalloc(&p, std::max<size_t>(n * sizeof(T), 16)));
+        allocs.push_back(p);
+        return (T *)p;
+    }
+    Opd alloc_opd(int ld) {
+        Opd o;
+        o.ld = ld;
+        o.hi = dalloc<_Float16>((size_t)chunk * ld);
+        o.lo = hilo ? dalloc<_Float16>((size_t)chunk * ld) : nullptr;
+        return o;
+    }
+    ~rwkv_engine() {
+        (void)hipSetDevice(device);
+        if (s_main) (void)hipStreamSynchronize(s_main);
+        if (s_soft) (void)hipStreamSynchronize(s_soft);
+        for (auto &g : graphs) if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+        for (void *p : allocs) (void)hipFree(p);
+        if (slab_host) (void)hipHostFree(slab_host);
+        if (logits_host) (void)hipHostFree(logits_host);
+        if (soft_host) (void)hipHostFree(soft_host);
+        if (h_meta) (void)hipHostFree(h_meta);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (s_main) (void)hipStreamDestroy(s_main);
+        if (s_soft) (void)hipStreamDestroy(s_soft);
+    }
+
+    // ---- launch wrapper: optional per-family hipEvent timing on the compute stream ----
+    template <class F>
+    void launch(int fam, F &&f) {
+        if (profiling) {
+            HIP_CHECK(hipEventRecord(ev0, s_main));
+            f();
+            HIP_CHECK(hipEventRecord(ev1, s_main));
+            HIP_CHECK(hipEventSynchronize(ev1));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+            prof_ms[fam] += ms;
+            prof_n[fam] += 1;
+        } else {
+            f();
+        }
+    }
+
+    void load(const rwkv_load_desc &d);
+    int gemm(std::vector<ProbSpec> &ps, int T, int fam);
+    void plan_step(const rwkv_slot_input *in, StepPlan &pl);
+    void upload_plan(const StepPlan &pl);
+    void run_layers(int T, int n_seq, int n_out, const int *d_token);
+    void infer(const rwkv_slot_input *in, rwkv_slot_output *out);
+    RowMeta meta_ptrs(int T) const;
+    const int *d_seq_slot, *d_seq_begin, *d_seq_len, *d_out_rows;
+};
+
+// ------------------------------------------------------------------------------------------------
+// loader
+// ------------------------------------------------------------------------------------------------
+static bool is_quant_target(int version, const std::string &suffix) {
+    static const char *att56[] = {"att.receptance.weight", "att.key.weight", "att.value.weight", "att.output.weight", "att.gate.weight"};
+    static const char *att7[] = {"att.receptance.weight", "att.key.weight", "att.value.weight", "att.output.weight"};
+    static const char *ffn56[] = {"ffn.key.weight", "ffn.value.weight", "ffn.receptance.weight"};
+    static const char *ffn7[] = {"ffn.key.weight", "ffn.value.weight"};
+    if (version == 7) {
+        for (auto s : att7) if (suffix == s) return true;
+        for (auto s : ffn7) if (suffix == s) return true;
+    } else {
+        for (auto s : att56) if (suffix == s) return true;
+        for (auto s : ffn56) if (suffix == s) return true;
+    }
+    return false;
+}
+
+void rwkv_engine::load(const rwkv_load_desc &d) {
+    SafeTensors st = SafeTensors::parse(d.st_bytes, d.st_len);
+    info = detect_info(st);
+    const int L = info.num_layer, C = info.num_emb, F = info.num_hidden, V = info.num_vocab, H = info.num_head;
+    max_batch = d.max_batch > 0 ? d.max_batch : 8;
+    chunk = d.token_chunk_size > 0 ? d.token_chunk_size : 128;
+    hilo = d.precision == RWKV_PRECISION_FP32;
+    quant_layers = std::max(0, std::min(d.quant_layers, L));
+    quant_type = d.quant_type;
+    if (quant_type != RWKV_QUANT_NONE && quant_type != RWKV_QUANT_INT8 && quant_type != RWKV_QUANT_NF4)
+        throw RwkvError(RWKV_ERR_UNSUPPORTED, "quant_type must be None, Int8 or NF4 (SF4 is not supported)");
+    if (quant_type != RWKV_QUANT_NONE && quant_layers > 0 && (C % 256 || F % 256))
+        throw RwkvError(RWKV_ERR_UNSUPPORTED, "quantisation needs num_emb and num_hidden to be multiples of 256");
+
+    HIP_CHECK(hipStreamCreateWithFlags(&s_main, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&s_soft, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreate(&ev0));
+    HIP_CHECK(hipEventCreate(&ev1));
+
+    // LoRA adapters parsed once (LoraBlend::full(alpha), lib.rs:466-482): W += alpha * B * A^T for every
+    // matrix that has `<name minus .weight>.lora.0` ([in, r], transposed on conversion) and `.lora.1` ([out, r]).
+    std::vector<std::pair<SafeTensors, float>> loras;
+    for (size_t i = 0; i < d.n_lora; ++i)
+        loras.emplace_back(SafeTensors::parse(d.lora[i].st_bytes, d.lora[i].st_len), d.lora[i].alpha);
+
+    size_t raw_cap = 0;
+    for (auto &kv : st.tensors) raw_cap = std::max(raw_cap, kv.second.nbytes);
+    _Float16 *raw = nullptr;                                   // temp upload buffer
+    HIP_CHECK(hipMalloc((void **)&raw, std::max<size_t>(raw_cap, 16)));
+    struct RawGuard { void *p; ~RawGuard() { (void)hipFree(p); } } rg{raw};
+    _Float16 *lbuf = nullptr;
+    size_t lbuf_cap = 0;
+    struct LGuard { _Float16 **p; ~LGuard() { if (*p) (void)hipFree(*p); } } lg{&lbuf};
+
+    auto upload_raw = [&](const StTensor &t) {
+        if (t.dtype != "F16") throw RwkvError(RWKV_ERR_UNSUPPORTED, "tensor dtype must be F16 (convert_safetensors.py:64)");
+        HIP_CHECK(hipMemcpyAsync(raw, t.data, t.nbytes, hipMemcpyHostToDevice, s_main));
+    };
+    auto load_vec = [&](const std::string &name, int op = 0) -> const float * {
+        const StTensor &t = st.get(name);
+        upload_raw(t);
+        float *v = dalloc<float>((size_t)t.numel());
+        launch_f16_to_f32(raw, v, t.numel(), op, s_main);
+        HIP_CHECK(hipStreamSynchronize(s_main));
+        vecs[name] = v;
+        weight_bytes += (uint64_t)t.numel() * 2;
+        return v;
+    };
+    auto load_raw16 = [&](const std::string &name, bool count) -> const _Float16 * {
+        const StTensor &t = st.get(name);
+        if (t.dtype != "F16") throw RwkvError(RWKV_ERR_UNSUPPORTED, "tensor dtype must be F16");
+        _Float16 *v = dalloc<_Float16>((size_t)t.numel());
+        HIP_CHECK(hipMemcpy(v, t.data, t.nbytes, hipMemcpyHostToDevice));
+        raws[name] = v;
+        if (count) weight_bytes += (uint64_t)t.nbytes;
+        return v;
+    };
+    // matrix [.., rows, K] (leading dims folded into `index`)
+    auto load_mat = [&](const std::string &name, int fmt, int index = -1, const std::string &key = "") -> const DMat * {
+        const StTensor &t = st.get(name);
+        if (t.shape.size() < 2) throw RwkvError(RWKV_ERR_FORMAT, name + ": expected a matrix");
+        const int K = (int)t.shape.back(), rows = (int)t.shape[t.shape.size() - 2];
+        upload_raw(t);
+        const _Float16 *src = raw + (index >= 0 ? (size_t)index * rows * K : 0);
+        if (index < 0) {
+            // LoRA blend on the raw fp16 matrix (fp32 math, one rounding back to fp16)
+            const std::string stem = name.size() > 7 && name.substr(name.size() - 7) == ".weight" ? name.substr(0, name.size() - 7) : name;
+            for (auto &lp : loras) {
+                const StTensor *A = lp.first.find(stem + ".lora.0"), *B = lp.first.find(stem + ".lora.1");
+                if (!A || !B) continue;
+                if (A->shape.size() != 2 || B->shape.size() != 2 || A->shape[0] != K || B->shape[0] != rows || A->shape[1] != B->shape[1])
+                    throw RwkvError(RWKV_ERR_FORMAT, "LoRA shape mismatch for " + stem);
+                const int r = (int)A->shape[1];
+                size_t need = (size_t)(K + rows) * r * 2;
+                if (need > lbuf_cap) {
+                    if (lbuf) (void)hipFree(lbuf);
+                    lbuf = nullptr;
+                    HIP_CHECK(hipMalloc((void **)&lbuf, need));
+                    lbuf_cap = need;
+                }
+                HIP_CHECK(hipMemcpyAsync(lbuf, A->data, A->nbytes, hipMemcpyHostToDevice, s_main));
+                HIP_CHECK(hipMemcpyAsync(lbuf + (size_t)K * r, B->data, B->nbytes, hipMemcpyHostToDevice, s_main));
+                launch_lora_blend(raw, lbuf + (size_t)K * r, lbuf, rows, K, r, lp.second, s_main);
+            }
+        }
+        if (K % 32) throw RwkvError(RWKV_ERR_UNSUPPORTED, name + ": inner dim must be a multiple of 32");
+        DMat m;
+        m.fmt = fmt;
+        m.K = K;
+        m.rows = (rows + 15) / 16 * 16;
+        if (fmt != W_F16 && (K % 256 || rows % 16)) throw RwkvError(RWKV_ERR_UNSUPPORTED, name + ": cannot quantise (dims)");
+        if (fmt == W_F16) {
+            size_t n = (size_t)m.rows * K * 2;
+            void *p = dalloc<uint8_t>(n);
+            launch_tile_f16(src, rows, m.rows, K, p, s_main);
+            m.data = p;
+            m.bytes = (uint64_t)rows * K * 2;
+        } else if (fmt == W_INT8) {
+            void *p = dalloc<uint8_t>((size_t)m.rows * K);
+            void *sc = dalloc<uint8_t>((size_t)m.rows * (K / 128) * 4);
+            launch_quant_int8(src, m.rows, K, p, sc, s_main);
+            m.data = p; m.scales = sc;
+            m.bytes = (uint64_t)m.rows * K + (uint64_t)m.rows * (K / 128) * 4;
+        } else {
+            void *p = dalloc<uint8_t>((size_t)m.rows * K / 2);
+            void *sc = dalloc<uint8_t>((size_t)m.rows * (K / 64) * 2);
+            launch_quant_nf4(src, m.rows, K, p, sc, s_main);
+            m.data = p; m.scales = sc;
+            m.bytes = (uint64_t)m.rows * K / 2 + (uint64_t)m.rows * (K / 64) * 2;
+        }
+        HIP_CHECK(hipStreamSynchronize(s_main));
+        weight_bytes += m.bytes;
+        auto it = mats.emplace(key.empty() ? name : key, m).first;
+        return &it->second;
+    };
+
+    emb = load_raw16("emb.weight", false);                    // embedding table: only B rows touched per step
+    ln0w = load_vec("blocks.0.ln0.weight");
+    ln0b = load_vec("blocks.0.ln0.bias");
+    lnow = load_vec("ln_out.weight");
+    lnob = load_vec("ln_out.bias");
+    head = load_mat("head.weight", W_F16);
+    if (head->rows != V) throw RwkvError(RWKV_ERR_FORMAT, "head.weight rows != vocab");
+
+    layers.resize(L);
+    for (int l = 0; l < L; ++l) {
+        LayerW &w = layers[l];
+        std::memset(&w, 0, sizeof(w));
+        const std::string p = "blocks." + std::to_string(l) + ".";
+        const int qf = (quant_type != RWKV_QUANT_NONE && l < quant_layers) ? (quant_type == RWKV_QUANT_INT8 ? W_INT8 : W_NF4) : W_F16;
+        auto qfmt = [&](const char *suffix) { return is_quant_target(info.version, suffix) ? qf : W_F16; };
+        w.ln1w = load_vec(p + "ln1.weight"); w.ln1b = load_vec(p + "ln1.bias");
+        w.ln2w = load_vec(p + "ln2.weight"); w.ln2b = load_vec(p + "ln2.bias");
+        w.lnxw = load_vec(p + "att.ln_x.weight"); w.lnxb = load_vec(p + "att.ln_x.bias");
+        w.Wr = load_mat(p + "att.receptance.weight", qfmt("att.receptance.weight"));
+        w.Wk = load_mat(p + "att.key.weight", qfmt("att.key.weight"));
+        w.Wv = load_mat(p + "att.value.weight", qfmt("att.value.weight"));
+        w.Wo = load_mat(p + "att.output.weight", qfmt("att.output.weight"));
+        w.Fk = load_mat(p + "ffn.key.weight", qfmt("ffn.key.weight"));
+        w.Fv = load_mat(p + "ffn.value.weight", qfmt("ffn.value.weight"));
+        if (info.version != 7) {
+            w.Wg = load_mat(p + "att.gate.weight", qfmt("att.gate.weight"));
+            w.Fr = load_mat(p + "ffn.receptance.weight", qfmt("ffn.receptance.weight"));
+            w.fmu[0] = load_vec(p + "ffn.time_mix_k");
+            w.fmu[1] = load_vec(p + "ffn.time_mix_r");
+            w.u = load_vec(p + "att.time_first");
+        }
+        if (info.version == 5) {
+            const char *n4[] = {"k", "v", "r", "g"};
+            for (int i = 0; i < 4; ++i) w.mu[i] = load_vec(p + "att.time_mix_" + n4[i]);
+            w.wdec = load_vec(p + "att.time_decay", 1);      // exp(-exp(decay)), static per channel
+        } else if (info.version == 6) {
+            const char *n6[] = {"x", "w", "k", "v", "r", "g"};
+            for (int i = 0; i < 6; ++i) w.mu[i] = load_vec(p + "att.time_mix_" + n6[i]);
+            w.wdec = load_vec(p + "att.time_decay");
+            w.W1 = load_mat(p + "att.time_mix_w1", W_F16);
+            const StTensor &w2 = st.get(p + "att.time_mix_w2");
+            if (w2.shape.size() != 3 || w2.shape[0] != 5) throw RwkvError(RWKV_ERR_FORMAT, "time_mix_w2 must be [5,C,Dm]");
+            Dm = (int)w2.shape[2];
+            for (int c = 0; c < 5; ++c) w.W2[c] = load_mat(p + "att.time_mix_w2", W_F16, c, p + "att.time_mix_w2#" + std::to_string(c));
+            w.D1 = load_mat(p + "att.time_decay_w1", W_F16);
+            Dd = w.D1->rows;
+            if (Dd > 128 || Dd % 4) throw RwkvError(RWKV_ERR_UNSUPPORTED, "time_decay LoRA dim must be <=128");
+            w.D2 = load_raw16(p + "att.time_decay_w2", true);
+        } else {
+            const char *n7[] = {"r", "w", "k", "v", "a", "g"};
+            for (int i = 0; i < 6; ++i) w.mu[i] = load_vec(p + "att.x_" + n7[i]);
+            w.fmu[0] = load_vec(p + "ffn.x_k");
+            w.w0 = load_vec(p + "att.w0"); w.a0 = load_vec(p + "att.a0");
+            w.k_k = load_vec(p + "att.k_k"); w.k_a = load_vec(p + "att.k_a"); w.r_k = load_vec(p + "att.r_k");
+            w.w1 = load_mat(p + "att.w1", W_F16); w.w2 = load_mat(p + "att.w2", W_F16);
+            w.a1 = load_mat(p + "att.a1", W_F16); w.a2 = load_mat(p + "att.a2", W_F16);
+            w.g1 = load_mat(p + "att.g1", W_F16); w.g2 = load_mat(p + "att.g2", W_F16);
+            if (l > 0 || st.find(p + "att.v0")) {
+                w.v0 = load_vec(p + "att.v0");
+                w.v1 = load_mat(p + "att.v1", W_F16); w.v2 = load_mat(p + "att.v2", W_F16);
+            }
+            for (const DMat *m : {w.w1, w.a1, w.v1, w.g1}) if (m) Dl = std::max(Dl, m->rows);
+        }
+    }
+
+    // ---- state + scratch
+    sx_slot_stride = (long)L * C;
+    wkv_slot_stride = (long)L * H * 4096;
+    sxa = dalloc<float>((size_t)max_batch * sx_slot_stride);
+    sxf = dalloc<float>((size_t)max_batch * sx_slot_stride);
+    wkv = dalloc<float>((size_t)max_batch * wkv_slot_stride);
+    HIP_CHECK(hipMemset(sxa, 0, (size_t)max_batch * sx_slot_stride * 4));
+    HIP_CHECK(hipMemset(sxf, 0, (size_t)max_batch * sx_slot_stride * 4));
+    HIP_CHECK(hipMemset(wkv, 0, (size_t)max_batch * wkv_slot_stride * 4));
+    const size_t slab = (size_t)L * 66 * C;
+    slab_dev = dalloc<float>(slab);
+    HIP_CHECK(hipHostMalloc((void **)&slab_host, slab * 4, hipHostMallocDefault));
+
+    const size_t TC = (size_t)chunk * C;
+    pstride = (long)TC;
+    xA = dalloc<float>(TC); xB = dalloc<float>(TC); P = dalloc<float>(TC * 8);
+    xx = dalloc<float>(TC); dx = dalloc<float>(TC);
+    fr = dalloc<float>(TC); fk = dalloc<float>(TC); fv = dalloc<float>(TC); fg = dalloc<float>(TC); frr = dalloc<float>(TC);
+    ftd = dalloc<float>((size_t)chunk * 128);
+    if (info.version == 7) {
+        fw7 = dalloc<float>(TC); fa7 = dalloc<float>(TC); fvg7 = dalloc<float>(TC); vfirst = dalloc<float>(TC);
+    }
+    for (auto &o : opA) o = alloc_opd(C);
+    opY = alloc_opd(C);
+    opO = alloc_opd(C);
+    opK = alloc_opd(F);
+    opM = alloc_opd(std::max(16, info.version == 6 ? 5 * Dm : 16));
+    for (auto &o : opL) o = alloc_opd(std::max(16, Dl));
+    logits = dalloc<float>((size_t)chunk * V);
+    HIP_CHECK(hipHostMalloc((void **)&logits_host, (size_t)chunk * V * 4, hipHostMallocDefault));
+    meta_cap = (size_t)chunk * 5 + (size_t)max_batch * 3 + 16;
+    d_meta = dalloc<int>(meta_cap);
+    HIP_CHECK(hipHostMalloc((void **)&h_meta, meta_cap * 4, hipHostMallocDefault));
+    d_tok_feedback = dalloc<int>(chunk);
+    d_counter = dalloc<int>(4);
+    HIP_CHECK(hipDeviceSynchronize());
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM planning: choose the K split per problem, the X chunk and launch
+// ------------------------------------------------------------------------------------------------
+static void choose_split(const DMat &W, bool partial, int max_w, int &ksw, int &ksb) {
+    const int strips = W.rows / 16, K = W.K;
+    double best = -1;
+    ksw = 1; ksb = 1;
+    for (int w : {1, 2, 4}) {
+        if (w > max_w) continue;
+        for (int b = 1; b <= (partial ? 8 : 1); ++b) {
+            if (K % b) continue;
+            const int Kb = K / b;
+            const int tk = W.fmt == W_F16 ? 32 : 256;
+            if (Kb % tk) continue;
+            if (w > 1 && Kb < GROUP_K * w) continue;
+            const int span = GROUP_K * w;
+            const double eff = (double)Kb / ((Kb + span - 1) / span * span);
+            const double waves = std::min(2048.0, (double)strips * w * b);
+            const double score = waves * eff - 24.0 * (b - 1) - 8.0 * (w - 1);
+            if (score > best) { best = score; ksw = w; ksb = b; }
+        }
+    }
+}
+
+int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam) {
+    if (ps.empty() || ps.size() > GEMM_MAXP) throw RwkvError(RWKV_ERR_INVALID, "gemm: bad problem count");
+    GemmLaunch Lh{};
+    Lh.nprob = (int)ps.size();
+    Lh.T = T;
+    const int NT = T <= 16 ? 1 : T <= 32 ? 2 : 4;
+    Lh.rows_st = std::min(T, NT * 16);
+    int max_ksw = 1, max_kb = 0, blocks = 0, np = 1;
+    const size_t per_k0 = (size_t)Lh.rows_st * 2 * (hilo ? 2 : 1);
+    int max_w = 4;                                           // keep one X chunk (GROUP_K*ksw wide) under 48 KiB of LDS
+    while (max_w > 1 && (size_t)(GROUP_K * max_w + 8) * per_k0 > 48 * 1024) max_w >>= 1;
+    for (size_t i = 0; i < ps.size(); ++i) {
+        const ProbSpec &s = ps[i];
+        GemmProb &g = Lh.p[i];
+        int ksw, ksb;
+        choose_split(*s.W, s.partial, max_w, ksw, ksb);
+        g.W = s.W->data; g.S = s.W->scales; g.fmt = s.W->fmt; g.rows = s.W->rows; g.K = s.W->K;
+        g.xhi = s.x.hi + s.xoff; g.xlo = s.x.lo ? s.x.lo + s.xoff : nullptr; g.ldx = s.x.ld;
+        g.ksw = ksw; g.ksb = ksb;
+        g.nblk_strip = (s.W->rows / 16 + (4 / ksw) - 1) / (4 / ksw);
+        g.block_begin = blocks;
+        blocks += g.nblk_strip * ksb;
+        g.act = s.act; g.post = s.post; g.bias = s.bias; g.m0 = s.m0; g.m1 = s.m1; g.ldm = s.ldm;
+        g.out_f32 = s.out; g.ldo = s.ldo; g.partial_stride = pstride;
+        g.out_hi = s.oh.hi; g.out_lo = s.oh.lo; g.ldh = s.oh.ld;
+        max_ksw = std::max(max_ksw, ksw);
+        max_kb = std::max(max_kb, s.W->K / ksb);
+        if (s.partial) np = ksb;
+    }
+    Lh.total_blocks = blocks;
+    const int span = GROUP_K * max_ksw;
+    const int kfull = (max_kb + span - 1) / span * span;
+    const size_t per_k = (size_t)Lh.rows_st * 2 * (hilo ? 2 : 1);
+    int kc = kfull;
+    const size_t soft_cap = 32 * 1024;
+    if ((size_t)(kc + 8) * per_k > soft_cap) {
+        kc = (int)(soft_cap / per_k) / span * span;
+        if (kc < span) kc = span;
+    }
+    Lh.kc = kc;
+    launch(fam, [&] { launch_gemm(Lh, NT, hilo, s_main); });
+    return np;
+}
+
+// ------------------------------------------------------------------------------------------------
+// step planning (RnnInput::new(batches, token_chunk_size), run.rs:1132) — which tokens ride this call
+// ------------------------------------------------------------------------------------------------
+void rwkv_engine::plan_step(const rwkv_slot_input *in, StepPlan &pl) {
+    const int B = max_batch;
+    pl.slot_consumed.assign(B, 0);
+    pl.slot_out_begin.assign(B, 0);
+    pl.slot_out_rows.assign(B, 0);
+    // water-filling of the chunk budget across slots with pending tokens: short (decode) requests are
+    // never starved by a long prefill (any split is result-equivalent: slots are independent)
+    long budget = chunk;
+    std::vector<int> act;
+    for (int b = 0; b < B; ++b) if (in[b].n_tokens > 0) act.push_back(b);
+    while (budget > 0 && !act.empty()) {
+        const long share = std::max<long>(1, budget / (long)act.size());
+        std::vector<int> next;
+        for (int b : act) {
+            if (budget <= 0) break;
+            const long want = (long)in[b].n_tokens - pl.slot_consumed[b];
+            const long take = std::min({want, share, budget});
+            pl.slot_consumed[b] += (int)take;
+            budget -= take;
+            if (pl.slot_consumed[b] < (long)in[b].n_tokens) next.push_back(b);
+        }
+        act.swap(next);
+    }
+    pl.token.clear(); pl.slot.clear(); pl.prev.clear(); pl.last.clear();
+    pl.seq_slot.clear(); pl.seq_begin.clear(); pl.seq_len.clear(); pl.out_rows.clear();
+    for (int b = 0; b < B; ++b) {
+        const int n = pl.slot_consumed[b];
+        if (!n) continue;
+        const int begin = (int)pl.token.size();
+        pl.seq_slot.push_back(b); pl.seq_begin.push_back(begin); pl.seq_len.push_back(n);
+        pl.slot_out_begin[b] = (int)pl.out_rows.size();
+        const bool exhausted = (size_t)n == in[b].n_tokens;
+        for (int i = 0; i < n; ++i) {
+            pl.token.push_back((int)in[b].tokens[i]);
+            pl.slot.push_back(b);
+            pl.prev.push_back(i == 0 ? -1 : begin + i - 1);
+            pl.last.push_back(i == 0 ? begin + n - 1 : -1);
+            if (in[b].option == RWKV_OPTION_FULL || (exhausted && i == n - 1)) pl.out_rows.push_back(begin + i);
+        }
+        pl.slot_out_rows[b] = (int)pl.out_rows.size() - pl.slot_out_begin[b];
+    }
+    pl.T = (int)pl.token.size();
+    pl.n_seq = (int)pl.seq_slot.size();
+    pl.n_out = (int)pl.out_rows.size();
+}
+
+// meta layout in d_meta: token[chunk] slot[chunk] prev[chunk] last[chunk] out_rows[chunk] seq_slot[B] seq_begin[B] seq_len[B]
+RowMeta rwkv_engine::meta_ptrs(int) const {
+    RowMeta rm;
+    rm.token = d_meta;
+    rm.slot = d_meta + chunk;
+    rm.prev = d_meta + 2 * chunk;
+    rm.last = d_meta + 3 * chunk;
+    return rm;
+}
+
+void rwkv_engine::upload_plan(const StepPlan &pl) {
+    int *h = h_meta;
+    std::memcpy(h, pl.token.data(), pl.T * 4);
+    std::memcpy(h + chunk, pl.slot.data(), pl.T * 4);
+    std::memcpy(h + 2 * chunk, pl.prev.data(), pl.T * 4);
+    std::memcpy(h + 3 * chunk, pl.last.data(), pl.T * 4);
+    std::memcpy(h + 4 * chunk, pl.out_rows.data(), pl.n_out * 4);
+    std::memcpy(h + 5 * chunk, pl.seq_slot.data(), pl.n_seq * 4);
+    std::memcpy(h + 5 * chunk + max_batch, pl.seq_begin.data(), pl.n_seq * 4);
+    std::memcpy(h + 5 * chunk + 2 * max_batch, pl.seq_len.data(), pl.n_seq * 4);
+    HIP_CHECK(hipMemcpyAsync(d_meta, h, meta_cap * 4, hipMemcpyHostToDevice, s_main));
+}
+
+// ------------------------------------------------------------------------------------------------
+// the forward pass: enqueue every kernel of one step on s_main
+// ------------------------------------------------------------------------------------------------
+void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token) {
+    const int C = info.num_emb, F = info.num_hidden, V = info.num_vocab, H = info.num_head, L = info.num_layer;
+    RowMeta rm = meta_ptrs(T);
+    rm.token = d_token;
+    const int *seq_slot = d_meta + 5 * chunk, *seq_begin = seq_slot + max_batch, *seq_len = seq_begin + max_batch;
+    const int *out_rows = d_meta + 4 * chunk;
+
+    float *cur = xA, *oth = xB;
+    int np = 0;
+    {
+        EmbedArgs e{emb, ln0w, ln0b, d_token, cur, C, V};
+        launch(FAM_ROW, [&] { launch_embed(e, T, s_main); });
+    }
+    for (int l = 0; l < L; ++l) {
+        const LayerW &w = layers[l];
+        // ---- time mix
+        LnShiftArgs a{};
+        a.x_in = cur; a.x_out = oth; a.P = P; a.np = np; a.pstride = pstride;
+        a.lnw = w.ln1w; a.lnb = w.ln1b;
+        a.sx = sxa + (long)l * C; a.sx_slot_stride = sx_slot_stride;
+        a.rm = rm; a.C = C; a.ldh = C;
+        std::vector<ProbSpec> ps;
+        auto prob = [&](const DMat *W, const Opd &x, int act, float *out, int ldo) {
+            ProbSpec s; s.W = W; s.x = x; s.act = act; s.out = out; s.ldo = ldo; return s;
+        };
+        if (info.version == 5) {
+            a.mode = 0; a.nmix = 4;
+            for (int i = 0; i < 4; ++i) { a.mu[i] = w.mu[i]; a.ohi[i] = opA[i].hi; a.olo[i] = opA[i].lo; }
+            launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
+            ps = {prob(w.Wk, opA[0], ACT_NONE, fk, C), prob(w.Wv, opA[1], ACT_NONE, fv, C),
+                  prob(w.Wr, opA[2], ACT_NONE, fr, C), prob(w.Wg, opA[3], ACT_SILU, fg, C)};
+            gemm(ps, T, FAM_GEMM);
+        } else if (info.version == 6) {
+            a.mode = 1; a.nmix = 1; a.mu[0] = w.mu[0]; a.ohi[0] = opA[0].hi; a.olo[0] = opA[0].lo;
+            a.xx_out = xx; a.dx_out = dx;
+            launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
+            {   // m = tanh(W1 z)  ->  operand [T][5*Dm]
+                ProbSpec s = prob(w.W1, opA[0], ACT_TANH, nullptr, 0);
+                s.oh = opM;
+                ps = {s};
+                gemm(ps, T, FAM_GEMM);
+            }
+            ps.clear();
+            for (int c = 0; c < 5; ++c) {   // x_c = xx + dx * (mu_c + W2_c m_c),  c in (w,k,v,r,g)
+                ProbSpec s = prob(w.W2[c], opM, ACT_NONE, nullptr, 0);
+                s.xoff = c * Dm;
+                s.bias = w.mu[1 + c]; s.post = POST_MIX; s.m0 = xx; s.m1 = dx; s.ldm = C;
+                s.oh = opA[1 + c];
+                ps.push_back(s);
+            }
+            gemm(ps, T, FAM_GEMM);
+            ps = {prob(w.Wk, opA[2], ACT_NONE, fk, C), prob(w.Wv, opA[3], ACT_NONE, fv, C),
+                  prob(w.Wr, opA[4], ACT_NONE, fr, C), prob(w.Wg, opA[5], ACT_SILU, fg, C),
+                  prob(w.D1, opA[1], ACT_TANH, ftd, Dd)};
+            gemm(ps, T, FAM_GEMM);
+        } else {
+            a.mode = 1; a.nmix = 6;
+            for (int i = 0; i < 6; ++i) { a.mu[i] = w.mu[i]; a.ohi[i] = opA[i].hi; a.olo[i] = opA[i].lo; }
+            launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
+            // opA: 0=r 1=w 2=k 3=v 4=a 5=g
+            ps = {prob(w.Wr, opA[0], ACT_NONE, fr, C), prob(w.Wk, opA[2], ACT_NONE, fk, C), prob(w.Wv, opA[3], ACT_NONE, fv, C)};
+            { ProbSpec s = prob(w.w1, opA[1], ACT_TANH, nullptr, 0); s.oh = opL[0]; ps.push_back(s); }
+            { ProbSpec s = prob(w.a1, opA[4], ACT_NONE, nullptr, 0); s.oh = opL[1]; ps.push_back(s); }
+            { ProbSpec s = prob(w.g1, opA[5], ACT_SIGMOID, nullptr, 0); s.oh = opL[2]; ps.push_back(s); }
+            if (l > 0) { ProbSpec s = prob(w.v1, opA[3], ACT_NONE, nullptr, 0); s.oh = opL[3]; ps.push_back(s); }
+            gemm(ps, T, FAM_GEMM);
+            ps.clear();
+            { ProbSpec s = prob(w.w2, opL[0], ACT_DECAY7, fw7, C); s.bias = w.w0; ps.push_back(s); }
+            { ProbSpec s = prob(w.a2, opL[1], ACT_SIGMOID, fa7, C); s.bias = w.a0; ps.push_back(s); }
+            { ProbSpec s = prob(w.g2, opL[2], ACT_NONE, fg, C); ps.push_back(s); }
+            if (l > 0) { ProbSpec s = prob(w.v2, opL[3], ACT_SIGMOID, fvg7, C); s.bias = w.v0; ps.push_back(s); }
+            gemm(ps, T, FAM_GEMM);
+        }
+        std::swap(cur, oth);
+        {
+            WkvArgs k{};
+            k.version = info.version; k.H = H; k.C = C; k.n_seq = n_seq;
+            k.seq_slot = seq_slot; k.seq_begin = seq_begin; k.seq_len = seq_len;
+            k.state = wkv + (long)l * H * 4096; k.slot_stride = wkv_slot_stride;
+            k.r = fr; k.k = fk; k.v = fv; k.g = fg;
+            k.wdec_or_decay = w.wdec; k.u = w.u; k.td = ftd; k.D2 = w.D2; k.Dd = Dd;
+            k.w7 = fw7; k.a7 = fa7; k.vg7 = fvg7; k.k_k = w.k_k; k.k_a = w.k_a; k.r_k = w.r_k;
+            k.v_first = vfirst; k.layer = l;
+            k.lnx_w = w.lnxw; k.lnx_b = w.lnxb;
+            k.yhi = opY.hi; k.ylo = opY.lo; k.ldh = C;
+            launch(FAM_WKV, [&] { launch_wkv(k, s_main); });
+        }
+        {
+            ProbSpec s = prob(w.Wo, opY, ACT_NONE, P, C);
+            s.partial = true;
+            ps = {s};
+            np = gemm(ps, T, FAM_GEMM);
+        }
+        // ---- channel mix
+        LnShiftArgs f{};
+        f.x_in = cur; f.x_out = oth; f.P = P; f.np = np; f.pstride = pstride;
+        f.lnw = w.ln2w; f.lnb = w.ln2b;
+        f.sx = sxf + (long)l * C; f.sx_slot_stride = sx_slot_stride;
+        f.rm = rm; f.C = C; f.ldh = C;
+        f.mode = info.version == 5 ? 0 : 1;
+        f.nmix = info.version == 7 ? 1 : 2;
+        for (int i = 0; i < f.nmix; ++i) { f.mu[i] = w.fmu[i]; f.ohi[i] = opA[i].hi; f.olo[i] = opA[i].lo; }
+        launch(FAM_ROW, [&] { launch_ln_shift(f, T, s_main); });
+        std::swap(cur, oth);
+        {
+            ProbSpec s = prob(w.Fk, opA[0], ACT_RELU2, nullptr, 0);
+            s.oh = opK;
+            ps = {s};
+            if (info.version != 7) ps.push_back(prob(w.Fr, opA[1], ACT_SIGMOID, frr, C));
+            gemm(ps, T, FAM_GEMM);
+        }
+        {
+            ProbSpec s = prob(w.Fv, opK, ACT_NONE, P, C);
+            s.partial = true;
+            if (info.version != 7) { s.post = POST_MUL; s.m0 = frr; s.ldm = C; }
+            ps = {s};
+            np = gemm(ps, T, FAM_GEMM);
+        }
+    }
+    if (n_out > 0) {
+        LnOutArgs o{cur, P, np, pstride, lnow, lnob, out_rows, opO.hi, opO.lo, C, C};
+        launch(FAM_ROW, [&] { launch_ln_out(o, n_out, s_main); });
+        std::vector<ProbSpec> ps(1);
+        ps[0].W = head; ps[0].x = opO; ps[0].out = logits; ps[0].ldo = V;
+        gemm(ps, n_out, FAM_HEAD);
+    } else if (np > 0) {
+        // nothing consumes the pending partial sums: fine, the residual stream dies with the step
+    }
+}
+
+void rwkv_engine::infer(const rwkv_slot_input *in, rwkv_slot_output *out) {
+    HIP_CHECK(hipSetDevice(device));
+    for (int b = 0; b < max_batch; ++b) {
+        out[b].n_rows = 0;
+        out[b].n_consumed = 0;
+        if (in[b].n_tokens && !in[b].tokens) throw RwkvError(RWKV_ERR_INVALID, "slot has n_tokens>0 but tokens==NULL");
+        if (in[b].option != RWKV_OPTION_LAST && in[b].option != RWKV_OPTION_FULL)
+            throw RwkvError(RWKV_ERR_INVALID, "bad RnnOption");
+    }
+    StepPlan pl;
+    plan_step(in, pl);
+    if (pl.T == 0) return;
+    for (int b = 0; b < max_batch; ++b)
+        if (pl.slot_out_rows[b] > 0 && (!out[b].logits || out[b].logits_capacity_rows < (size_t)pl.slot_out_rows[b]))
+            throw RwkvError(RWKV_ERR_INVALID, "logits buffer too small for slot " + std::to_string(b));
+    upload_plan(pl);
+    const uint64_t key = ((uint64_t)pl.T << 40) | ((uint64_t)pl.n_seq << 20) | (uint64_t)pl.n_out;
+    if (use_graphs && !profiling) {
+        auto it = graphs.find(key);
+        if (it == graphs.end()) {
+            hipGraph_t g = nullptr;
+            HIP_CHECK(hipStreamBeginCapture(s_main, hipStreamCaptureModeThreadLocal));
+            try {
+                run_layers(pl.T, pl.n_seq, pl.n_out, d_meta);
+            } catch (...) {
+                (void)hipStreamEndCapture(s_main, &g);
+                if (g) (void)hipGraphDestroy(g);
+                throw;
+            }
+            HIP_CHECK(hipStreamEndCapture(s_main, &g));
+            GraphEntry ge;
+            HIP_CHECK(hipGraphInstantiate(&ge.exec, g, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(g));
+            if (graphs.size() > 64) {
+                for (auto &o : graphs) (void)hipGraphExecDestroy(o.second.exec);
+                graphs.clear();
+            }
+            it = graphs.emplace(key, ge).first;
+        }
+        HIP_CHECK(hipGraphLaunch(it->second.exec, s_main));
+    } else {
+        run_layers(pl.T, pl.n_seq, pl.n_out, d_meta);
+    }
+    const int V = info.num_vocab;
+    if (pl.n_out > 0)
+        HIP_CHECK(hipMemcpyAsync(logits_host, logits, (size_t)pl.n_out * V * 4, hipMemcpyDeviceToHost, s_main));
+    HIP_CHECK(hipStreamSynchronize(s_main));
+    for (int b = 0; b < max_batch; ++b) {
+        out[b].n_consumed = (size_t)pl.slot_consumed[b];
+        out[b].n_rows = (size_t)pl.slot_out_rows[b];
+        if (pl.slot_out_rows[b] > 0)
+            std::memcpy(out[b].logits, logits_host + (size_t)pl.slot_out_begin[b] * V, (size_t)pl.slot_out_rows[b] * V * 4);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *rwkv_last_error(void) { return g_err.c_str(); }
+int32_t rwkv_abi_version(void) { return RWKV_ABI_VERSION; }
+
+int32_t rwkv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+rwkv_status rwkv_device_name(int32_t index, char *buf, size_t buf_len) {
+    return guard([&] {
+        if (!buf || !buf_len) throw RwkvError(RWKV_ERR_INVALID, "null buffer");
+        hipDeviceProp_t p;
+        HIP_CHECK(hipGetDeviceProperties(&p, index));
+        std::snprintf(buf, buf_len, "%s (%s, HIP)", p.name, p.gcnArchName);
+    });
+}
+
+rwkv_status rwkv_model_info_from_st(const uint8_t *st_bytes, size_t st_len, rwkv_model_info *out) {
+    return guard([&] {
+        if (!out) throw RwkvError(RWKV_ERR_INVALID, "null out");
+        SafeTensors st = SafeTensors::parse(st_bytes, st_len);
+        *out = detect_info(st);
+    });
+}
+
+rwkv_status rwkv_engine_create(const rwkv_load_desc *desc, rwkv_engine **out) {
+    return guard([&] {
+        if (!desc || !out || !desc->st_bytes) throw RwkvError(RWKV_ERR_INVALID, "null argument");
+        *out = nullptr;
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+            throw RwkvError(RWKV_ERR_DEVICE, "no HIP device: librwkv_hip has no CPU fallback");
+        int dev = desc->adapter >= 0 ? desc->adapter : 0;   // Auto / Economical: every MI355X is identical -> device 0
+        if (dev >= n) throw RwkvError(RWKV_ERR_DEVICE, "adapter index out of range (ContextError::RequestAdapterFailed)");
+        HIP_CHECK(hipSetDevice(dev));
+        hipDeviceProp_t p;
+        HIP_CHECK(hipGetDeviceProperties(&p, dev));
+        if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
+            throw RwkvError(RWKV_ERR_DEVICE, std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
+        std::unique_ptr<rwkv_engine> e(new rwkv_engine());
+        e->device = dev;
+        e->load(*desc);
+        *out = e.release();
+    });
+}
+
+void rwkv_engine_destroy(rwkv_engine *e) { delete e; }
+
+rwkv_status rwkv_engine_info(const rwkv_engine *e, rwkv_model_info *out) {
+    return guard([&] {
+        if (!e || !out) throw RwkvError(RWKV_ERR_INVALID, "null argument");
+        *out = e->info;
+    });
+}
+int32_t rwkv_engine_device(const rwkv_engine *e) { return e ? e->device : -1; }
+int32_t rwkv_engine_max_batch(const rwkv_engine *e) { return e ? e->max_batch : 0; }
+uint64_t rwkv_engine_weight_bytes(const rwkv_engine *e) { return e ? e->weight_bytes : 0; }
+
+rwkv_status rwkv_infer(rwkv_engine *e, const rwkv_slot_input *in, rwkv_slot_output *out) {
+    return guard([&] {
+        if (!e || !in || !out) throw RwkvError(RWKV_ERR_INVALID, "null argument");
+        e->infer(in, out);
+    });
+}
+
+const char *rwkv_profile_family_name(int32_t f) { return f >= 0 && f < RWKV_PROFILE_FAMILIES ? kFamilyNames[f] : ""; }
+
+rwkv_status rwkv_profile_infer(rwkv_engine *e, const rwkv_slot_input *in, rwkv_slot_output *out, float *ms, int32_t *launches) {
+    return guard([&] {
+        if (!e || !in || !out || !ms) throw RwkvError(RWKV_ERR_INVALID, "null argument");
+        std::fill(e->prof_ms, e->prof_ms + RWKV_PROFILE_FAMILIES, 0.f);
+        std::fill(e->prof_n, e->prof_n + RWKV_PROFILE_FAMILIES, 0);
+        e->profiling = true;
+        try {
+            e->infer(in, out);
+        } catch (...) {
+            e->profiling = false;
+            throw;
+        }
+        e->profiling = false;
+        for (int i = 0; i < RWKV_PROFILE_FAMILIES; ++i) {
+            ms[i] = e->prof_ms[i];
+            if (launches) launches[i] = e->prof_n[i];
+        }
+    });
+}
+
+// ---- state ---------------------------------------------------------------------------------------
+size_t rwkv_state_len(const rwkv_engine *e) { return e ? (size_t)e->info.num_layer * 66 * e->info.num_emb : 0; }
+void rwkv_state_shape(const rwkv_engine *e, size_t shape[4]) {
+    if (!e || !shape) return;
+    shape[0] = (size_t)e->info.num_emb; shape[1] = 66; shape[2] = (size_t)e->info.num_layer; shape[3] = 1;
+}
+rwkv_status rwkv_state_init(const rwkv_engine *e, float *dst) {
+    return guard([&] {
+        if (!e || !dst) throw RwkvError(RWKV_ERR_INVALID, "null argument");
+        std::memset(dst, 0, rwkv_state_len(e) * 4);         // v5/v6/v7 initial state is all-zero
+    });
+}
+static StatePackArgs pack_args(rwkv_engine *e, float *sxa, float *sxf, float *wkv, int to_slab, int layer_only) {
+    StatePackArgs a{};
+    a.slab = e->slab_dev; a.sxa = sxa; a.sxf = sxf; a.wkv = wkv;
+    a.L = e->info.num_layer; a.C = e->info.num_emb; a.H = e->info.num_head;
+    a.transposed = e->info.version != 7; a.to_slab = to_slab; a.layer_only = layer_only;
+    return a;
+}
+static void check_slot(const rwkv_engine *e, int slot) {
+    if (!e) throw RwkvError(RWKV_ERR_INVALID, "null engine");
+    if (slot < 0 || slot >= e->max_batch) throw RwkvError(RWKV_ERR_INVALID, "slot out of range");
+}
+rwkv_status rwkv_state_load(rwkv_engine *e, int32_t slot, const float *src) {
+    return guard([&] {
+        check_slot(e, slot);
+        if (!src) throw RwkvError(RWKV_ERR_INVALID, "null src");
+        HIP_CHECK(hipSetDevice(e->device));
+        const size_t n = rwkv_state_len(e);
+        std::memcpy(e->slab_host, src, n * 4);
+        HIP_CHECK(hipMemcpyAsync(e->slab_dev, e->slab_host, n * 4, hipMemcpyHostToDevice, e->s_main));
+        launch_state_pack(pack_args(e, e->sxa + slot * e->sx_slot_stride, e->sxf + slot * e->sx_slot_stride,
+                                    e->wkv + slot * e->wkv_slot_stride, 0, -1), e->s_main);
+        HIP_CHECK(hipStreamSynchronize(e->s_main));
+    });
+}
+rwkv_status rwkv_state_back(rwkv_engine *e, int32_t slot, float *dst) {
+    return guard([&] {
+        check_slot(e, slot);
+        if (!dst) throw RwkvError(RWKV_ERR_INVALID, "null dst");
+        HIP_CHECK(hipSetDevice(e->device));
+        const size_t n = rwkv_state_len(e);
+        launch_state_pack(pack_args(e, e->sxa + slot * e->sx_slot_stride, e->sxf + slot * e->sx_slot_stride,
+                                    e->wkv + slot * e->wkv_slot_stride, 1, -1), e->s_main);
+        HIP_CHECK(hipMemcpyAsync(e->slab_host, e->slab_dev, n * 4, hipMemcpyDeviceToHost, e->s_main));
+        HIP_CHECK(hipStreamSynchronize(e->s_main));
+        std::memcpy(dst, e->slab_host, n * 4);
+    });
+}
+rwkv_status rwkv_state_back_layer(rwkv_engine *e, int32_t slot, int32_t layer, float *dst) {
+    return guard([&] {
+        check_slot(e, slot);
+        if (!dst || layer < 0 || layer >= e->info.num_layer) throw RwkvError(RWKV_ERR_INVALID, "bad layer/dst");
+        HIP_CHECK(hipSetDevice(e->device));
+        const size_t n = (size_t)64 * e->info.num_emb;
+        launch_state_pack(pack_args(e, e->sxa + slot * e->sx_slot_stride, e->sxf + slot * e->sx_slot_stride,
+                                    e->wkv + slot * e->wkv_slot_stride, 1, layer), e->s_main);
+        HIP_CHECK(hipMemcpyAsync(e->slab_host, e->slab_dev, n * 4, hipMemcpyDeviceToHost, e->s_main));
+        HIP_CHECK(hipStreamSynchronize(e->s_main));
+        std::memcpy(dst, e->slab_host, n * 4);
+    });
+}
+rwkv_status rwkv_state_read(rwkv_engine *e, int32_t slot, rwkv_dstate **snap) {
+    return guard([&] {
+        check_slot(e, slot);
+        if (!snap) throw RwkvError(RWKV_ERR_INVALID, "null snap");
+        HIP_CHECK(hipSetDevice(e->device));
+        std::unique_ptr<rwkv_dstate> s(new rwkv_dstate());
+        s->device = e->device;
+        const size_t nsx = (size_t)e->sx_slot_stride * 4, nw = (size_t)e->wkv_slot_stride * 4;
+        HIP_CHECK(hipMalloc((void **)&s->sxa, nsx));
+        HIP_CHECK(hipMalloc((void **)&s->sxf, nsx));
+        HIP_CHECK(hipMalloc((void **)&s->wkv, nw));
+        HIP_CHECK(hipMemcpyAsync(s->sxa, e->sxa + slot * e->sx_slot_stride, nsx, hipMemcpyDeviceToDevice, e->s_main));
+        HIP_CHECK(hipMemcpyAsync(s->sxf, e->sxf + slot * e->sx_slot_stride, nsx, hipMemcpyDeviceToDevice, e->s_main));
+        HIP_CHECK(hipMemcpyAsync(s->wkv, e->wkv + slot * e->wkv_slot_stride, nw, hipMemcpyDeviceToDevice, e->s_main));
+        HIP_CHECK(hipStreamSynchronize(e->s_main));
+        *snap = s.release();
+    });
+}
+rwkv_status rwkv_state_write(rwkv_engine *e, int32_t slot, const rwkv_dstate *s) {
+    return guard([&] {
+        check_slot(e, slot);
+        if (!s) throw RwkvError(RWKV_ERR_INVALID, "null snap");
+        HIP_CHECK(hipSetDevice(e->device));
+        const size_t nsx = (size_t)e->sx_slot_stride * 4, nw = (size_t)e->wkv_slot_stride * 4;
+        HIP_CHECK(hipMemcpyAsync(e->sxa + slot * e->sx_slot_stride, s->sxa, nsx, hipMemcpyDeviceToDevice, e->s_main));
+        HIP_CHECK(hipMemcpyAsync(e->sxf + slot * e->sx_slot_stride, s->sxf, nsx, hipMemcpyDeviceToDevice, e->s_main));
+        HIP_CHECK(hipMemcpyAsync(e->wkv + slot * e->wkv_slot_stride, s->wkv, nw, hipMemcpyDeviceToDevice, e->s_main));
+        HIP_CHECK(hipStreamSynchronize(e->s_main));
+    });
+}
+void rwkv_dstate_free(rwkv_dstate *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipFree(s->sxa); (void)hipFree(s->sxf); (void)hipFree(s->wkv);
+    delete s;
+}
+
+rwkv_status rwkv_read_init_state(const rwkv_engine *e, const uint8_t *st_bytes, size_t st_len, float *dst) {
+    return guard([&] {
+        if (!e || !dst) throw RwkvError(RWKV_ERR_INVALID, "null argument");
+        SafeTensors st = SafeTensors::parse(st_bytes, st_len);
+        const int L = e->info.num_layer, C = e->info.num_emb, H = e->info.num_head, N = 64;
+        if (!st.find("blocks.0.att.time_state")) throw RwkvError(RWKV_ERR_NO_STATE, "no `time_state` tensors in file");
+        std::memset(dst, 0, rwkv_state_len(e) * 4);
+        for (int l = 0; l < L; ++l) {
+            const StTensor &t = st.get("blocks." + std::to_string(l) + ".att.time_state");
+            if (t.dtype != "F16" || t.numel() != (int64_t)H * N * N) throw RwkvError(RWKV_ERR_FORMAT, "bad time_state tensor");
+            const _Float16 *ts = (const _Float16 *)t.data;     // stored [H][j][i] (converter transposed the last two dims)
+            float *rows = dst + ((size_t)l * 66 + 1) * C;
+            for (int h = 0; h < H; ++h)
+                for (int j = 0; j < N; ++j)
+                    for (int i = 0; i < N; ++i) rows[(size_t)i * C + h * N + j] = (float)ts[((size_t)h * N + j) * N + i];
+        }
+    });
+}
+
+// ---- softmax (second caller thread, own stream) ---------------------------------------------------
+rwkv_status rwkv_softmax(rwkv_engine *e, const float *const *in, float *const *out, size_t n_rows) {
+    return guard([&] {
+        if (!e || (n_rows && (!in || !out))) throw RwkvError(RWKV_ERR_INVALID, "null argument");
+        if (!n_rows) return;
+        HIP_CHECK(hipSetDevice(e->device));
+        const size_t V = (size_t)e->info.num_vocab;
+        static std::mutex mu;                                  // one softmax task per engine by contract; guard the staging
+        std::lock_guard<std::mutex> lk(mu);
+        if (n_rows > e->soft_rows_cap) {
+            if (e->soft_host) (void)hipHostFree(e->soft_host);
+            e->soft_host = nullptr;
+            const size_t cap = std::max<size_t>(n_rows, (size_t)e->max_batch);
+            e->soft_in = e->dalloc<float>(cap * V);
+            e->soft_out = e->dalloc<float>(cap * V);
+            HIP_CHECK(hipHostMalloc((void **)&e->soft_host, cap * V * 4, hipHostMallocDefault));
+            e->soft_rows_cap = cap;
+        }
+        for (size_t r = 0; r < n_rows; ++r) {
+            if (!in[r] || !out[r]) throw RwkvError(RWKV_ERR_INVALID, "null row");
+            std::memcpy(e->soft_host + r * V, in[r], V * 4);
+        }
+        HIP_CHECK(hipMemcpyAsync(e->soft_in, e->soft_host, n_rows * V * 4, hipMemcpyHostToDevice, e->s_soft));
+        launch_softmax(e->soft_in, e->soft_out, (int)n_rows, (int)V, e->s_soft);
+        HIP_CHECK(hipMemcpyAsync(e->soft_host, e->soft_out, n_rows * V * 4, hipMemcpyDeviceToHost, e->s_soft));
+        HIP_CHECK(hipStreamSynchronize(e->s_soft));
+        for (size_t r = 0; r < n_rows; ++r) std::memcpy(out[r], e->soft_host + r * V, V * 4);
+    });
+}
+
+// ---- device-resident greedy decode ----------------------------------------------------------------
+rwkv_status rwkv_decode_greedy(rwkv_engine *e, int32_t n_slots, const uint32_t *first_tokens, int32_t n_steps,
+                               uint32_t *out_tokens, float *elapsed_ms) {
+    return guard([&] {
+        if (!e || !first_tokens || !out_tokens || n_slots <= 0 || n_slots > e->max_batch || n_slots > e->chunk || n_steps <= 0)
+            throw RwkvError(RWKV_ERR_INVALID, "bad arguments");
+        HIP_CHECK(hipSetDevice(e->device));
+        StepPlan pl;
+        std::vector<rwkv_slot_input> in(e->max_batch);
+        std::vector<uint32_t> tk(first_tokens, first_tokens + n_slots);
+        for (int b = 0; b < e->max_batch; ++b) {
+            in[b] = rwkv_slot_input{b < n_slots ? &tk[b] : nullptr, (size_t)(b < n_slots ? 1 : 0), RWKV_OPTION_LAST, 0};
+        }
+        e->plan_step(in.data(), pl);
+        e->upload_plan(pl);
+        const size_t need = (size_t)n_steps * n_slots;
+        if (need > e->hist_cap) {
+            e->d_hist = e->dalloc<int>(need);
+            e->hist_cap = need;
+        }
+        HIP_CHECK(hipMemcpyAsync(e->d_tok_feedback, tk.data(), n_slots * 4, hipMemcpyHostToDevice, e->s_main));
+        HIP_CHECK(hipStreamSynchronize(e->s_main));
+        // one graph = one decode step + arg-max feeding the next step's token ids on the device
+        hipGraph_t g = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIP_CHECK(hipStreamBeginCapture(e->s_main, hipStreamCaptureModeThreadLocal));
+        try {
+            e->run_layers(pl.T, pl.n_seq, pl.n_out, e->d_tok_feedback);
+            launch_argmax(e->logits, n_slots, e->info.num_vocab, e->d_tok_feedback, e->s_main);
+        } catch (...) {
+            (void)hipStreamEndCapture(e->s_main, &g);
+            if (g) (void)hipGraphDestroy(g);
+            throw;
+        }
+        HIP_CHECK(hipStreamEndCapture(e->s_main, &g));
+        HIP_CHECK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
+        HIP_CHECK(hipGraphDestroy(g));
+        struct ExecGuard { hipGraphExec_t x; ~ExecGuard() { (void)hipGraphExecDestroy(x); } } eg{exec};
+        HIP_CHECK(hipEventRecord(e->ev0, e->s_main));
+        for (int s = 0; s < n_steps; ++s) {
+            HIP_CHECK(hipGraphLaunch(exec, e->s_main));
+            HIP_CHECK(hipMemcpyAsync(e->d_hist + (size_t)s * n_slots, e->d_tok_feedback, n_slots * 4, hipMemcpyDeviceToDevice, e->s_main));
+        }
+        HIP_CHECK(hipEventRecord(e->ev1, e->s_main));
+        HIP_CHECK(hipEventSynchronize(e->ev1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        if (elapsed_ms) *elapsed_ms = ms;
+        HIP_CHECK(hipMemcpy(out_tokens, e->d_hist, need * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+}  // extern "C"

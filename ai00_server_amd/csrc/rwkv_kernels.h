@@ -1,0 +1,168 @@
+// rwkv_kernels.h — host-visible launch descriptors for the gfx950 kernels in rwkv_kernels.hip.
+// Pure POD + launch prototypes; no HIP types except hipStream_t.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rwkv {
+
+enum WFmt : int { W_F16 = 0, W_INT8 = 1, W_NF4 = 2 };
+enum Act : int { ACT_NONE = 0, ACT_TANH = 1, ACT_SIGMOID = 2, ACT_RELU2 = 3, ACT_SILU = 4, ACT_DECAY7 = 5 };
+enum Post : int { POST_NONE = 0, POST_MUL = 1, POST_MIX = 2 };
+
+constexpr int TILE_ROWS = 16;        // output rows per strip (MFMA 16x16x32 M)
+constexpr int KSTEP = 32;            // K per MFMA
+constexpr int GROUP_K = 256;         // K covered by one register group of one wave (8 MFMA k-steps)
+constexpr int GEMM_THREADS = 256;    // 4 waves
+constexpr int GEMM_MAXP = 8;
+constexpr int INT8_BLOCK = 128;
+constexpr int NF4_BLOCK = 64;
+
+// A weight matrix W[rows][K] resident in HBM in the pre-tiled MFMA-A layout:
+//   fp16: tile = 16 rows x 32 k  = 1 KiB ; lane l holds row (l&15), k = kt*32 + (l>>4)*8 + [0,8)
+//   int8: tile = 16 rows x 64 k  = 1 KiB ; lane bytes [0,8) -> k-step 0, [8,16) -> k-step 1
+//   nf4 : tile = 16 rows x 128 k = 1 KiB ; lane byte m: k-step m/4, e = (m%4)*2 + {lo,hi nibble}
+// tiles of one strip are contiguous along K: tile index = strip*KT + kt.
+struct DMat {
+    const void *data = nullptr;     // tiled payload
+    const void *scales = nullptr;   // int8: half2{a,b} [strip][K/128][16]; nf4: half [strip][K/64][16]
+    int fmt = W_F16;
+    int rows = 0;                   // multiple of 16
+    int K = 0;                      // multiple of 32 (fp16) / 128 (int8, nf4)
+    uint64_t bytes = 0;             // payload + scales, for roofline accounting
+};
+
+struct GemmProb {
+    const void *W;
+    const void *S;
+    const _Float16 *xhi;            // activation operand [T][ldx] (f16, hi part)
+    const _Float16 *xlo;            // lo part (may be null when !HILO)
+    int fmt, rows, K, ldx;
+    int ksw;                        // waves splitting K inside a block (1,2,4)
+    int ksb;                        // blocks splitting K (partials written, linear epilogue only)
+    int nblk_strip;                 // blocks per K-slice = ceil(strips / (4/ksw))
+    int block_begin;                // first block of this problem in the launch
+    // epilogue:  v = act(acc + bias[row]);  POST_MUL: v *= m0[t][row];  POST_MIX: v = m0 + m1 * v
+    int act, post;
+    const float *bias;
+    const float *m0, *m1;
+    int ldm;
+    float *out_f32;                 // [T][ldo] (+ kb*partial_stride when ksb>1)
+    int ldo;
+    long partial_stride;
+    _Float16 *out_hi, *out_lo;      // operand output [T][ldh]
+    int ldh;
+};
+
+struct GemmLaunch {
+    GemmProb p[GEMM_MAXP];
+    int nprob;
+    int T;                          // activation rows
+    int kc;                         // K per staged X chunk (multiple of GROUP_K * ksw for every problem)
+    int rows_st;                    // rows staged per pass (= min(T, NT*16))
+    int total_blocks;
+};
+
+void launch_gemm(const GemmLaunch &L, int NT, bool hilo, hipStream_t s);
+
+struct RowMeta {                    // device arrays, one entry per row of this step
+    const int *token;               // token id
+    const int *slot;                // state slot
+    const int *prev;                // previous row of the same slot in this step, or -1 (-> state)
+    const int *last;                // for first rows: last row of the slot in this step; else -1
+};
+
+struct LnShiftArgs {
+    const float *x_in;
+    float *x_out;                   // x_in + sum of partials (ping-pong residual stream)
+    const float *P;                 // partials [np][pstride]
+    int np;
+    long pstride;
+    const float *lnw, *lnb;
+    float *sx;                      // token-shift state for this layer: sx + slot*sx_slot_stride
+    long sx_slot_stride;
+    RowMeta rm;
+    int mode;                       // 0: V5  op = xx*mu + prev*(1-mu);  1: V6/V7 op = xx + (prev-xx)*mu
+    int nmix;
+    const float *mu[6];
+    _Float16 *ohi[6];
+    _Float16 *olo[6];
+    int ldh;
+    float *xx_out, *dx_out;         // optional fp32 copies (V6 time-mix LoRA epilogue needs them)
+    int C;
+};
+void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s);
+
+struct EmbedArgs {
+    const _Float16 *emb;            // raw [V][C]
+    const float *lnw, *lnb;         // ln0
+    const int *token;
+    float *x;
+    int C, V;
+};
+void launch_embed(const EmbedArgs &a, int T, hipStream_t s);
+
+struct LnOutArgs {
+    const float *x_in;
+    const float *P;
+    int np;
+    long pstride;
+    const float *lnw, *lnb;
+    const int *out_rows;            // rows to emit (compacted)
+    _Float16 *ohi, *olo;
+    int ldh, C;
+};
+void launch_ln_out(const LnOutArgs &a, int n_out, hipStream_t s);
+
+struct WkvArgs {
+    int version;                    // 5, 6, 7
+    int H, C;
+    int n_seq;                      // active slots in this step
+    const int *seq_slot;            // [n_seq]
+    const int *seq_begin;           // [n_seq] first row
+    const int *seq_len;             // [n_seq]
+    float *state;                   // internal WKV state of this layer: state + slot*slot_stride + h*4096
+    long slot_stride;
+    const float *r, *k, *v;         // [T][C]
+    const float *g;                 // [T][C] gate (v5/v6: silu applied; v7: g)
+    // v5: wdec = precomputed exp(-exp(time_decay)) [C]; v6: time_decay [C] + td [T][Dd] + D2 fp16 [C][Dd]
+    const float *wdec_or_decay;
+    const float *u;                 // time_first [C] (v5/v6)
+    const float *td;
+    const _Float16 *D2;
+    int Dd;
+    // v7
+    const float *w7, *a7, *vg7;     // [T][C]: decay, a, value-gate
+    const float *k_k, *k_a, *r_k;   // [C]
+    float *v_first;                 // [T][C]; layer 0 writes, others read
+    int layer;
+    const float *lnx_w, *lnx_b;
+    _Float16 *yhi, *ylo;
+    int ldh;
+};
+void launch_wkv(const WkvArgs &a, hipStream_t s);
+
+// ---- state slab <-> internal layout ---------------------------------------------------
+struct StatePackArgs {
+    float *slab;                    // public [L][N+2][C]
+    float *sxa, *sxf;               // internal [L][C] of this slot
+    float *wkv;                     // internal [L][H][64][64] of this slot (T[p=value][q=key])
+    int L, C, H;
+    int transposed;                 // 1 for v5/v6 (public S[i=key][j=value]), 0 for v7
+    int to_slab;                    // 1: internal -> slab, 0: slab -> internal
+    int layer_only;                 // >=0: only this layer's WKV rows, slab points at [N][C]
+};
+void launch_state_pack(const StatePackArgs &a, hipStream_t s);
+
+void launch_softmax(const float *in, float *out, int n_rows, int V, hipStream_t s);
+void launch_argmax(const float *logits, int n_rows, int V, int *out_tok, hipStream_t s);
+
+// ---- load-time: raw fp16 [rows][K] -> tiled / quantised --------------------------------
+void launch_tile_f16(const _Float16 *raw, int rows_valid, int rows, int K, void *out, hipStream_t s);
+void launch_quant_int8(const _Float16 *raw, int rows, int K, void *out, void *scales, hipStream_t s);
+void launch_quant_nf4(const _Float16 *raw, int rows, int K, void *out, void *scales, hipStream_t s);
+void launch_f16_to_f32(const _Float16 *in, float *out, long n, int op, hipStream_t s); // op 0: copy, 1: exp(-exp(x))
+// W[rows][K] (fp16 raw) += alpha * B[rows][r] * A^T  (A stored [K][r]) — LoRA blend, fp32 math
+void launch_lora_blend(_Float16 *W, const _Float16 *B, const _Float16 *A, int rows, int K, int r, float alpha, hipStream_t s);
+
+}  // namespace rwkv

@@ -1,0 +1,817 @@
+// rwkv_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels for the RWKV V5/V6/V7 forward pass.
+//
+// Reference arithmetic: the web-rwkv calls behind `runtime.infer` (crates/ai00-core/src/run.rs:1143),
+// restated in SURVEY.md Appendix A.  Kernel inventory:
+//   gemm_kernel      K4-K7,K12-K15  skinny MFMA GEMM over pre-tiled fp16/int8/nf4 weights, fused epilogues
+//   ln_shift_kernel  K2,K3,K14      residual-partials add + LayerNorm + token shift + operand emit
+//   embed_kernel     K1             emb gather + ln0
+//   ln_out_kernel    K2             final LayerNorm on the rows whose logits are requested
+//   wkv_kernel       K8-K11,K13     WKV recurrence (+v6 decay LoRA stage 2, +v7 kappa/a/v-mix), GroupNorm, gate
+//   state_pack       K17            public slab [C,N+2,L,1] <-> internal state layout
+//   softmax / argmax K16            batched over the vocabulary
+//   tile/quant       K18,K19        load-time: raw fp16 -> tiled fp16 / int8 / nf4 ; LoRA blend
+//
+// gfx950 only: wave = 64 lanes, v_mfma_f32_16x16x32_f16, no portability shims.
+#include "rwkv_kernels.h"
+
+namespace rwkv {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float apply_act(int act, float v) {
+    switch (act) {
+        case ACT_TANH: return tanhf(v);
+        case ACT_SIGMOID: return sigmoidf_(v);
+        case ACT_RELU2: { float r = fmaxf(v, 0.0f); return r * r; }
+        case ACT_SILU: return v * sigmoidf_(v);
+        case ACT_DECAY7: return expf(-0.606531f * sigmoidf_(v));
+        default: return v;
+    }
+}
+
+// fp32 -> (hi, lo) f16 pair: hi = rn(v) saturated, lo = rn(v - hi).  hi+lo carries ~22 mantissa bits.
+__device__ __forceinline__ void split_hilo(float v, _Float16 &hi, _Float16 &lo) {
+    float c = fminf(fmaxf(v, -65504.0f), 65504.0f);
+    hi = (_Float16)c;
+    lo = (_Float16)(c - (float)hi);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// block-wide sum over 256 threads; `red` is >= 4 floats of LDS.  All threads get the result.
+__device__ __forceinline__ float block_sum256(float v, float *red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// =====================================================================================
+// GEMM: out[t][row] = epi( sum_k W[row][k] * X[t][k] ),  W pre-tiled, X = f16 (hi[,lo]) operand
+// =====================================================================================
+template <int FMT> struct WGroup;                  // registers holding one 256-k group of one strip
+template <> struct WGroup<W_F16> { u32x4 q[8]; };
+template <> struct WGroup<W_INT8> { u32x4 q[4]; uint2 s; };
+template <> struct WGroup<W_NF4> { u32x4 q[2]; uint2 s; };
+
+template <int FMT>
+__device__ __forceinline__ void load_group(WGroup<FMT> &g, const GemmProb &P, int strip, int k0, int kend, int lane) {
+    if constexpr (FMT == W_F16) {
+        const int KT = P.K >> 5;
+        const u32x4 *base = (const u32x4 *)P.W + ((long)strip * KT + (k0 >> 5)) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (k0 + j * 32 < kend) g.q[j] = __builtin_nontemporal_load(base + j * 64);
+            else g.q[j] = (u32x4){0u, 0u, 0u, 0u};
+        }
+    } else if constexpr (FMT == W_INT8) {
+        const int KT = P.K >> 6;
+        const u32x4 *base = (const u32x4 *)P.W + ((long)strip * KT + (k0 >> 6)) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (k0 + j * 64 < kend) g.q[j] = __builtin_nontemporal_load(base + j * 64);
+            else g.q[j] = (u32x4){0u, 0u, 0u, 0u};
+        }
+        const int NG = P.K >> 8;
+        const uint2 *sb = (const uint2 *)P.S + ((long)strip * NG + (k0 >> 8)) * 16 + (lane & 15);
+        g.s = (k0 < kend) ? *sb : make_uint2(0, 0);
+    } else {
+        const int KT = P.K >> 7;
+        const u32x4 *base = (const u32x4 *)P.W + ((long)strip * KT + (k0 >> 7)) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (k0 + j * 128 < kend) g.q[j] = __builtin_nontemporal_load(base + j * 64);
+            else g.q[j] = (u32x4){0u, 0u, 0u, 0u};
+        }
+        const int NG = P.K >> 8;
+        const uint2 *sb = (const uint2 *)P.S + ((long)strip * NG + (k0 >> 8)) * 16 + (lane & 15);
+        g.s = (k0 < kend) ? *sb : make_uint2(0, 0);
+    }
+}
+
+__device__ __forceinline__ f16x2 as_h2(u32 v) { return __builtin_bit_cast(f16x2, v); }
+__device__ __forceinline__ u32 as_u32(f16x2 v) { return __builtin_bit_cast(u32, v); }
+
+// int8: two bytes of `d` (selected by `sel`) -> half2 of a*q+b, one rounding (v_pk_fma_f16)
+__device__ __forceinline__ u32 dq8(u32 d, u32 sel, f16x2 a2, f16x2 b2) {
+    u32 p = __builtin_amdgcn_perm(0x64646464u, d, sel);           // bytes -> 0x6400|q == 1024+q exactly
+    f16x2 h = as_h2(p) - (f16x2){(_Float16)1024.0f, (_Float16)1024.0f};
+    return as_u32(__builtin_elementwise_fma(h, a2, b2));
+}
+
+// NF4 code points rounded to fp16 (oracle: NF4_TABLE_F16), as byte tables for v_perm lookups.
+// value i = TH[i]<<8 | TL[i]
+__device__ __constant__ unsigned short nf4_f16_bits[16] = {
+    0xBC00, 0xB992, 0xB833, 0xB652, 0xB48D, 0xB1EA, 0xADD4, 0x0000,
+    0x2D18, 0x3126, 0x33E0, 0x3568, 0x370D, 0x3880, 0x39C9, 0x3C00};
+
+struct Nf4Lut { u32 tl[4], th[4]; };
+__device__ __forceinline__ Nf4Lut make_nf4_lut() {
+    Nf4Lut t;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            u32 v = nf4_f16_bits[d * 4 + b];
+            lo |= (v & 0xFF) << (8 * b);
+            hi |= (v >> 8) << (8 * b);
+        }
+        t.tl[d] = lo; t.th[d] = hi;
+    }
+    return t;
+}
+// 4 nibble indices (one per byte of n) -> 4 fp16 code points as two half2 words
+__device__ __forceinline__ void nf4_lookup4(u32 n, const Nf4Lut &t, u32 &h01, u32 &h23) {
+    u32 sel = n & 0x07070707u;
+    u32 mask = ((n >> 3) & 0x01010101u) * 0xFFu;
+    u32 la = __builtin_amdgcn_perm(t.tl[1], t.tl[0], sel);
+    u32 lb = __builtin_amdgcn_perm(t.tl[3], t.tl[2], sel);
+    u32 ha = __builtin_amdgcn_perm(t.th[1], t.th[0], sel);
+    u32 hb = __builtin_amdgcn_perm(t.th[3], t.th[2], sel);
+    u32 L = (la & ~mask) | (lb & mask);
+    u32 Hh = (ha & ~mask) | (hb & mask);
+    h01 = __builtin_amdgcn_perm(Hh, L, 0x05010400u);
+    h23 = __builtin_amdgcn_perm(Hh, L, 0x07030602u);
+}
+
+template <int FMT>
+__device__ __forceinline__ f16x8 frag(const WGroup<FMT> &g, int ks, const Nf4Lut &lut) {
+    if constexpr (FMT == W_F16) {
+        return __builtin_bit_cast(f16x8, g.q[ks]);
+    } else if constexpr (FMT == W_INT8) {
+        const u32x4 q = g.q[ks >> 1];
+        const u32 d0 = (ks & 1) ? q.z : q.x, d1 = (ks & 1) ? q.w : q.y;
+        const u32 ab = (ks >> 2) ? g.s.y : g.s.x;            // 128-block of this k-step
+        const f16x2 abh = as_h2(ab);
+        const f16x2 a2 = {abh[0], abh[0]}, b2 = {abh[1], abh[1]};
+        u32x4 r;
+        r.x = dq8(d0, 0x04010400u, a2, b2);
+        r.y = dq8(d0, 0x04030402u, a2, b2);
+        r.z = dq8(d1, 0x04010400u, a2, b2);
+        r.w = dq8(d1, 0x04030402u, a2, b2);
+        return __builtin_bit_cast(f16x8, r);
+    } else {
+        const u32x4 q = g.q[ks >> 2];
+        const int w = ks & 3;
+        const u32 d = w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w;
+        // absmax of 64-block (ks>>1) inside the 256-group: 4 halfs packed in g.s
+        const u32 sw = (ks >> 2) ? g.s.y : g.s.x;
+        const f16x2 sh = as_h2(sw);
+        const _Float16 am = ((ks >> 1) & 1) ? sh[1] : sh[0];
+        const f16x2 am2 = {am, am};
+        u32x4 r;
+        u32 a, b;
+        nf4_lookup4(d & 0x0F0F0F0Fu, lut, a, b);
+        r.x = as_u32(as_h2(a) * am2);
+        r.y = as_u32(as_h2(b) * am2);
+        nf4_lookup4((d >> 4) & 0x0F0F0F0Fu, lut, a, b);
+        r.z = as_u32(as_h2(a) * am2);
+        r.w = as_u32(as_h2(b) * am2);
+        return __builtin_bit_cast(f16x8, r);
+    }
+}
+
+template <int NT, bool HILO, int FMT>
+__device__ __forceinline__ void compute_group(const WGroup<FMT> &g, f32x4 (&acc)[NT], const _Float16 *xs_hi,
+                                              const _Float16 *xs_lo, int stride_h, int kofs, int k0, int kend,
+                                              int rows_valid, int lane, const Nf4Lut &lut) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        if (k0 + ks * 32 < kend) {                                  // wave-uniform
+            const f16x8 a = frag<FMT>(g, ks, lut);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                int row = nt * 16 + (lane & 15);
+                row = row < rows_valid ? row : rows_valid - 1;
+                const int off = row * stride_h + kofs + ks * 32 + (lane >> 4) * 8;
+                const f16x8 bh = *(const f16x8 *)(xs_hi + off);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh, acc[nt], 0, 0, 0);
+                if constexpr (HILO) {
+                    const f16x8 bl = *(const f16x8 *)(xs_lo + off);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+template <int NT, bool HILO, int FMT>
+__device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lb = (int)blockIdx.x - P.block_begin;
+    const int kb = lb / P.nblk_strip, sb = lb - kb * P.nblk_strip;
+    const int ksw = P.ksw, spb = 4 / ksw;
+    const int strip = sb * spb + wave / ksw;
+    const int kpart = wave % ksw;
+    const int strips = P.rows >> 4;
+    const bool strip_ok = strip < strips;
+    const int Kb = P.K / P.ksb;
+    const int kbeg = kb * Kb, kend = kbeg + Kb;
+    const int kc = L.kc;
+    const int kw = kc / ksw;                                       // k per wave per chunk
+    const int gpc = kw / GROUP_K;                                  // groups per wave per chunk
+    const int nchunks = (Kb + kc - 1) / kc;
+    const int stride_h = kc + 8;                                   // halfs; +16 B pad against bank conflicts
+    _Float16 *xs_hi = (_Float16 *)smem;
+    _Float16 *xs_lo = xs_hi + (long)L.rows_st * stride_h;
+    Nf4Lut lut;
+    if constexpr (FMT == W_NF4) lut = make_nf4_lut();
+
+    for (int t0 = 0; t0 < L.T; t0 += NT * 16) {
+        const int rows_valid = min(L.rows_st, L.T - t0);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        WGroup<FMT> cur, nxt;
+        const int ngroups = nchunks * gpc;
+        if (strip_ok) load_group<FMT>(cur, P, strip, kbeg + kpart * kw, kend, lane);
+        for (int c = 0; c < nchunks; ++c) {
+            const int ck0 = kbeg + c * kc;
+            __syncthreads();
+            {   // stage X[t0 .. t0+rows_valid)[ck0 .. ck0+kc) -> LDS, 16 B pieces
+                const int ppr = kc >> 3;
+                const int total = rows_valid * ppr;
+                for (int p = tid; p < total; p += GEMM_THREADS) {
+                    const int r = p / ppr, c8 = p - r * ppr;
+                    const int k = ck0 + c8 * 8;
+                    uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+                    if (k < kend) {
+                        vh = *(const uint4 *)(P.xhi + (long)(t0 + r) * P.ldx + k);
+                        if constexpr (HILO) vl = *(const uint4 *)(P.xlo + (long)(t0 + r) * P.ldx + k);
+                    }
+                    *(uint4 *)(xs_hi + r * stride_h + c8 * 8) = vh;
+                    if constexpr (HILO) *(uint4 *)(xs_lo + r * stride_h + c8 * 8) = vl;
+                }
+            }
+            __syncthreads();
+            if (strip_ok) {
+                for (int gi = 0; gi < gpc; ++gi) {
+                    const int g = c * gpc + gi;
+                    const int k0 = ck0 + kpart * kw + gi * GROUP_K;
+                    if (g + 1 < ngroups) {
+                        const int c2 = (gi + 1 < gpc) ? c : c + 1;
+                        const int gi2 = (gi + 1 < gpc) ? gi + 1 : 0;
+                        load_group<FMT>(nxt, P, strip, kbeg + c2 * kc + kpart * kw + gi2 * GROUP_K, kend, lane);
+                    }
+                    compute_group<NT, HILO, FMT>(cur, acc, xs_hi, xs_lo, stride_h, kpart * kw + gi * GROUP_K, k0, kend,
+                                                 rows_valid, lane, lut);
+                    cur = nxt;
+                }
+            }
+        }
+        // ---- reduce the ksw partial accumulators of a strip through LDS
+        if (ksw > 1) {
+            __syncthreads();
+            f32x4 *red = (f32x4 *)smem;                           // [wave][nt][lane]
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) red[(wave * NT + nt) * 64 + lane] = acc[nt];
+            __syncthreads();
+            if (kpart == 0) {
+                for (int w2 = 1; w2 < ksw; ++w2)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] += red[((wave + w2) * NT + nt) * 64 + lane];
+            }
+        }
+        // ---- epilogue
+        if (strip_ok && kpart == 0) {
+            const int row0 = strip * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int t = t0 + nt * 16 + (lane & 15);
+                if (t < L.T) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = acc[nt][r];
+                        if (P.bias) x += P.bias[row0 + r];
+                        x = apply_act(P.act, x);
+                        if (P.post == POST_MUL) x *= P.m0[(long)t * P.ldm + row0 + r];
+                        else if (P.post == POST_MIX)
+                            x = P.m0[(long)t * P.ldm + row0 + r] + P.m1[(long)t * P.ldm + row0 + r] * x;
+                        v[r] = x;
+                    }
+                    if (P.out_f32) {
+                        float *o = P.out_f32 + (long)kb * P.partial_stride + (long)t * P.ldo + row0;
+                        *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                    if (P.out_hi) {
+                        f16x4 h, l;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { _Float16 a, b; split_hilo(v[r], a, b); h[r] = a; l[r] = b; }
+                        *(f16x4 *)(P.out_hi + (long)t * P.ldh + row0) = h;
+                        if (P.out_lo) *(f16x4 *)(P.out_lo + (long)t * P.ldh + row0) = l;
+                    }
+                }
+            }
+        }
+        if (t0 + NT * 16 < L.T) __syncthreads();
+    }
+}
+
+template <int NT, bool HILO>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int pi = 0;
+    for (int i = 1; i < L.nprob; ++i)
+        if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
+    const GemmProb &P = L.p[pi];
+    if (P.fmt == W_F16) gemm_body<NT, HILO, W_F16>(L, P, smem);
+    else if (P.fmt == W_INT8) gemm_body<NT, HILO, W_INT8>(L, P, smem);
+    else gemm_body<NT, HILO, W_NF4>(L, P, smem);
+}
+
+void launch_gemm(const GemmLaunch &L, int NT, bool hilo, hipStream_t s) {
+    size_t xbytes = (size_t)L.rows_st * (L.kc + 8) * 2 * (hilo ? 2 : 1);
+    size_t rbytes = (size_t)4 * NT * 64 * 16;
+    size_t lds = xbytes > rbytes ? xbytes : rbytes;
+    dim3 grid(L.total_blocks), block(GEMM_THREADS);
+    static bool attr_done[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_done[dev & 15]) {                               // allow > 64 KiB dynamic LDS (gfx950: 160 KiB / CU)
+        const int cap = 160 * 1024;
+        (void)hipFuncSetAttribute((const void *)gemm_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void *)gemm_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void *)gemm_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void *)gemm_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void *)gemm_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void *)gemm_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        attr_done[dev & 15] = true;
+    }
+#define LG(NT_, H_) hipLaunchKernelGGL((gemm_kernel<NT_, H_>), grid, block, lds, s, L)
+    if (hilo) { if (NT == 1) LG(1, true); else if (NT == 2) LG(2, true); else LG(4, true); }
+    else      { if (NT == 1) LG(1, false); else if (NT == 2) LG(2, false); else LG(4, false); }
+#undef LG
+}
+
+// =====================================================================================
+// Row kernels (one 256-thread block per row)
+// =====================================================================================
+// PT = values per thread (C <= PT*256).  Everything stays in registers (fully unrolled, predicated).
+#define ROW_FOR(i, c) _Pragma("unroll") for (int i = 0, c = threadIdx.x; i < PT; ++i, c += 256) if (c < C)
+
+template <int PT>
+__device__ __forceinline__ void row_load_sum(const float *x_in, const float *P, int np, long pstride, int row, int C,
+                                             float (&v)[PT]) {
+    ROW_FOR(i, c) {
+        float a = x_in[(long)row * C + c];
+        for (int j = 0; j < np; ++j) a += P[j * pstride + (long)row * C + c];
+        v[i] = a;
+    }
+}
+// two-pass LayerNorm (mean, then centred variance), eps 1e-5 — same order as the oracle's _ln
+template <int PT>
+__device__ __forceinline__ void row_layernorm(float (&v)[PT], int C, const float *w, const float *b, float *red) {
+    float s = 0.f;
+    ROW_FOR(i, c) s += v[i];
+    const float mean = block_sum256(s, red) / (float)C;
+    float q = 0.f;
+    ROW_FOR(i, c) { const float d = v[i] - mean; q += d * d; }
+    const float var = block_sum256(q, red) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    ROW_FOR(i, c) v[i] = (v[i] - mean) * rstd * w[c] + b[c];
+}
+
+template <int PT>
+__global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
+    __shared__ float red[4];
+    const int t = blockIdx.x, C = a.C;
+    float xv[PT], pv[PT];
+    row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, t, C, xv);
+    if (a.x_out) { ROW_FOR(i, c) a.x_out[(long)t * C + c] = xv[i]; }
+    row_layernorm<PT>(xv, C, a.lnw, a.lnb, red);
+    const int slot = a.rm.slot[t], prev = a.rm.prev[t], last = a.rm.last[t];
+    float *sx = a.sx + (long)slot * a.sx_slot_stride;
+    if (prev >= 0) {
+        row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, prev, C, pv);
+        row_layernorm<PT>(pv, C, a.lnw, a.lnb, red);
+    } else {
+        ROW_FOR(i, c) pv[i] = sx[c];
+    }
+    if (last >= 0) {            // this block owns the slot's token-shift state write (after its own read above)
+        if (last == t) {
+            ROW_FOR(i, c) sx[c] = xv[i];
+        } else {
+            float lv[PT];
+            row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, last, C, lv);
+            row_layernorm<PT>(lv, C, a.lnw, a.lnb, red);
+            ROW_FOR(i, c) sx[c] = lv[i];
+        }
+    }
+    ROW_FOR(i, c) {
+        const float xx = xv[i], pr = pv[i];
+        const float dx = pr - xx;
+        if (a.xx_out) a.xx_out[(long)t * C + c] = xx;
+        if (a.dx_out) a.dx_out[(long)t * C + c] = dx;
+        for (int m = 0; m < a.nmix; ++m) {
+            const float mu = a.mu[m][c];
+            const float o = a.mode == 0 ? xx * mu + pr * (1.0f - mu) : xx + dx * mu;
+            _Float16 h, l;
+            split_hilo(o, h, l);
+            a.ohi[m][(long)t * a.ldh + c] = h;
+            if (a.olo[m]) a.olo[m][(long)t * a.ldh + c] = l;
+        }
+    }
+}
+#define ROW_DISPATCH(KERN, C_, GRID, ...)                                                          \
+    do {                                                                                           \
+        if ((C_) <= 1024) hipLaunchKernelGGL((KERN<4>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__); \
+        else if ((C_) <= 2048) hipLaunchKernelGGL((KERN<8>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__); \
+        else if ((C_) <= 4096) hipLaunchKernelGGL((KERN<16>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERN<32>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__);             \
+    } while (0)
+
+void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s) { ROW_DISPATCH(ln_shift_kernel, a.C, T, a); }
+
+template <int PT>
+__global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
+    __shared__ float red[4];
+    const int t = blockIdx.x, C = a.C;
+    int tok = a.token[t];
+    tok = tok < 0 ? 0 : (tok >= a.V ? a.V - 1 : tok);
+    float v[PT];
+    ROW_FOR(i, c) v[i] = (float)a.emb[(long)tok * C + c];
+    row_layernorm<PT>(v, C, a.lnw, a.lnb, red);
+    ROW_FOR(i, c) a.x[(long)t * C + c] = v[i];
+}
+void launch_embed(const EmbedArgs &a, int T, hipStream_t s) { ROW_DISPATCH(embed_kernel, a.C, T, a); }
+
+template <int PT>
+__global__ __launch_bounds__(256) void ln_out_kernel(const LnOutArgs a) {
+    __shared__ float red[4];
+    const int o = blockIdx.x, C = a.C;
+    const int t = a.out_rows[o];
+    float v[PT];
+    row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, t, C, v);
+    row_layernorm<PT>(v, C, a.lnw, a.lnb, red);
+    ROW_FOR(i, c) {
+        _Float16 h, l;
+        split_hilo(v[i], h, l);
+        a.ohi[(long)o * a.ldh + c] = h;
+        if (a.olo) a.olo[(long)o * a.ldh + c] = l;
+    }
+}
+void launch_ln_out(const LnOutArgs &a, int n_out, hipStream_t s) { ROW_DISPATCH(ln_out_kernel, a.C, n_out, a); }
+
+// =====================================================================================
+// WKV recurrence.  One 256-thread block per (active slot, head); the slot's rows of this step are
+// consumed sequentially with the 64x64 state held in registers:
+//   thread (ig = tid>>4, jg = tid&15) owns T[p = a*16+ig][q = jg*4 .. +4], a = 0..3
+// Internal layout T[p = value index][q = key index] for every version (v5/v6: T[j][i] = S_ij).
+//   v5/v6: out_p = sum_q r_q (u_q k_q v_p + T_pq) ;  T_pq <- k_q v_p + w_q T_pq
+//   v7   : sa_p = sum_q T_pq (-kk_q) ; T_pq <- T_pq w_q + sa_p (kk_q a_q) + v_p k_q ; out_p = sum_q T_pq r_q
+// followed by GroupNorm over the head (eps 64e-5), gate, and (v7) the r.k.r_k bonus.
+// =====================================================================================
+__device__ __forceinline__ float sum16(float v) {       // reduce across the 16 lanes sharing (tid>>4)
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void wkv_kernel(const WkvArgs a) {
+    __shared__ __attribute__((aligned(16))) float sh_r[64], sh_k[64], sh_v[64], sh_w[64], sh_u[64], sh_kk[64], sh_ka[64];
+    __shared__ float sh_out[64], sh_td[128], sh_red[4], sh_stat[2];
+    const int seq = blockIdx.x, h = blockIdx.y;
+    const int tid = threadIdx.x, ig = tid >> 4, jg = tid & 15;
+    const int slot = a.seq_slot[seq], row0 = a.seq_begin[seq], nrow = a.seq_len[seq];
+    const int C = a.C, cb = h * 64;
+    float *st = a.state + (long)slot * a.slot_stride + (long)h * 4096;
+
+    float4 T[4];
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) T[aa] = *(const float4 *)(st + (aa * 16 + ig) * 64 + jg * 4);
+    if (a.version != 7 && tid < 64) sh_u[tid] = a.u[cb + tid];
+    if (a.version == 5 && tid < 64) sh_w[tid] = a.wdec_or_decay[cb + tid];
+
+    for (int it = 0; it < nrow; ++it) {
+        const int t = row0 + it;
+        const long rb = (long)t * C + cb;
+        __syncthreads();                                   // previous iteration's readers done
+        if (tid < 64) {
+            float r = a.r[rb + tid], k = a.k[rb + tid], v = a.v[rb + tid];
+            if (a.version == 7) {
+                const float av = a.a7[rb + tid];
+                float kk = k * a.k_k[cb + tid];
+                const float ss = wave_sum(kk * kk);        // tid<64 == wave 0: L2 norm over the head
+                kk = kk / fmaxf(sqrtf(ss), 1e-12f);
+                k = k * (1.0f + (av - 1.0f) * a.k_a[cb + tid]);
+                if (a.layer == 0) a.v_first[rb + tid] = v;
+                else v = v + (a.v_first[rb + tid] - v) * a.vg7[rb + tid];
+                sh_kk[tid] = -kk;                          // -kappa
+                sh_ka[tid] = kk * av;                      // kappa * a
+                sh_w[tid] = a.w7[rb + tid];
+            }
+            sh_r[tid] = r; sh_k[tid] = k; sh_v[tid] = v;
+        }
+        if (a.version == 6) {
+            if (tid < a.Dd) sh_td[tid] = a.td[(long)t * a.Dd + tid];
+            __syncthreads();
+            // decay LoRA stage 2: d_c = time_decay_c + sum_d D2[c][d] td[d];  w = exp(-exp(d)).  4 threads / channel
+            const int ch = tid >> 2, part = tid & 3;
+            const int per = a.Dd >> 2;
+            const _Float16 *d2 = a.D2 + (long)(cb + ch) * a.Dd + part * per;
+            float s = 0.f;
+            for (int d = 0; d < per; ++d) s += (float)d2[d] * sh_td[part * per + d];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            if (part == 0) sh_w[ch] = expf(-expf(a.wdec_or_decay[cb + ch] + s));
+        }
+        __syncthreads();
+        const float4 rq = *(const float4 *)(sh_r + jg * 4);
+        const float4 kq = *(const float4 *)(sh_k + jg * 4);
+        const float4 wq = *(const float4 *)(sh_w + jg * 4);
+        float outp[4];
+        if (a.version != 7) {
+            const float4 uq = *(const float4 *)(sh_u + jg * 4);
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                const float vp = sh_v[aa * 16 + ig];
+                float4 &S = T[aa];
+                float o;
+                float kv;
+                kv = kq.x * vp; o = rq.x * (uq.x * kv + S.x); S.x = kv + wq.x * S.x;
+                kv = kq.y * vp; o += rq.y * (uq.y * kv + S.y); S.y = kv + wq.y * S.y;
+                kv = kq.z * vp; o += rq.z * (uq.z * kv + S.z); S.z = kv + wq.z * S.z;
+                kv = kq.w * vp; o += rq.w * (uq.w * kv + S.w); S.w = kv + wq.w * S.w;
+                outp[aa] = sum16(o);
+            }
+        } else {
+            const float4 nk = *(const float4 *)(sh_kk + jg * 4);
+            const float4 ka = *(const float4 *)(sh_ka + jg * 4);
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                const float vp = sh_v[aa * 16 + ig];
+                float4 &S = T[aa];
+                float sa = S.x * nk.x + S.y * nk.y + S.z * nk.z + S.w * nk.w;
+                sa = sum16(sa);
+                S.x = S.x * wq.x + sa * ka.x + vp * kq.x;
+                S.y = S.y * wq.y + sa * ka.y + vp * kq.y;
+                S.z = S.z * wq.z + sa * ka.z + vp * kq.z;
+                S.w = S.w * wq.w + sa * ka.w + vp * kq.w;
+                float o = S.x * rq.x + S.y * rq.y + S.z * rq.z + S.w * rq.w;
+                outp[aa] = sum16(o);
+            }
+        }
+        if (jg == 0) {
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) sh_out[aa * 16 + ig] = outp[aa];
+        }
+        __syncthreads();
+        if (tid < 64) {                                    // wave 0: GroupNorm over the head + gate
+            const float o = sh_out[tid];
+            const float mean = wave_sum(o) * (1.0f / 64.0f);
+            const float d = o - mean;
+            const float var = wave_sum(d * d) * (1.0f / 64.0f);
+            float y = d / sqrtf(var + 64e-5f) * a.lnx_w[cb + tid] + a.lnx_b[cb + tid];
+            if (a.version == 7) {
+                const float bonus = wave_sum(sh_r[tid] * sh_k[tid] * a.r_k[cb + tid]);
+                y += bonus * sh_v[tid];
+            }
+            y *= a.g[rb + tid];
+            _Float16 hh, ll;
+            split_hilo(y, hh, ll);
+            a.yhi[(long)t * a.ldh + cb + tid] = hh;
+            if (a.ylo) a.ylo[(long)t * a.ldh + cb + tid] = ll;
+        }
+    }
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) *(float4 *)(st + (aa * 16 + ig) * 64 + jg * 4) = T[aa];
+}
+void launch_wkv(const WkvArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(wkv_kernel, dim3(a.n_seq, a.H), dim3(256), 0, s, a);
+}
+
+// =====================================================================================
+// State slab <-> internal.  slab[l][0][c]=sx_att, slab[l][1+i][h*64+j]=S_h[i][j], slab[l][65][c]=sx_ffn
+// internal wkv T[l][h][p][q]:  transposed (v5/v6): S[i][j] = T[p=j][q=i];  v7: S[i][j] = T[p=i][q=j]
+// =====================================================================================
+__global__ void state_pack_kernel(const StatePackArgs a) {
+    const int C = a.C, N = 64;
+    const long per_layer = (long)(N + 2) * C;
+    const long total = a.layer_only >= 0 ? (long)N * C : (long)a.L * per_layer;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int l, row, c;
+        if (a.layer_only >= 0) { l = a.layer_only; row = 1 + (int)(idx / C); c = (int)(idx % C); }
+        else { l = (int)(idx / per_layer); long r2 = idx % per_layer; row = (int)(r2 / C); c = (int)(r2 % C); }
+        float *src;
+        if (row == 0) src = a.sxa + (long)l * C + c;
+        else if (row == N + 1) src = a.sxf + (long)l * C + c;
+        else {
+            const int i = row - 1, h = c >> 6, j = c & 63;
+            const int p = a.transposed ? j : i, q = a.transposed ? i : j;
+            src = a.wkv + (((long)l * a.H + h) * 64 + p) * 64 + q;
+        }
+        if (a.to_slab) a.slab[idx] = *src; else *src = a.slab[idx];
+    }
+}
+void launch_state_pack(const StatePackArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(state_pack_kernel, dim3(1024), dim3(256), 0, s, a);
+}
+
+// =====================================================================================
+// softmax / argmax over the vocabulary (one block per row)
+// =====================================================================================
+__global__ __launch_bounds__(256) void softmax_kernel(const float *in, float *out, int V) {
+    __shared__ float red[4];
+    const float *x = in + (long)blockIdx.x * V;
+    float *y = out + (long)blockIdx.x * V;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < V; i += 256) m = fmaxf(m, x[i]);
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+    for (int i = threadIdx.x; i < V; i += 256) s += expf(x[i] - m);
+    s = block_sum256(s, red);
+    const float inv = 1.0f / s;
+    for (int i = threadIdx.x; i < V; i += 256) y[i] = expf(x[i] - m) * inv;
+}
+void launch_softmax(const float *in, float *out, int n_rows, int V, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_kernel, dim3(n_rows), dim3(256), 0, s, in, out, V);
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float *logits, int V, int *out_tok) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const float *x = logits + (long)blockIdx.x * V;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += 256) {
+        const float v = x[i];
+        if (v > best) { best = v; idx = i; }               // strided ascending: first max kept per thread
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) {
+        const float ov = __shfl_xor(best, k, 64);
+        const int oi = __shfl_xor(idx, k, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        out_tok[blockIdx.x] = idx;                          // lowest index on ties == np.argmax
+    }
+}
+void launch_argmax(const float *logits, int n_rows, int V, int *out_tok, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_kernel, dim3(n_rows), dim3(256), 0, s, logits, V, out_tok);
+}
+
+// =====================================================================================
+// Load-time layout kernels
+// =====================================================================================
+// fp16 tile: out uint4 index ((strip*KT + kt)*64 + lane) <- W[strip*16 + (lane&15)][kt*32 + (lane>>4)*8 .. +8]
+__global__ void tile_f16_kernel(const _Float16 *raw, int rows_valid, int rows, int K, uint4 *out) {
+    const int KT = K >> 5;
+    const long total = (long)(rows >> 4) * KT * 64;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const long tile = idx >> 6;
+        const int kt = (int)(tile % KT), strip = (int)(tile / KT);
+        const int row = strip * 16 + (lane & 15), k = kt * 32 + (lane >> 4) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < rows_valid) v = *(const uint4 *)(raw + (long)row * K + k);
+        out[idx] = v;
+    }
+}
+void launch_tile_f16(const _Float16 *raw, int rows_valid, int rows, int K, void *out, hipStream_t s) {
+    hipLaunchKernelGGL(tile_f16_kernel, dim3(2048), dim3(256), 0, s, raw, rows_valid, rows, K, (uint4 *)out);
+}
+
+// int8: one thread per (row, 128-block).  q = rint((x-b)/a), a = fp16((max-min)/255), b = fp16(min)
+// tiled byte position of element (row, k): tile kt=k/64, lane=(row&15)+16*kc with kc=(k%32)/8, byte=(k%64>=32?8:0)+(k%8)
+__global__ void quant_int8_kernel(const _Float16 *raw, int rows, int K, unsigned char *out, f16x2 *scales) {
+    const int nb = K >> 7;
+    const long total = (long)rows * nb;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / nb), blk = (int)(idx % nb);
+        const _Float16 *x = raw + (long)row * K + blk * 128;
+        float mn = INFINITY, mx = -INFINITY;
+        for (int i = 0; i < 128; ++i) { const float v = (float)x[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+        const _Float16 ah = (_Float16)((mx - mn) / 255.0f);
+        const _Float16 bh = (_Float16)mn;
+        const float af = (float)ah, bf = (float)bh;
+        const float safe = af > 0.f ? af : 1.0f;
+        const int strip = row >> 4, r16 = row & 15;
+        const int KT = K >> 6, NG = K >> 8;
+        for (int i = 0; i < 128; ++i) {
+            const int k = blk * 128 + i;
+            float q = rintf(((float)x[i] - bf) / safe);
+            q = fminf(fmaxf(q, 0.f), 255.f);
+            const int kt = k >> 6, kin = k & 63;
+            const int lane = r16 + 16 * ((kin & 31) >> 3);
+            const int byte = (kin >= 32 ? 8 : 0) + (kin & 7);
+            out[(((long)strip * KT + kt) * 64 + lane) * 16 + byte] = (unsigned char)q;
+        }
+        // scales layout [strip][K/256][16][2]{a,b}
+        scales[(((long)strip * NG + (blk >> 1)) * 16 + r16) * 2 + (blk & 1)] = (f16x2){ah, bh};
+    }
+}
+void launch_quant_int8(const _Float16 *raw, int rows, int K, void *out, void *scales, hipStream_t s) {
+    hipLaunchKernelGGL(quant_int8_kernel, dim3(2048), dim3(256), 0, s, raw, rows, K, (unsigned char *)out, (f16x2 *)scales);
+}
+
+// nf4: one thread per (row, 64-block).  tiled nibble position of (row,k): tile kt=k/128, lane=(row&15)+16*kc,
+// kc=(k%32)/8, kstep=(k%128)/32, e=k%8: byte = kstep*4 + (e&3), nibble = e>>2 (0 = low)
+__global__ void quant_nf4_kernel(const _Float16 *raw, int rows, int K, unsigned char *out, _Float16 *scales,
+                                 const float *mids) {
+    const int nb = K >> 6;
+    const long total = (long)rows * nb;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / nb), blk = (int)(idx % nb);
+        const _Float16 *x = raw + (long)row * K + blk * 64;
+        float am = 0.f;
+        for (int i = 0; i < 64; ++i) am = fmaxf(am, fabsf((float)x[i]));
+        const _Float16 amh = (_Float16)am;                 // exact: inputs are fp16
+        const float safe = am > 0.f ? am : 1.0f;
+        const int strip = row >> 4, r16 = row & 15;
+        const int KT = K >> 7, NG = K >> 8;
+        for (int i = 0; i < 64; i += 8) {
+            // 8 consecutive k share (kt, kstep, kc): bytes kstep*4 + 0..3, lo nibble e=0..3, hi nibble e=4..7
+            const int k = blk * 64 + i;
+            const int kt = k >> 7, kin = k & 127;
+            const int kstep = kin >> 5, kc = (kin & 31) >> 3;
+            const int lane = r16 + 16 * kc;
+            unsigned char code[8];
+            for (int e = 0; e < 8; ++e) {
+                const float xn = (float)x[i + e] / safe;
+                int c = 0;
+                for (int m = 0; m < 15; ++m) c += (xn > mids[m]) ? 1 : 0;
+                code[e] = (unsigned char)c;
+            }
+            unsigned char *dst = out + (((long)strip * KT + kt) * 64 + lane) * 16 + kstep * 4;
+            for (int b = 0; b < 4; ++b) dst[b] = (unsigned char)(code[b] | (code[b + 4] << 4));
+        }
+        // scales layout [strip][K/256][16][4] half
+        scales[(((long)strip * NG + (blk >> 2)) * 16 + r16) * 4 + (blk & 3)] = amh;
+    }
+}
+static float *g_nf4_mid_dev[16] = {nullptr};
+void launch_quant_nf4(const _Float16 *raw, int rows, int K, void *out, void *scales, hipStream_t s) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!g_nf4_mid_dev[dev & 15]) {
+        // exact fp32 midpoints, computed like the oracle: (Q[i+1] + Q[i]) * 0.5f
+        static const float Q[16] = {-1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f,
+                                    -0.28444138169288635f, -0.18477343022823334f, -0.09105003625154495f, 0.0f,
+                                    0.07958029955625534f, 0.16093020141124725f, 0.24611230194568634f, 0.33791524171829224f,
+                                    0.44070982933044434f, 0.5626170039176941f, 0.7229568362236023f, 1.0f};
+        float mids[15];
+        for (int i = 0; i < 15; ++i) mids[i] = (Q[i + 1] + Q[i]) * 0.5f;
+        float *d = nullptr;
+        (void)hipMalloc(&d, sizeof(mids));
+        (void)hipMemcpy(d, mids, sizeof(mids), hipMemcpyHostToDevice);
+        g_nf4_mid_dev[dev & 15] = d;
+    }
+    hipLaunchKernelGGL(quant_nf4_kernel, dim3(2048), dim3(256), 0, s, raw, rows, K, (unsigned char *)out,
+                       (_Float16 *)scales, (const float *)g_nf4_mid_dev[dev & 15]);
+}
+
+__global__ void f16_to_f32_kernel(const _Float16 *in, float *out, long n, int op) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = (float)in[i];
+        if (op == 1) v = expf(-expf(v));
+        out[i] = v;
+    }
+}
+void launch_f16_to_f32(const _Float16 *in, float *out, long n, int op, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(f16_to_f32_kernel, dim3(blocks), dim3(256), 0, s, in, out, n, op);
+}
+
+__global__ void lora_blend_kernel(_Float16 *W, const _Float16 *B, const _Float16 *A, int rows, int K, int r, float alpha) {
+    const long total = (long)rows * K;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / K), k = (int)(idx % K);
+        float s = 0.f;
+        for (int j = 0; j < r; ++j) s += (float)B[(long)row * r + j] * (float)A[(long)k * r + j];
+        W[idx] = (_Float16)((float)W[idx] + alpha * s);
+    }
+}
+void launch_lora_blend(_Float16 *W, const _Float16 *B, const _Float16 *A, int rows, int K, int r, float alpha, hipStream_t s) {
+    hipLaunchKernelGGL(lora_blend_kernel, dim3(2048), dim3(256), 0, s, W, B, A, rows, K, r, alpha);
+}
+
+}  // namespace rwkv
