@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -487,68 +488,89 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
 // ------------------------------------------------------------------------------------------------
 // GEMM planning: choose the K split per problem, the X chunk and launch
 // ------------------------------------------------------------------------------------------------
-static void choose_split(const DMat &W, bool partial, int max_w, int &ksw, int &ksb) {
-    const int strips = W.rows / 16, K = W.K;
-    double best = -1;
-    ksw = 1; ksb = 1;
-    for (int w : {1, 2, 4}) {
-        if (w > max_w) continue;
-        for (int b = 1; b <= (partial ? 8 : 1); ++b) {
-            if (K % b) continue;
-            const int Kb = K / b;
-            const int tk = W.fmt == W_F16 ? 32 : 256;
-            if (Kb % tk) continue;
-            if (w > 1 && Kb < GROUP_K * w) continue;
-            const int span = GROUP_K * w;
-            const double eff = (double)Kb / ((Kb + span - 1) / span * span);
-            const double waves = std::min(2048.0, (double)strips * w * b);
-            const double score = waves * eff - 24.0 * (b - 1) - 8.0 * (w - 1);
-            if (score > best) { best = score; ksw = w; ksb = b; }
-        }
-    }
+static int env_int(const char *name) {
+    const char *v = std::getenv(name);
+    return v ? std::atoi(v) : 0;
 }
 
-int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam) {
+// Decomposition of one launch (DESIGN.md "GEMM planning"): every wave owns KW = KSW*32 k of the block's K range;
+// linear ("partial") problems may split K across `ksb` blocks (the consumer row kernel sums the partials);
+// a block walks `spb` strips.  Aim: >= ~1.5 blocks per CU in flight, whole matrix in flight at once.
+static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo, long pstride, int force_spb = 0) {
     if (ps.empty() || ps.size() > GEMM_MAXP) throw RwkvError(RWKV_ERR_INVALID, "gemm: bad problem count");
-    GemmLaunch Lh{};
+    Lh = GemmLaunch{};
     Lh.nprob = (int)ps.size();
     Lh.T = T;
-    const int NT = T <= 16 ? 1 : T <= 32 ? 2 : 4;
-    Lh.rows_st = std::min(T, NT * 16);
-    int max_ksw = 1, max_kb = 0, blocks = 0, np = 1;
-    const size_t per_k0 = (size_t)Lh.rows_st * 2 * (hilo ? 2 : 1);
-    int max_w = 4;                                           // keep one X chunk (GROUP_K*ksw wide) under 48 KiB of LDS
-    while (max_w > 1 && (size_t)(GROUP_K * max_w + 8) * per_k0 > 48 * 1024) max_w >>= 1;
+    int NT, KSW;
+    gemm_variant(T, hilo, NT, KSW);
+    const int KW = KSW * 32;
+    static const int f_spb = env_int("RWKV_SPB"), f_ksb = env_int("RWKV_KSB");
+    long total_strips = 0;
+    for (auto &s : ps) total_strips += s.W->rows / 16;
+    int blocks = 0, np = 1, max_nw = 1, lds_items = 1;
+    bool shot = true, tail = false;
     for (size_t i = 0; i < ps.size(); ++i) {
         const ProbSpec &s = ps[i];
         GemmProb &g = Lh.p[i];
-        int ksw, ksb;
-        choose_split(*s.W, s.partial, max_w, ksw, ksb);
-        g.W = s.W->data; g.S = s.W->scales; g.fmt = s.W->fmt; g.rows = s.W->rows; g.K = s.W->K;
+        const int K = s.W->K, strips = s.W->rows / 16;
+        const int align = s.W->fmt == W_F16 ? 32 : 256;
+        // K split across blocks: mandatory when the range needs more than 16 waves, optional (linear epilogues)
+        // to spread small matrices over more CUs
+        int ksb = 1;
+        auto valid = [&](int b) { return K % b == 0 && (K / b) % align == 0; };
+        const int need = 1;                                   // slices beyond the block's waves are looped over
+        if (s.partial) {
+            // smallest split that gives >= 1.5 blocks per CU (one strip per block), else the largest valid one <= 8
+            int best = 0;
+            for (int b = 1; b <= 8; ++b) {
+                if (!valid(b)) continue;
+                best = b;
+                if ((long)strips * b >= 384) break;
+            }
+            if (!best) throw RwkvError(RWKV_ERR_UNSUPPORTED, "cannot split inner dimension");
+            ksb = best;
+            if (f_ksb && valid(f_ksb)) ksb = f_ksb;
+        }
+        const int Kb = K / ksb;
+        const int nslice = (Kb + KW - 1) / KW;                 // balanced: every wave owns the same number of slices
+        const int nw = (nslice + (nslice + GEMM_MAX_WAVES - 1) / GEMM_MAX_WAVES - 1) / ((nslice + GEMM_MAX_WAVES - 1) / GEMM_MAX_WAVES);
+        // strips per block: the whole grid should be resident at once (~164 VGPRs -> 12 waves per CU), and a wave's
+        // rounds should fit in registers so that every load is issued up-front (single shot); the head matrix is too
+        // big for that and runs 8 strips per block, software-pipelined.
+        const int sub = KSW / 8, maxr = gemm_max_rounds(s.W->fmt);
+        const long cap = 256L * std::max(1, 12 / nw);
+        int spb = (int)((total_strips * ksb + cap - 1) / cap);
+        if ((total_strips * ksb + spb - 1) / spb > 1024) spb = 8;            // huge matrices (head): long pipelined blocks
+        spb = std::max(1, std::min(spb, 8));
+        if (force_spb) spb = force_spb; else if (f_spb) spb = f_spb;
+        spb = std::min(spb, std::max(1, 150 / (nw * NT)));                     // LDS: spb*nw*NT KiB <= 150 KiB
+        g.W = s.W->data; g.S = s.W->scales; g.fmt = s.W->fmt; g.rows = s.W->rows; g.K = K;
         g.xhi = s.x.hi + s.xoff; g.xlo = s.x.lo ? s.x.lo + s.xoff : nullptr; g.ldx = s.x.ld;
-        g.ksw = ksw; g.ksb = ksb;
-        g.nblk_strip = (s.W->rows / 16 + (4 / ksw) - 1) / (4 / ksw);
+        g.spb = spb; g.nw = nw; g.ksb = ksb;
+        g.nblk_strip = (strips + spb - 1) / spb;
         g.block_begin = blocks;
         blocks += g.nblk_strip * ksb;
         g.act = s.act; g.post = s.post; g.bias = s.bias; g.m0 = s.m0; g.m1 = s.m1; g.ldm = s.ldm;
         g.out_f32 = s.out; g.ldo = s.ldo; g.partial_stride = pstride;
         g.out_hi = s.oh.hi; g.out_lo = s.oh.lo; g.ldh = s.oh.ld;
-        max_ksw = std::max(max_ksw, ksw);
-        max_kb = std::max(max_kb, s.W->K / ksb);
+        max_nw = std::max(max_nw, nw);
+        if (spb * sub > maxr) shot = false;
+        if (Kb % 256) tail = true;
+        lds_items = std::max(lds_items, spb * nw);
         if (s.partial) np = ksb;
     }
     Lh.total_blocks = blocks;
-    const int span = GROUP_K * max_ksw;
-    const int kfull = (max_kb + span - 1) / span * span;
-    const size_t per_k = (size_t)Lh.rows_st * 2 * (hilo ? 2 : 1);
-    int kc = kfull;
-    const size_t soft_cap = 32 * 1024;
-    if ((size_t)(kc + 8) * per_k > soft_cap) {
-        kc = (int)(soft_cap / per_k) / span * span;
-        if (kc < span) kc = span;
-    }
-    Lh.kc = kc;
-    launch(fam, [&] { launch_gemm(Lh, NT, hilo, s_main); });
+    Lh.threads = max_nw * 64;
+    Lh.lds_items = lds_items;
+    Lh.single_shot = shot ? 1 : 0;
+    Lh.tail = tail ? 1 : 0;
+    return np;
+}
+
+int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam) {
+    GemmLaunch Lh;
+    const int np = plan_gemm(Lh, ps, T, hilo, pstride);
+    launch(fam, [&] { launch_gemm(Lh, hilo, s_main); });
     return np;
 }
 
@@ -1102,6 +1124,67 @@ rwkv_status rwkv_decode_greedy(rwkv_engine *e, int32_t n_slots, const uint32_t *
         HIP_CHECK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
         if (elapsed_ms) *elapsed_ms = ms;
         HIP_CHECK(hipMemcpy(out_tokens, e->d_hist, need * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+// ---- kernel microbench (measurement hook): one [rows x K] problem, `nmat` distinct weight copies rotated so
+// that the 256 MiB Infinity Cache cannot serve re-reads; returns average microseconds per launch.
+rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int32_t hilo, int32_t spb, int32_t nmat,
+                            int32_t iters, float *us_per_launch, float *lds_kib) {
+    return guard([&] {
+        if (rows % 16 || K % 256 || T < 1 || nmat < 1 || iters < 1 || iters > 2000) throw RwkvError(RWKV_ERR_INVALID, "bad args");
+        hipStream_t st;
+        HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        const size_t wbytes = fmt == W_F16 ? (size_t)rows * K * 2 : fmt == W_INT8 ? (size_t)rows * K : (size_t)rows * K / 2;
+        const size_t sbytes = fmt == W_F16 ? 16 : fmt == W_INT8 ? (size_t)rows * (K / 128) * 4 : (size_t)rows * (K / 64) * 2;
+        std::vector<void *> bufs;
+        auto dal = [&](size_t n) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, n)); bufs.push_back(p); return p; };
+        std::vector<DMat> mats(nmat);
+        for (int i = 0; i < nmat; ++i) {
+            mats[i].data = dal(wbytes); mats[i].scales = dal(sbytes);
+            HIP_CHECK(hipMemset((void *)mats[i].data, 0x11 + i, wbytes));
+            HIP_CHECK(hipMemset((void *)mats[i].scales, 0x2c, sbytes));
+            mats[i].fmt = fmt; mats[i].rows = rows; mats[i].K = K;
+        }
+        Opd x; x.ld = K;
+        x.hi = (_Float16 *)dal((size_t)T * K * 2); x.lo = (_Float16 *)dal((size_t)T * K * 2);
+        HIP_CHECK(hipMemset(x.hi, 0, (size_t)T * K * 2)); HIP_CHECK(hipMemset(x.lo, 0, (size_t)T * K * 2));
+        float *out = (float *)dal((size_t)T * rows * 4);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+        std::vector<float *> parts;                                   // partial-sum target when K needs a block split
+        float *pbuf = (float *)dal((size_t)8 * T * rows * 4);
+        auto run = [&](int n) {
+            for (int i = 0; i < n; ++i) {
+                std::vector<ProbSpec> ps(1);
+                ps[0].W = &mats[i % nmat]; ps[0].x = x; ps[0].out = K > 5120 ? pbuf : out; ps[0].ldo = rows;
+                ps[0].partial = K > 5120;
+                GemmLaunch Lh;
+                plan_gemm(Lh, ps, T, hilo != 0, (long)T * rows, spb);
+                if (lds_kib) *lds_kib = (float)Lh.total_blocks;
+                launch_gemm(Lh, hilo != 0, st);
+            }
+        };
+        run(nmat);
+        HIP_CHECK(hipStreamSynchronize(st));
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        run(iters);
+        HIP_CHECK(hipStreamEndCapture(st, &g));
+        HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        HIP_CHECK(hipGraphLaunch(ge, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipEventRecord(e0, st));
+        HIP_CHECK(hipGraphLaunch(ge, st));
+        HIP_CHECK(hipEventRecord(e1, st));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
+        if (us_per_launch) *us_per_launch = ms * 1e3f / iters;
+        for (void *p : bufs) (void)hipFree(p);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
     });
 }
 

@@ -12,8 +12,7 @@ enum Post : int { POST_NONE = 0, POST_MUL = 1, POST_MIX = 2 };
 
 constexpr int TILE_ROWS = 16;        // output rows per strip (MFMA 16x16x32 M)
 constexpr int KSTEP = 32;            // K per MFMA
-constexpr int GROUP_K = 256;         // K covered by one register group of one wave (8 MFMA k-steps)
-constexpr int GEMM_THREADS = 256;    // 4 waves
+constexpr int GEMM_MAX_WAVES = 10;    // 640-thread blocks: <= 168 VGPRs per lane
 constexpr int GEMM_MAXP = 8;
 constexpr int INT8_BLOCK = 128;
 constexpr int NF4_BLOCK = 64;
@@ -38,9 +37,10 @@ struct GemmProb {
     const _Float16 *xhi;            // activation operand [T][ldx] (f16, hi part)
     const _Float16 *xlo;            // lo part (may be null when !HILO)
     int fmt, rows, K, ldx;
-    int ksw;                        // waves splitting K inside a block (1,2,4)
+    int spb;                        // strips (of 16 output rows) per block
+    int nw;                         // waves covering the block's K range (KW = 512 or 256 k each)
     int ksb;                        // blocks splitting K (partials written, linear epilogue only)
-    int nblk_strip;                 // blocks per K-slice = ceil(strips / (4/ksw))
+    int nblk_strip;                 // blocks per K-slice = ceil(strips / spb)
     int block_begin;                // first block of this problem in the launch
     // epilogue:  v = act(acc + bias[row]);  POST_MUL: v *= m0[t][row];  POST_MIX: v = m0 + m1 * v
     int act, post;
@@ -58,12 +58,16 @@ struct GemmLaunch {
     GemmProb p[GEMM_MAXP];
     int nprob;
     int T;                          // activation rows
-    int kc;                         // K per staged X chunk (multiple of GROUP_K * ksw for every problem)
-    int rows_st;                    // rows staged per pass (= min(T, NT*16))
+    int threads;                    // block size = 64 * max nw over the problems
+    int lds_items;                  // max over problems of spb*nw (LDS = items * NT KiB)
+    int single_shot;                // every problem's rounds per wave fit in registers: issue all loads up-front
+    int tail;                       // some fp16 problem has a K range that is not a multiple of 256: predicated variant
     int total_blocks;
 };
 
-void launch_gemm(const GemmLaunch &L, int NT, bool hilo, hipStream_t s);
+void gemm_variant(int T, bool hilo, int &NT, int &KSW);   // tile variant used for T rows
+void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s);
+int gemm_max_rounds(int fmt);                             // rounds of 256 k a wave can hold at once (single-shot)
 
 struct RowMeta {                    // device arrays, one entry per row of this step
     const int *token;               // token id

@@ -60,49 +60,48 @@ __device__ __forceinline__ float block_sum256(float v, float *red) {
 
 // =====================================================================================
 // GEMM: out[t][row] = epi( sum_k W[row][k] * X[t][k] ),  W pre-tiled, X = f16 (hi[,lo]) operand
+//
+// K-stationary skinny GEMM.  A block owns `spb` strips of 16 output rows and one K range; wave w of
+// the block owns k in [kbeg + w*KW, +KW), KW = KSW*32.  Each wave loads its slice of X ONCE, straight
+// from L2 into MFMA B-fragment registers (rows beyond T clamp to the last row, so the traffic is T*64 B
+// per k-step), then streams the 1 KiB weight tiles of strip after strip from HBM (non-temporal; the
+// next strip's tiles are in flight while the current strip is multiplied).  The per-wave partial
+// accumulators are parked in LDS and reduced after ONE barrier; the reducing wave applies the epilogue.
+// No X staging, no chunk loop: every load of the kernel is issued within the first few hundred cycles.
 // =====================================================================================
-template <int FMT> struct WGroup;                  // registers holding one 256-k group of one strip
-template <> struct WGroup<W_F16> { u32x4 q[8]; };
-template <> struct WGroup<W_INT8> { u32x4 q[4]; uint2 s; };
-template <> struct WGroup<W_NF4> { u32x4 q[2]; uint2 s; };
+template <int FMT> struct Fmt;
+template <> struct Fmt<W_F16> { static constexpr int TK = 32, KS = 1, SH = 5; };
+template <> struct Fmt<W_INT8> { static constexpr int TK = 64, KS = 2, SH = 6; };
+template <> struct Fmt<W_NF4> { static constexpr int TK = 128, KS = 4, SH = 7; };
 
-template <int FMT>
-__device__ __forceinline__ void load_group(WGroup<FMT> &g, const GemmProb &P, int strip, int k0, int kend, int lane) {
-    if constexpr (FMT == W_F16) {
-        const int KT = P.K >> 5;
-        const u32x4 *base = (const u32x4 *)P.W + ((long)strip * KT + (k0 >> 5)) * 64 + lane;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (k0 + j * 32 < kend) g.q[j] = __builtin_nontemporal_load(base + j * 64);
-            else g.q[j] = (u32x4){0u, 0u, 0u, 0u};
-        }
-    } else if constexpr (FMT == W_INT8) {
-        const int KT = P.K >> 6;
-        const u32x4 *base = (const u32x4 *)P.W + ((long)strip * KT + (k0 >> 6)) * 64 + lane;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (k0 + j * 64 < kend) g.q[j] = __builtin_nontemporal_load(base + j * 64);
-            else g.q[j] = (u32x4){0u, 0u, 0u, 0u};
-        }
-        const int NG = P.K >> 8;
-        const uint2 *sb = (const uint2 *)P.S + ((long)strip * NG + (k0 >> 8)) * 16 + (lane & 15);
-        g.s = (k0 < kend) ? *sb : make_uint2(0, 0);
-    } else {
-        const int KT = P.K >> 7;
-        const u32x4 *base = (const u32x4 *)P.W + ((long)strip * KT + (k0 >> 7)) * 64 + lane;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (k0 + j * 128 < kend) g.q[j] = __builtin_nontemporal_load(base + j * 64);
-            else g.q[j] = (u32x4){0u, 0u, 0u, 0u};
-        }
-        const int NG = P.K >> 8;
-        const uint2 *sb = (const uint2 *)P.S + ((long)strip * NG + (k0 >> 8)) * 16 + (lane & 15);
-        g.s = (k0 < kend) ? *sb : make_uint2(0, 0);
-    }
-}
+constexpr int RS = 8;                                   // k-steps (of 32) per register round = 256 k
+template <int FMT> struct WRound {                      // one strip's tiles for 256 k of this wave's K slice
+    u32x4 q[RS / Fmt<FMT>::KS];
+    uint2 s;                                            // quant scales of the 256-k group (unused for fp16)
+};
 
 __device__ __forceinline__ f16x2 as_h2(u32 v) { return __builtin_bit_cast(f16x2, v); }
 __device__ __forceinline__ u32 as_u32(f16x2 v) { return __builtin_bit_cast(u32, v); }
+
+// TAIL = false: the caller guarantees the whole 256-k round lies inside [.., kend) -> branch-free
+template <int FMT, bool TAIL>
+__device__ __forceinline__ void load_round(WRound<FMT> &w, const GemmProb &P, int strip, int k0, int kend, bool ok, int lane) {
+    constexpr int NTILE = RS / Fmt<FMT>::KS, TK = Fmt<FMT>::TK, SH = Fmt<FMT>::SH;
+    const int KT = P.K >> SH;
+    const u32x4 *base = (const u32x4 *)P.W + ((long)strip * KT + (k0 >> SH)) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < NTILE; ++j) {
+        if (!TAIL || (ok && k0 + j * TK < kend)) w.q[j] = __builtin_nontemporal_load(base + j * 64);
+        else w.q[j] = (u32x4){0u, 0u, 0u, 0u};
+    }
+    if constexpr (FMT != W_F16) {
+        const int NG = P.K >> 8;
+        const uint2 *sb = (const uint2 *)P.S + ((long)strip * NG + (k0 >> 8)) * 16 + (lane & 15);
+        w.s = (!TAIL || (ok && k0 < kend)) ? *sb : make_uint2(0, 0);
+    } else {
+        w.s = make_uint2(0, 0);
+    }
+}
 
 // int8: two bytes of `d` (selected by `sel`) -> half2 of a*q+b, one rounding (v_pk_fma_f16)
 __device__ __forceinline__ u32 dq8(u32 d, u32 sel, f16x2 a2, f16x2 b2) {
@@ -112,7 +111,6 @@ __device__ __forceinline__ u32 dq8(u32 d, u32 sel, f16x2 a2, f16x2 b2) {
 }
 
 // NF4 code points rounded to fp16 (oracle: NF4_TABLE_F16), as byte tables for v_perm lookups.
-// value i = TH[i]<<8 | TL[i]
 __device__ __constant__ unsigned short nf4_f16_bits[16] = {
     0xBC00, 0xB992, 0xB833, 0xB652, 0xB48D, 0xB1EA, 0xADD4, 0x0000,
     0x2D18, 0x3126, 0x33E0, 0x3568, 0x370D, 0x3880, 0x39C9, 0x3C00};
@@ -147,14 +145,15 @@ __device__ __forceinline__ void nf4_lookup4(u32 n, const Nf4Lut &t, u32 &h01, u3
     h23 = __builtin_amdgcn_perm(Hh, L, 0x07030602u);
 }
 
+// MFMA A fragment (16 rows x 32 k) of k-step `ks` (0..RS) of a round
 template <int FMT>
-__device__ __forceinline__ f16x8 frag(const WGroup<FMT> &g, int ks, const Nf4Lut &lut) {
+__device__ __forceinline__ f16x8 frag(const WRound<FMT> &w, int ks, const Nf4Lut &lut) {
     if constexpr (FMT == W_F16) {
-        return __builtin_bit_cast(f16x8, g.q[ks]);
+        return __builtin_bit_cast(f16x8, w.q[ks]);
     } else if constexpr (FMT == W_INT8) {
-        const u32x4 q = g.q[ks >> 1];
+        const u32x4 q = w.q[ks >> 1];
         const u32 d0 = (ks & 1) ? q.z : q.x, d1 = (ks & 1) ? q.w : q.y;
-        const u32 ab = (ks >> 2) ? g.s.y : g.s.x;            // 128-block of this k-step
+        const u32 ab = (ks >> 2) ? w.s.y : w.s.x;                // 128-block inside the 256-group
         const f16x2 abh = as_h2(ab);
         const f16x2 a2 = {abh[0], abh[0]}, b2 = {abh[1], abh[1]};
         u32x4 r;
@@ -164,11 +163,10 @@ __device__ __forceinline__ f16x8 frag(const WGroup<FMT> &g, int ks, const Nf4Lut
         r.w = dq8(d1, 0x04030402u, a2, b2);
         return __builtin_bit_cast(f16x8, r);
     } else {
-        const u32x4 q = g.q[ks >> 2];
-        const int w = ks & 3;
-        const u32 d = w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w;
-        // absmax of 64-block (ks>>1) inside the 256-group: 4 halfs packed in g.s
-        const u32 sw = (ks >> 2) ? g.s.y : g.s.x;
+        const u32x4 q = w.q[ks >> 2];
+        const int wsel = ks & 3;
+        const u32 d = wsel == 0 ? q.x : wsel == 1 ? q.y : wsel == 2 ? q.z : q.w;
+        const u32 sw = (ks >> 2) ? w.s.y : w.s.x;                // 64-blocks 2*(ks>>2) + ((ks>>1)&1)
         const f16x2 sh = as_h2(sw);
         const _Float16 am = ((ks >> 1) & 1) ? sh[1] : sh[0];
         const f16x2 am2 = {am, am};
@@ -184,137 +182,159 @@ __device__ __forceinline__ f16x8 frag(const WGroup<FMT> &g, int ks, const Nf4Lut
     }
 }
 
-template <int NT, bool HILO, int FMT>
-__device__ __forceinline__ void compute_group(const WGroup<FMT> &g, f32x4 (&acc)[NT], const _Float16 *xs_hi,
-                                              const _Float16 *xs_lo, int stride_h, int kofs, int k0, int kend,
-                                              int rows_valid, int lane, const Nf4Lut &lut) {
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        if (k0 + ks * 32 < kend) {                                  // wave-uniform
-            const f16x8 a = frag<FMT>(g, ks, lut);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                int row = nt * 16 + (lane & 15);
-                row = row < rows_valid ? row : rows_valid - 1;
-                const int off = row * stride_h + kofs + ks * 32 + (lane >> 4) * 8;
-                const f16x8 bh = *(const f16x8 *)(xs_hi + off);
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh, acc[nt], 0, 0, 0);
-                if constexpr (HILO) {
-                    const f16x8 bl = *(const f16x8 *)(xs_lo + off);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, acc[nt], 0, 0, 0);
-                }
-            }
-        }
-    }
-}
-
-template <int NT, bool HILO, int FMT>
+template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, int FMT>
 __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int KW = KSW * 32, SUB = KSW / RS, RK = RS * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches/addresses
     const int lb = (int)blockIdx.x - P.block_begin;
     const int kb = lb / P.nblk_strip, sb = lb - kb * P.nblk_strip;
-    const int ksw = P.ksw, spb = 4 / ksw;
-    const int strip = sb * spb + wave / ksw;
-    const int kpart = wave % ksw;
-    const int strips = P.rows >> 4;
-    const bool strip_ok = strip < strips;
+    const int spb = P.spb, nw = P.nw;                             // nw = waves of this block that own K slices
+    const int strip0 = sb * spb;
+    const int nstrip = min(spb, (P.rows >> 4) - strip0);
     const int Kb = P.K / P.ksb;
     const int kbeg = kb * Kb, kend = kbeg + Kb;
-    const int kc = L.kc;
-    const int kw = kc / ksw;                                       // k per wave per chunk
-    const int gpc = kw / GROUP_K;                                  // groups per wave per chunk
-    const int nchunks = (Kb + kc - 1) / kc;
-    const int stride_h = kc + 8;                                   // halfs; +16 B pad against bank conflicts
-    _Float16 *xs_hi = (_Float16 *)smem;
-    _Float16 *xs_lo = xs_hi + (long)L.rows_st * stride_h;
+    const int nslice = (Kb + KW - 1) / KW;                        // >= nw; a wave takes slices wave, wave+nw, ...
+    f32x4 *red = (f32x4 *)smem;                                   // [spb][nw][NT][64 lanes]
     Nf4Lut lut;
     if constexpr (FMT == W_NF4) lut = make_nf4_lut();
 
-    for (int t0 = 0; t0 < L.T; t0 += NT * 16) {
-        const int rows_valid = min(L.rows_st, L.T - t0);
-        f32x4 acc[NT];
+    // one 256-k round of MFMAs: acc += W(round) * X(sub)
+    auto mma_round = [&](const WRound<FMT> &w, f32x4 (&acc)[NT], const f16x8 (&xb)[NT][KSW], const f16x8 (*xl)[HILO ? KSW : 1],
+                         int sub, int k0) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < RS; ++ks) {
+            if (!TAIL || k0 + (sub * RS + ks) * 32 < kend) {
+                const f16x8 a = frag<FMT>(w, ks, lut);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[nt][sub * RS + ks], acc[nt], 0, 0, 0);
+                    if constexpr (HILO) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xl[nt][sub * RS + ks], acc[nt], 0, 0, 0);
+                }
+            }
+        }
+    };
 
-        WGroup<FMT> cur, nxt;
-        const int ngroups = nchunks * gpc;
-        if (strip_ok) load_group<FMT>(cur, P, strip, kbeg + kpart * kw, kend, lane);
-        for (int c = 0; c < nchunks; ++c) {
-            const int ck0 = kbeg + c * kc;
-            __syncthreads();
-            {   // stage X[t0 .. t0+rows_valid)[ck0 .. ck0+kc) -> LDS, 16 B pieces
-                const int ppr = kc >> 3;
-                const int total = rows_valid * ppr;
-                for (int p = tid; p < total; p += GEMM_THREADS) {
-                    const int r = p / ppr, c8 = p - r * ppr;
-                    const int k = ck0 + c8 * 8;
-                    uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
-                    if (k < kend) {
-                        vh = *(const uint4 *)(P.xhi + (long)(t0 + r) * P.ldx + k);
-                        if constexpr (HILO) vl = *(const uint4 *)(P.xlo + (long)(t0 + r) * P.ldx + k);
-                    }
-                    *(uint4 *)(xs_hi + r * stride_h + c8 * 8) = vh;
-                    if constexpr (HILO) *(uint4 *)(xs_lo + r * stride_h + c8 * 8) = vl;
-                }
-            }
-            __syncthreads();
-            if (strip_ok) {
-                for (int gi = 0; gi < gpc; ++gi) {
-                    const int g = c * gpc + gi;
-                    const int k0 = ck0 + kpart * kw + gi * GROUP_K;
-                    if (g + 1 < ngroups) {
-                        const int c2 = (gi + 1 < gpc) ? c : c + 1;
-                        const int gi2 = (gi + 1 < gpc) ? gi + 1 : 0;
-                        load_group<FMT>(nxt, P, strip, kbeg + c2 * kc + kpart * kw + gi2 * GROUP_K, kend, lane);
-                    }
-                    compute_group<NT, HILO, FMT>(cur, acc, xs_hi, xs_lo, stride_h, kpart * kw + gi * GROUP_K, k0, kend,
-                                                 rows_valid, lane, lut);
-                    cur = nxt;
-                }
-            }
-        }
-        // ---- reduce the ksw partial accumulators of a strip through LDS
-        if (ksw > 1) {
-            __syncthreads();
-            f32x4 *red = (f32x4 *)smem;                           // [wave][nt][lane]
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) red[(wave * NT + nt) * 64 + lane] = acc[nt];
-            __syncthreads();
-            if (kpart == 0) {
-                for (int w2 = 1; w2 < ksw; ++w2)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[nt] += red[((wave + w2) * NT + nt) * 64 + lane];
-            }
-        }
-        // ---- epilogue
-        if (strip_ok && kpart == 0) {
-            const int row0 = strip * 16 + (lane >> 4) * 4;
+    for (int t0 = 0; t0 < L.T; t0 += NT * 16) {
+        for (int sl = wave; sl < nslice && wave < nw; sl += nw) {
+            const int k0 = kbeg + sl * KW;
+            // rounds of this slice that lie inside the K range (the last slice may be short)
+            const int nsub = TAIL ? SUB : min(SUB, (kend - k0) / RK);
+            const int nround = nstrip * nsub;
+            WRound<FMT> cur, nxt;
+            // X slice of this wave -> B fragments (lane: token = lane&15, k = ks*32 + (lane>>4)*8 .. +8)
+            f16x8 xb[NT][KSW], xl[HILO ? NT : 1][HILO ? KSW : 1];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int t = t0 + nt * 16 + (lane & 15);
-                if (t < L.T) {
-                    float v[4];
+                int row = t0 + nt * 16 + (lane & 15);
+                row = row < L.T ? row : L.T - 1;
+                const _Float16 *ph = P.xhi + (long)row * P.ldx + k0 + (lane >> 4) * 8;
+                const _Float16 *pl = HILO ? P.xlo + (long)row * P.ldx + k0 + (lane >> 4) * 8 : nullptr;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float x = acc[nt][r];
-                        if (P.bias) x += P.bias[row0 + r];
-                        x = apply_act(P.act, x);
-                        if (P.post == POST_MUL) x *= P.m0[(long)t * P.ldm + row0 + r];
-                        else if (P.post == POST_MIX)
-                            x = P.m0[(long)t * P.ldm + row0 + r] + P.m1[(long)t * P.ldm + row0 + r] * x;
-                        v[r] = x;
-                    }
-                    if (P.out_f32) {
-                        float *o = P.out_f32 + (long)kb * P.partial_stride + (long)t * P.ldo + row0;
-                        *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
-                    }
-                    if (P.out_hi) {
-                        f16x4 h, l;
+                for (int sub = 0; sub < SUB; ++sub) {
+                    if (TAIL || sub < nsub) {                      // one uniform branch per 256-k round
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { _Float16 a, b; split_hilo(v[r], a, b); h[r] = a; l[r] = b; }
-                        *(f16x4 *)(P.out_hi + (long)t * P.ldh + row0) = h;
-                        if (P.out_lo) *(f16x4 *)(P.out_lo + (long)t * P.ldh + row0) = l;
+                        for (int k8 = 0; k8 < RS; ++k8) {
+                            const int ks = sub * RS + k8;
+                            const bool in = !TAIL || (k0 + ks * 32 < kend);
+                            xb[nt][ks] = in ? *(const f16x8 *)(ph + ks * 32) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                            if constexpr (HILO) xl[nt][ks] = in ? *(const f16x8 *)(pl + ks * 32) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                        }
+                    } else {
+#pragma unroll
+                        for (int k8 = 0; k8 < RS; ++k8) {
+                            xb[nt][sub * RS + k8] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                            if constexpr (HILO) xl[nt][sub * RS + k8] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                        }
                     }
+                }
+            }
+            // weights after X: the X fragments are L2 hits and complete first, so (in-order vmcnt) the MFMAs of round r
+            // only wait for rounds <= r while later rounds are still streaming in from HBM
+            load_round<FMT, TAIL>(cur, P, strip0, k0, kend, true, lane);
+            f32x4 acc[NT];
+            auto park = [&](int s) {                               // partial sums of strip s -> LDS slot of this wave
+                f32x4 *slot = red + ((s * nw + wave) * NT) * 64 + lane;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (sl == wave) slot[nt * 64] = acc[nt]; else slot[nt * 64] += acc[nt];
+                }
+            };
+            if constexpr (SHOT) {
+                // ---- single shot: every weight tile of this wave is in flight before the first MFMA.
+                // (host guarantees spb * SUB <= MAXR)
+                constexpr int MAXR = FMT == W_F16 ? 2 : 4;        // rounds a wave holds in registers at once (gemm_max_rounds)
+                WRound<FMT> w[MAXR];
+                w[0] = cur;
+#pragma unroll
+                for (int r = 1; r < MAXR; ++r) {
+                    const int s = r / SUB, sub = r % SUB;
+                    if (s < nstrip && sub < nsub) load_round<FMT, TAIL>(w[r], P, strip0 + s, k0 + sub * RK, kend, true, lane);
+                }
+#pragma unroll
+                for (int r = 0; r < MAXR; ++r) {
+                    const int s = r / SUB, sub = r % SUB;          // compile-time after unrolling
+                    if (s < nstrip) {
+                        if (sub == 0) {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                        if (sub < nsub) mma_round(w[r], acc, xb, xl, sub, k0);
+                        if (sub == SUB - 1) park(s);
+                    }
+                }
+            } else {
+                for (int s = 0; s < nstrip; ++s) {
+#pragma unroll
+                    for (int sub = 0; sub < SUB; ++sub) {          // compile-time: xb indices stay static
+                        if (sub < nsub) {
+                            const bool more_sub = sub + 1 < nsub;
+                            if (more_sub || s + 1 < nstrip)
+                                load_round<FMT, TAIL>(nxt, P, strip0 + (more_sub ? s : s + 1), k0 + (more_sub ? sub + 1 : 0) * RK, kend, true, lane);
+                            if (sub == 0) {
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            }
+                            mma_round(cur, acc, xb, xl, sub, k0);
+                            cur = nxt;
+                        }
+                    }
+                    park(s);
+                }
+            }
+            (void)nround;
+        }
+        __syncthreads();
+        // ---- reduce + epilogue: (strip, n-tile) items round-robin over the block's waves
+        const int nwaves = blockDim.x >> 6;
+        for (int item = wave; item < nstrip * NT; item += nwaves) {
+            const int s = item / NT, nt = item - s * NT;
+            f32x4 v4 = red[((s * nw) * NT + nt) * 64 + lane];
+            for (int w2 = 1; w2 < nw; ++w2) v4 += red[((s * nw + w2) * NT + nt) * 64 + lane];
+            const int row0 = (strip0 + s) * 16 + (lane >> 4) * 4;
+            const int t = t0 + nt * 16 + (lane & 15);
+            if (t < L.T) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = v4[r];
+                    if (P.bias) x += P.bias[row0 + r];
+                    x = apply_act(P.act, x);
+                    if (P.post == POST_MUL) x *= P.m0[(long)t * P.ldm + row0 + r];
+                    else if (P.post == POST_MIX)
+                        x = P.m0[(long)t * P.ldm + row0 + r] + P.m1[(long)t * P.ldm + row0 + r] * x;
+                    v[r] = x;
+                }
+                if (P.out_f32) {
+                    float *o = P.out_f32 + (long)kb * P.partial_stride + (long)t * P.ldo + row0;
+                    *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
+                }
+                if (P.out_hi) {
+                    f16x4 h, l;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { _Float16 a, b; split_hilo(v[r], a, b); h[r] = a; l[r] = b; }
+                    *(f16x4 *)(P.out_hi + (long)t * P.ldh + row0) = h;
+                    if (P.out_lo) *(f16x4 *)(P.out_lo + (long)t * P.ldh + row0) = l;
                 }
             }
         }
@@ -322,117 +342,162 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
     }
 }
 
-template <int NT, bool HILO>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmLaunch L) {
+template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL>
+__global__ __launch_bounds__(GEMM_MAX_WAVES * 64) void gemm_kernel(const GemmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int pi = 0;
     for (int i = 1; i < L.nprob; ++i)
         if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
     const GemmProb &P = L.p[pi];
-    if (P.fmt == W_F16) gemm_body<NT, HILO, W_F16>(L, P, smem);
-    else if (P.fmt == W_INT8) gemm_body<NT, HILO, W_INT8>(L, P, smem);
-    else gemm_body<NT, HILO, W_NF4>(L, P, smem);
+    if (P.fmt == W_F16) gemm_body<NT, KSW, HILO, SHOT, TAIL, W_F16>(L, P, smem);
+    else if (P.fmt == W_INT8) gemm_body<NT, KSW, HILO, SHOT, false, W_INT8>(L, P, smem);   // quantised K is a multiple of 256
+    else gemm_body<NT, KSW, HILO, SHOT, false, W_NF4>(L, P, smem);
 }
 
-void launch_gemm(const GemmLaunch &L, int NT, bool hilo, hipStream_t s) {
-    size_t xbytes = (size_t)L.rows_st * (L.kc + 8) * 2 * (hilo ? 2 : 1);
-    size_t rbytes = (size_t)4 * NT * 64 * 16;
-    size_t lds = xbytes > rbytes ? xbytes : rbytes;
-    dim3 grid(L.total_blocks), block(GEMM_THREADS);
+void gemm_variant(int T, bool hilo, int &NT, int &KSW) {
+    if (hilo) { NT = 1; KSW = 8; }
+    else if (T <= 16) { NT = 1; KSW = 16; }
+    else { NT = 2; KSW = 8; }
+}
+
+void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
+    int NT, KSW;
+    gemm_variant(L.T, hilo, NT, KSW);
+    const size_t lds = (size_t)L.lds_items * NT * 64 * 16;
+    dim3 grid(L.total_blocks), block(L.threads);
     static bool attr_done[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
+#define GEMM_V3(X, sh, tl) X(1, 8, true, sh, tl) X(1, 16, false, sh, tl) X(2, 8, false, sh, tl)
+#define GEMM_VARIANTS(X) GEMM_V3(X, true, true) GEMM_V3(X, true, false) GEMM_V3(X, false, true) GEMM_V3(X, false, false)
     if (!attr_done[dev & 15]) {                               // allow > 64 KiB dynamic LDS (gfx950: 160 KiB / CU)
         const int cap = 160 * 1024;
-        (void)hipFuncSetAttribute((const void *)gemm_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void *)gemm_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void *)gemm_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void *)gemm_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void *)gemm_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void *)gemm_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+#define SET_ATTR(a, b, c, d, e) (void)hipFuncSetAttribute((const void *)gemm_kernel<a, b, c, d, e>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        GEMM_VARIANTS(SET_ATTR)
+#undef SET_ATTR
         attr_done[dev & 15] = true;
     }
-#define LG(NT_, H_) hipLaunchKernelGGL((gemm_kernel<NT_, H_>), grid, block, lds, s, L)
-    if (hilo) { if (NT == 1) LG(1, true); else if (NT == 2) LG(2, true); else LG(4, true); }
-    else      { if (NT == 1) LG(1, false); else if (NT == 2) LG(2, false); else LG(4, false); }
-#undef LG
+    const bool shot = L.single_shot != 0, tail = L.tail != 0;
+#define LAUNCH(a, b, c, d, e) if (NT == a && KSW == b && hilo == c && shot == d && tail == e) hipLaunchKernelGGL((gemm_kernel<a, b, c, d, e>), grid, block, lds, s, L);
+    GEMM_VARIANTS(LAUNCH)
+#undef LAUNCH
+#undef GEMM_VARIANTS
+#undef GEMM_V3
 }
+
+int gemm_max_rounds(int fmt) { return fmt == W_F16 ? 2 : 4; }
 
 // =====================================================================================
 // Row kernels (one 256-thread block per row)
 // =====================================================================================
-// PT = values per thread (C <= PT*256).  Everything stays in registers (fully unrolled, predicated).
-#define ROW_FOR(i, c) _Pragma("unroll") for (int i = 0, c = threadIdx.x; i < PT; ++i, c += 256) if (c < C)
+// PT = float4 groups per thread (C <= PT*1024).  Everything stays in registers (fully unrolled, predicated),
+// all global loads of a phase are issued before the first dependent use.
+#define ROW_FOR(i, c) _Pragma("unroll") for (int i = 0, c = threadIdx.x * 4; i < PT; ++i, c += 1024) if (c < C)
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *(const float4 *)p; }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 template <int PT>
-__device__ __forceinline__ void row_load_sum(const float *x_in, const float *P, int np, long pstride, int row, int C,
-                                             float (&v)[PT]) {
-    ROW_FOR(i, c) {
-        float a = x_in[(long)row * C + c];
-        for (int j = 0; j < np; ++j) a += P[j * pstride + (long)row * C + c];
-        v[i] = a;
+__device__ __forceinline__ void row_load_sum(const float *__restrict__ x_in, const float *__restrict__ P, int np, long pstride,
+                                             int row, int C, float4 (&v)[PT]) {
+    ROW_FOR(i, c) v[i] = ld4(x_in + (long)row * C + c);
+    for (int j = 0; j < np; ++j) {
+        ROW_FOR(i, c) v[i] = v[i] + ld4(P + j * pstride + (long)row * C + c);
     }
 }
 // two-pass LayerNorm (mean, then centred variance), eps 1e-5 — same order as the oracle's _ln
 template <int PT>
-__device__ __forceinline__ void row_layernorm(float (&v)[PT], int C, const float *w, const float *b, float *red) {
+__device__ __forceinline__ void row_layernorm(float4 (&v)[PT], int C, const float *__restrict__ w, const float *__restrict__ b, float *red) {
+    float4 wv[PT], bv[PT];
+    ROW_FOR(i, c) { wv[i] = ld4(w + c); bv[i] = ld4(b + c); }
     float s = 0.f;
-    ROW_FOR(i, c) s += v[i];
+    ROW_FOR(i, c) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     const float mean = block_sum256(s, red) / (float)C;
     float q = 0.f;
-    ROW_FOR(i, c) { const float d = v[i] - mean; q += d * d; }
+    ROW_FOR(i, c) {
+        const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
     const float var = block_sum256(q, red) / (float)C;
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    ROW_FOR(i, c) v[i] = (v[i] - mean) * rstd * w[c] + b[c];
+    ROW_FOR(i, c) {
+        v[i].x = (v[i].x - mean) * rstd * wv[i].x + bv[i].x;
+        v[i].y = (v[i].y - mean) * rstd * wv[i].y + bv[i].y;
+        v[i].z = (v[i].z - mean) * rstd * wv[i].z + bv[i].z;
+        v[i].w = (v[i].w - mean) * rstd * wv[i].w + bv[i].w;
+    }
+}
+
+__device__ __forceinline__ void store_operand4(_Float16 *__restrict__ hi, _Float16 *__restrict__ lo, long off, float4 o) {
+    f16x4 h, l;
+    _Float16 a, b;
+    split_hilo(o.x, a, b); h[0] = a; l[0] = b;
+    split_hilo(o.y, a, b); h[1] = a; l[1] = b;
+    split_hilo(o.z, a, b); h[2] = a; l[2] = b;
+    split_hilo(o.w, a, b); h[3] = a; l[3] = b;
+    *(f16x4 *)(hi + off) = h;
+    if (lo) *(f16x4 *)(lo + off) = l;
 }
 
 template <int PT>
 __global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
     __shared__ float red[4];
     const int t = blockIdx.x, C = a.C;
-    float xv[PT], pv[PT];
-    row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, t, C, xv);
-    if (a.x_out) { ROW_FOR(i, c) a.x_out[(long)t * C + c] = xv[i]; }
-    row_layernorm<PT>(xv, C, a.lnw, a.lnb, red);
     const int slot = a.rm.slot[t], prev = a.rm.prev[t], last = a.rm.last[t];
-    float *sx = a.sx + (long)slot * a.sx_slot_stride;
-    if (prev >= 0) {
-        row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, prev, C, pv);
-        row_layernorm<PT>(pv, C, a.lnw, a.lnb, red);
-    } else {
-        ROW_FOR(i, c) pv[i] = sx[c];
-    }
+    float *__restrict__ sx = a.sx + (long)slot * a.sx_slot_stride;
+    float4 xv[PT], pv[PT];
+    row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, t, C, xv);
+    if (prev >= 0) row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, prev, C, pv);
+    else { ROW_FOR(i, c) pv[i] = ld4(sx + c); }
+    if (a.x_out) { ROW_FOR(i, c) *(float4 *)(a.x_out + (long)t * C + c) = xv[i]; }
+    row_layernorm<PT>(xv, C, a.lnw, a.lnb, red);
+    if (prev >= 0) row_layernorm<PT>(pv, C, a.lnw, a.lnb, red);
     if (last >= 0) {            // this block owns the slot's token-shift state write (after its own read above)
         if (last == t) {
-            ROW_FOR(i, c) sx[c] = xv[i];
+            ROW_FOR(i, c) *(float4 *)(sx + c) = xv[i];
         } else {
-            float lv[PT];
+            float4 lv[PT];
             row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, last, C, lv);
             row_layernorm<PT>(lv, C, a.lnw, a.lnb, red);
-            ROW_FOR(i, c) sx[c] = lv[i];
+            ROW_FOR(i, c) *(float4 *)(sx + c) = lv[i];
         }
     }
-    ROW_FOR(i, c) {
-        const float xx = xv[i], pr = pv[i];
-        const float dx = pr - xx;
-        if (a.xx_out) a.xx_out[(long)t * C + c] = xx;
-        if (a.dx_out) a.dx_out[(long)t * C + c] = dx;
-        for (int m = 0; m < a.nmix; ++m) {
-            const float mu = a.mu[m][c];
-            const float o = a.mode == 0 ? xx * mu + pr * (1.0f - mu) : xx + dx * mu;
-            _Float16 h, l;
-            split_hilo(o, h, l);
-            a.ohi[m][(long)t * a.ldh + c] = h;
-            if (a.olo[m]) a.olo[m][(long)t * a.ldh + c] = l;
+    float4 dxv[PT];
+    ROW_FOR(i, c) dxv[i] = make_float4(pv[i].x - xv[i].x, pv[i].y - xv[i].y, pv[i].z - xv[i].z, pv[i].w - xv[i].w);
+    if (a.xx_out) { ROW_FOR(i, c) *(float4 *)(a.xx_out + (long)t * C + c) = xv[i]; }
+    if (a.dx_out) { ROW_FOR(i, c) *(float4 *)(a.dx_out + (long)t * C + c) = dxv[i]; }
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+        if (m < a.nmix) {
+            const float *__restrict__ mu = a.mu[m];
+            _Float16 *__restrict__ oh = a.ohi[m];
+            _Float16 *__restrict__ ol = a.olo[m];
+            float4 muv[PT];
+            ROW_FOR(i, c) muv[i] = ld4(mu + c);
+            ROW_FOR(i, c) {
+                float4 o;
+                if (a.mode == 0) {
+                    o.x = xv[i].x * muv[i].x + pv[i].x * (1.0f - muv[i].x);
+                    o.y = xv[i].y * muv[i].y + pv[i].y * (1.0f - muv[i].y);
+                    o.z = xv[i].z * muv[i].z + pv[i].z * (1.0f - muv[i].z);
+                    o.w = xv[i].w * muv[i].w + pv[i].w * (1.0f - muv[i].w);
+                } else {
+                    o.x = xv[i].x + dxv[i].x * muv[i].x;
+                    o.y = xv[i].y + dxv[i].y * muv[i].y;
+                    o.z = xv[i].z + dxv[i].z * muv[i].z;
+                    o.w = xv[i].w + dxv[i].w * muv[i].w;
+                }
+                store_operand4(oh, ol, (long)t * a.ldh + c, o);
+            }
         }
     }
 }
 #define ROW_DISPATCH(KERN, C_, GRID, ...)                                                          \
     do {                                                                                           \
-        if ((C_) <= 1024) hipLaunchKernelGGL((KERN<4>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__); \
-        else if ((C_) <= 2048) hipLaunchKernelGGL((KERN<8>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__); \
-        else if ((C_) <= 4096) hipLaunchKernelGGL((KERN<16>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERN<32>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__);             \
+        if ((C_) <= 1024) hipLaunchKernelGGL((KERN<1>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__); \
+        else if ((C_) <= 2048) hipLaunchKernelGGL((KERN<2>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__); \
+        else if ((C_) <= 4096) hipLaunchKernelGGL((KERN<4>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERN<8>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__);             \
     } while (0)
 
 void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s) { ROW_DISPATCH(ln_shift_kernel, a.C, T, a); }
@@ -443,10 +508,13 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
     const int t = blockIdx.x, C = a.C;
     int tok = a.token[t];
     tok = tok < 0 ? 0 : (tok >= a.V ? a.V - 1 : tok);
-    float v[PT];
-    ROW_FOR(i, c) v[i] = (float)a.emb[(long)tok * C + c];
+    float4 v[PT];
+    ROW_FOR(i, c) {
+        const f16x4 e = *(const f16x4 *)(a.emb + (long)tok * C + c);
+        v[i] = make_float4((float)e[0], (float)e[1], (float)e[2], (float)e[3]);
+    }
     row_layernorm<PT>(v, C, a.lnw, a.lnb, red);
-    ROW_FOR(i, c) a.x[(long)t * C + c] = v[i];
+    ROW_FOR(i, c) *(float4 *)(a.x + (long)t * C + c) = v[i];
 }
 void launch_embed(const EmbedArgs &a, int T, hipStream_t s) { ROW_DISPATCH(embed_kernel, a.C, T, a); }
 
@@ -455,15 +523,10 @@ __global__ __launch_bounds__(256) void ln_out_kernel(const LnOutArgs a) {
     __shared__ float red[4];
     const int o = blockIdx.x, C = a.C;
     const int t = a.out_rows[o];
-    float v[PT];
+    float4 v[PT];
     row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, t, C, v);
     row_layernorm<PT>(v, C, a.lnw, a.lnb, red);
-    ROW_FOR(i, c) {
-        _Float16 h, l;
-        split_hilo(v[i], h, l);
-        a.ohi[(long)o * a.ldh + c] = h;
-        if (a.olo) a.olo[(long)o * a.ldh + c] = l;
-    }
+    ROW_FOR(i, c) store_operand4(a.ohi, a.olo, (long)o * a.ldh + c, v[i]);
 }
 void launch_ln_out(const LnOutArgs &a, int n_out, hipStream_t s) { ROW_DISPATCH(ln_out_kernel, a.C, n_out, a); }
 

@@ -93,6 +93,7 @@ ABI_SYMBOLS = {
                                        C.POINTER(C.c_int32)]),
     "rwkv_decode_greedy": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_uint32),
                                        C.POINTER(C.c_float)]),
+    "rwkv_bench_gemm": (C.c_int32, [C.c_int32] * 8 + [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 PROFILE_FAMILIES = 8
 
@@ -400,6 +401,14 @@ class Runtime:
         a = np.empty(self.state._np_shape(), np.float32)
         _check(lib().rwkv_read_init_state(self._h, p, n, a.ctypes.data))
         return a
+
+
+def bench_gemm(rows: int, K: int, fmt: int, T: int, hilo: bool = False, spb: int = 0, nmat: int = 16,
+               iters: int = 200) -> tuple[float, float]:
+    """Kernel microbench hook: (microseconds per launch inside a captured graph, blocks per launch)."""
+    us, lds = C.c_float(), C.c_float()
+    _check(lib().rwkv_bench_gemm(rows, K, fmt, T, int(hilo), spb, nmat, iters, C.byref(us), C.byref(lds)))
+    return float(us.value), float(lds.value)
 
 
 def softmax(rt: Runtime, tensors: list[np.ndarray]) -> list[np.ndarray]:

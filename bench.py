@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py — decode throughput of the RWKV hot path on MI355X, with roofline and CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload v6-3b] [--batch 32] [--quant int8]
+
+A "step" is one decode step of the hot path over a batch of B slots (one token per slot: B tokens),
+inputs (weights, recurrent state, token ids) resident in HBM: the arg-max token is fed back on the device
+(`rwkv_decode_greedy`), so no PCIe traffic sits inside the timed region.  N > 1: one process per GPU
+(launched by torch.distributed.run), every rank is an independent replica with its own weights, slots and
+stream (replicas only, no collective on the data path); weak scaling.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="v6-3b")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--quant", default="int8", choices=["none", "int8", "nf4"])
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep", default="", help="extra batch sizes reported under 'sweep', e.g. 1,8")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    from ai00_server_amd import runtime as rt
+    from oracle import rwkv_ref as R   # checkpoint synthesis + the cpu_baseline leg only
+
+    t0 = time.time()
+    st, tensors = R.synth_st(args.workload, fast=True)
+    info = R.model_info(tensors)
+    shapes = {k: v.shape for k, v in tensors.items()}
+    qt = {"none": 0, "int8": 1, "nf4": 2}[args.quant]
+    ql = info.num_layer if qt else 0
+    B = args.batch
+    t_synth = time.time() - t0
+
+    t0 = time.time()
+    eng = (rt.ModelBuilder(st, adapter=local_rank).quant(ql, rt.Quant(qt))
+           .build(max_batch=max(B, 1), token_chunk_size=max(128, B),
+                  precision=rt.Precision.Fp32 if args.precision == "fp32" else rt.Precision.Fp16))
+    t_load = time.time() - t0
+    del st
+
+    V = info.num_vocab
+    first = np.array([R.synth_prompt(s, 1)[0] % V for s in range(B)], dtype=np.uint32)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(nb, steps, warmup):
+        ft = first[:nb]
+        if warmup > 0:
+            eng.decode_greedy(ft, warmup)
+        barrier()
+        t = time.perf_counter()
+        toks, dev_ms = eng.decode_greedy(ft, steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        barrier()
+        if dist is not None:
+            x = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(x, op=dist.ReduceOp.MAX)
+            dt = float(x.item())
+        return dt, dev_ms, toks
+
+    dt, dev_ms, toks = timed(B, args.steps, args.warmup)
+    ms_per_step = dt * 1e3 / args.steps
+    value = B * world * args.steps / dt
+
+    ab = R.algorithmic_bytes(info, shapes, ql, qt, B)
+    step_frac = ab["per_step"] * (args.steps / dt) / HBM_PEAK
+
+    # ---- roofline of the dominant kernel (the layer GEMMs): per-launch hipEvent timing on the engine stream
+    roof = None
+    if rank == 0:
+        inp_tokens = [[int(first[b])] for b in range(B)]
+        fam_ms = {}
+        nprof = 5
+        for it in range(nprof + 1):
+            inp = rt.RnnInput([rt.RnnInputBatch(list(inp_tokens[b]) if b < B else [], rt.RnnOption.Last)
+                               for b in range(eng.max_batch)])
+            _, _, fam = eng.profile_infer(inp)
+            if it == 0:
+                continue        # first pass warms caches / clocks
+            for k, (ms, n) in fam.items():
+                a = fam_ms.setdefault(k, [0.0, 0])
+                a[0] += ms
+                a[1] += n
+        g_ms, g_n = fam_ms["gemm_layers"]
+        h_ms, h_n = fam_ms["gemm_head"]
+        head_bytes = V * info.num_emb * 2
+        vec_bytes = sum(int(np.prod(s)) * 2 for k, s in shapes.items() if len([d for d in s if d > 1]) <= 1)
+        layer_gemm_bytes = eng.weight_bytes - head_bytes - vec_bytes          # weights the layer GEMM launches stream
+        achieved = layer_gemm_bytes / (g_ms / nprof * 1e-3)
+        roof = {"bound": "hbm", "kernel": "gemm_kernel (layer projections)", "achieved": achieved / 1e9,
+                "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                "launches_per_step": g_n // nprof, "avg_launch_us": g_ms / g_n * 1e3,
+                "bytes_per_step": layer_gemm_bytes,
+                "head_gemm_GBps": head_bytes / (h_ms / nprof * 1e-3) / 1e9,
+                "family_ms_per_step": {k: v[0] / nprof for k, v in fam_ms.items()},
+                "step": {"bytes": ab["per_step"], "frac_of_peak": step_frac, "W_q": ab["W_q"], "S": ab["S"]}}
+
+    sweep = {}
+    if rank == 0 and args.sweep:
+        for nb in [int(x) for x in args.sweep.split(",") if x]:
+            if nb > eng.max_batch:
+                continue
+            d2, _, _ = timed(nb, args.steps, min(args.warmup, 10)) if dist is None else (None, None, None)
+            if d2:
+                abn = R.algorithmic_bytes(info, shapes, ql, qt, nb)
+                sweep[str(nb)] = {"tokens_per_s": nb * args.steps / d2, "ms_per_step": d2 * 1e3 / args.steps,
+                                  "frac_of_peak": abn["per_step"] * (args.steps / d2) / HBM_PEAK}
+
+    # PCIe-inclusive rate through rwkv_infer (logits D2H every token, as run.rs:809-832 does) — never `value`
+    pcie = None
+    if rank == 0:
+        nst = max(5, min(30, args.steps))
+        inp_tok = [int(x) for x in first]
+        t = time.perf_counter()
+        for _ in range(nst):
+            inp = rt.RnnInput([rt.RnnInputBatch([inp_tok[b]] if b < B else [], rt.RnnOption.Last)
+                               for b in range(eng.max_batch)])
+            _, outs = eng.infer(inp)
+        pcie = B * nst / (time.perf_counter() - t)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the oracle ("port") on the host cores, B=1, bounded sample (fp32 weights, no quantisation on the CPU side)
+        t0 = time.time()
+        ref = R.RwkvRef(tensors)
+        s = ref.init_state()
+        ref.forward([int(first[0])], s)                # warm
+        n_tok, t1 = 0, time.time()
+        while time.time() - t1 < 12.0 and n_tok < 64:
+            ref.forward([int(toks[n_tok % len(toks), 0])], s)
+            n_tok += 1
+        cdt = time.time() - t1
+        cpu = {"value": n_tok / cdt, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+               "sample": f"{n_tok} decode tokens, batch 1, numpy fp32 oracle (weights fp16-rounded, unquantised), "
+                         f"{args.workload}"}
+    eng.close()
+
+    if rank == 0:
+        line = {"metric": "decode tokens/sec (whole job)", "value": value, "unit": "tokens/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": {"none": "f16", "int8": "u8->f16", "nf4": "nf4->f16"}[args.quant] + "/f32acc",
+                "data": "synthetic",
+                "config": {"workload": f"RWKV-{args.workload} {args.quant} decode, batch={B}/GPU, greedy, state+tokens resident in HBM",
+                           "quant": args.quant, "batch_per_gpu": B, "precision": args.precision,
+                           "parallelism": f"replicas x{world} (no collective)"},
+                "tokens_per_s_per_gpu": value / world, "device_ms_per_step": dev_ms / args.steps,
+                "roofline": roof, "cpu_baseline": cpu, "pcie_inclusive_tokens_per_s": pcie, "sweep": sweep or None,
+                "load_s": t_load, "synth_s": t_synth}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -162,6 +162,12 @@ rwkv_status rwkv_profile_infer(rwkv_engine *e, const rwkv_slot_input *in, rwkv_s
 rwkv_status rwkv_decode_greedy(rwkv_engine *e, int32_t n_slots, const uint32_t *first_tokens,
                                int32_t n_steps, uint32_t *out_tokens, float *elapsed_ms);
 
+/* kernel microbench: one [rows x K] GEMM problem in weight format `fmt` (0 fp16, 1 int8, 2 nf4) against T
+ * activation rows; `nmat` distinct weight copies are rotated so re-reads miss the Infinity Cache.
+ * ksw = 0 lets the planner choose the in-block K split.  Returns microseconds per launch. */
+rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int32_t hilo, int32_t ksw,
+                            int32_t nmat, int32_t iters, float *us_per_launch, float *lds_kib);
+
 #ifdef __cplusplus
 }
 #endif

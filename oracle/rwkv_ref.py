@@ -52,6 +52,21 @@ NF4_MID = ((NF4_TABLE[1:] + NF4_TABLE[:-1]) * np.float32(0.5)).astype(np.float32
 NF4_TABLE_F16 = NF4_TABLE.astype(np.float16)
 
 
+def big_empty(shape, dtype) -> np.ndarray:
+    """np.empty backed by an anonymous mmap with MADV_HUGEPAGE for large arrays: first-touch page
+    faults are the dominant cost of building multi-GB checkpoints inside sandboxed containers."""
+    import mmap
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    if n < (64 << 20):
+        return np.empty(shape, dtype)
+    m = mmap.mmap(-1, n, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    try:
+        m.madvise(14)  # MADV_HUGEPAGE
+    except (OSError, ValueError, AttributeError):
+        pass
+    return np.frombuffer(m, dtype=dtype).reshape(shape)
+
+
 # --------------------------------------------------------------------------------------
 # safetensors I/O (plain, so the oracle does not depend on the product's parser)
 # --------------------------------------------------------------------------------------
@@ -244,7 +259,9 @@ class RwkvRef:
             v16 = np.asarray(v, dtype=np.float16)
             if k in qn:
                 v16 = fake_quant(v16, quant_type)
-            self.w[k] = v16.astype(np.float32)
+            dst = big_empty(v16.shape, np.float32)
+            dst[...] = v16
+            self.w[k] = dst
 
     # ---- state slab: [L][N+2][C] fp32 == shape [C, N+2, L, 1] fastest-dim-first (run.rs:987)
     def state_shape(self):
@@ -465,91 +482,141 @@ CONFIGS = {
 
 
 def synth_checkpoint(version: int, L: int, C: int, F: int, V: int, seed: int = 20251024,
-                     fast: bool = False) -> dict[str, np.ndarray]:
+                     fast: bool = False, alloc=None, shapes_only: bool = False) -> dict[str, np.ndarray]:
     """Seeded synthetic fp16 tensors in the converted `.st` layout (App. A.1 of SURVEY.md;
     names/transposes follow convert_safetensors.py:96-101 literally).
-    `fast=True` fills the big matrices from a tiled random block (bench-only; same statistics)."""
+    `fast=True` fills the big matrices by tiling a 16M-sample random block (bench-only; same statistics).
+    `alloc(name, shape)` may supply the destination arrays (e.g. views into a file buffer);
+    `shapes_only=True` returns {name: shape} without generating anything."""
     rng = np.random.Generator(np.random.SFC64(seed))
     H, N = C // HEAD_SIZE, HEAD_SIZE
-    t: dict[str, np.ndarray] = {}
-    pool = None
-    if fast:
-        pool = rng.standard_normal(1 << 24, dtype=np.float32)
+    t: dict = {}
+    pools: dict = {}
+    base_pool = None
 
-    def mat(o, i, std=None):
+    def put(name, shape, gen):
+        shape = tuple(int(x) for x in shape)
+        if shapes_only:
+            t[name] = shape
+            return
+        dst = alloc(name, shape) if alloc is not None else np.empty(shape, np.float16)
+        gen(dst)
+        t[name] = dst
+
+    def mat(name, o, i, std=None):
         std = (0.5 / np.sqrt(i)) if std is None else std
-        if pool is not None and o * i > (1 << 20):
-            n = o * i
-            off = int(rng.integers(0, 1 << 20))
-            reps = -(-(n + off) // pool.size)
-            a = np.tile(pool, reps)[off:off + n] if reps > 1 else pool[off:off + n]
-            return (a * np.float32(std)).astype(np.float16).reshape(o, i)
-        return (rng.standard_normal((o, i), dtype=np.float32) * np.float32(std)).astype(np.float16)
 
-    def vec(shape, mean=0.0, std=0.02):
-        return (mean + rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float16)
+        def gen(dst):
+            nonlocal base_pool
+            if fast and o * i > (1 << 20):
+                key = float(std)
+                if key not in pools:
+                    if base_pool is None:
+                        base_pool = rng.standard_normal(1 << 24, dtype=np.float32)
+                    pools[key] = (base_pool * np.float32(std)).astype(np.float16)
+                pool = pools[key]
+                flat = dst.reshape(-1)
+                off = int(rng.integers(0, 1 << 20))
+                pos = 0
+                while pos < flat.size:
+                    n = min(pool.size - off, flat.size - pos)
+                    flat[pos:pos + n] = pool[off:off + n]
+                    pos += n
+                    off = 0
+            else:
+                dst[...] = (rng.standard_normal((o, i), dtype=np.float32) * np.float32(std)).astype(np.float16)
+        put(name, (o, i), gen)
 
-    def uni(shape, lo, hi):
-        return rng.uniform(lo, hi, size=shape).astype(np.float16)
+    def vec(name, shape, mean=0.0, std=0.02):
+        shape = (shape,) if isinstance(shape, int) else shape
+        put(name, shape, lambda d: d.__setitem__(Ellipsis, (mean + rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float16)))
 
-    t["emb.weight"] = mat(V, C, std=0.5)
+    def uni(name, shape, lo, hi):
+        put(name, shape, lambda d: d.__setitem__(Ellipsis, rng.uniform(lo, hi, size=shape).astype(np.float16)))
+
+    mat("emb.weight", V, C, std=0.5)
     for l in range(L):
         p = f"blocks.{l}."
         if l == 0:
-            t[p + "ln0.weight"] = vec(C, 1.0)
-            t[p + "ln0.bias"] = vec(C)
+            vec(p + "ln0.weight", C, 1.0)
+            vec(p + "ln0.bias", C)
         for ln in ("ln1", "ln2"):
-            t[p + ln + ".weight"] = vec(C, 1.0)
-            t[p + ln + ".bias"] = vec(C)
+            vec(p + ln + ".weight", C, 1.0)
+            vec(p + ln + ".bias", C)
         a = p + "att."
         if version == 5:
             for n in "kvrg":
-                t[a + f"time_mix_{n}"] = uni((1, 1, C), 0, 1)
-            t[a + "time_decay"] = uni((H, N), -6, -0.5)
-            t[a + "time_first"] = vec((H, N), 0.0, 0.3)
+                uni(a + f"time_mix_{n}", (1, 1, C), 0, 1)
+            uni(a + "time_decay", (H, N), -6, -0.5)
+            vec(a + "time_first", (H, N), 0.0, 0.3)
         elif version == 6:
             Dm, Dd = (64, 128) if C >= 4096 else (32, 64)
             for n in "xwkvrg":
-                t[a + f"time_mix_{n}"] = uni((1, 1, C), 0, 1)
-            t[a + "time_mix_w1"] = vec((5 * Dm, C))          # orig [C,5Dm] transposed
-            t[a + "time_mix_w2"] = vec((5, C, Dm))           # orig [5,Dm,C] transposed
-            t[a + "time_decay"] = uni((1, 1, C), -6, -0.5)
-            t[a + "time_decay_w1"] = vec((Dd, C))
-            t[a + "time_decay_w2"] = vec((C, Dd))
-            t[a + "time_first"] = vec((H, N), 0.0, 0.3)
+                uni(a + f"time_mix_{n}", (1, 1, C), 0, 1)
+            vec(a + "time_mix_w1", (5 * Dm, C))          # orig [C,5Dm] transposed
+            vec(a + "time_mix_w2", (5, C, Dm))           # orig [5,Dm,C] transposed
+            uni(a + "time_decay", (1, 1, C), -6, -0.5)
+            vec(a + "time_decay_w1", (Dd, C))
+            vec(a + "time_decay_w2", (C, Dd))
+            vec(a + "time_first", (H, N), 0.0, 0.3)
         else:
             Dw, Da, Dv, Dg = (96, 96, 64, 320) if C >= 2560 else (64, 64, 32, 128)
             if C < 1024:
                 Dw, Da, Dv, Dg = 32, 32, 32, 64
             for n in "rwkvag":
-                t[a + f"x_{n}"] = uni((1, 1, C), 0, 1)
-            t[a + "w0"] = uni((1, 1, C), -7, -1)
-            t[a + "w1"] = vec((Dw, C)); t[a + "w2"] = vec((C, Dw))
-            t[a + "a0"] = vec((1, 1, C), 0.0, 0.3)
-            t[a + "a1"] = vec((Da, C)); t[a + "a2"] = vec((C, Da))
-            t[a + "v0"] = vec((1, 1, C), 0.0, 0.3)
-            t[a + "v1"] = vec((Dv, C)); t[a + "v2"] = vec((C, Dv))
-            t[a + "g1"] = vec((Dg, C), 0.0, 0.05); t[a + "g2"] = vec((C, Dg), 0.0, 0.05)
-            t[a + "k_k"] = vec((1, 1, C), 0.85, 0.05)
-            t[a + "k_a"] = vec((1, 1, C), 1.0, 0.02)
-            t[a + "r_k"] = vec((H, N), 0.0, 0.1)
+                uni(a + f"x_{n}", (1, 1, C), 0, 1)
+            uni(a + "w0", (1, 1, C), -7, -1)
+            vec(a + "w1", (Dw, C)); vec(a + "w2", (C, Dw))
+            vec(a + "a0", (1, 1, C), 0.0, 0.3)
+            vec(a + "a1", (Da, C)); vec(a + "a2", (C, Da))
+            vec(a + "v0", (1, 1, C), 0.0, 0.3)
+            vec(a + "v1", (Dv, C)); vec(a + "v2", (C, Dv))
+            vec(a + "g1", (Dg, C), 0.0, 0.05); vec(a + "g2", (C, Dg), 0.0, 0.05)
+            vec(a + "k_k", (1, 1, C), 0.85, 0.05)
+            vec(a + "k_a", (1, 1, C), 1.0, 0.02)
+            vec(a + "r_k", (H, N), 0.0, 0.1)
         for n in ("receptance", "key", "value", "output") + (("gate",) if version != 7 else ()):
-            t[a + n + ".weight"] = mat(C, C)
-        t[a + "ln_x.weight"] = vec(C, 1.0)
-        t[a + "ln_x.bias"] = vec(C)
+            mat(a + n + ".weight", C, C)
+        vec(a + "ln_x.weight", C, 1.0)
+        vec(a + "ln_x.bias", C)
         f = p + "ffn."
         if version == 7:
-            t[f + "x_k"] = uni((1, 1, C), 0, 1)
+            uni(f + "x_k", (1, 1, C), 0, 1)
         else:
-            t[f + "time_mix_k"] = uni((1, 1, C), 0, 1)
-            t[f + "time_mix_r"] = uni((1, 1, C), 0, 1)
-            t[f + "receptance.weight"] = mat(C, C)
-        t[f + "key.weight"] = mat(F, C)
-        t[f + "value.weight"] = mat(C, F)
-    t["ln_out.weight"] = vec(C, 1.0)
-    t["ln_out.bias"] = vec(C)
-    t["head.weight"] = mat(V, C)
+            uni(f + "time_mix_k", (1, 1, C), 0, 1)
+            uni(f + "time_mix_r", (1, 1, C), 0, 1)
+            mat(f + "receptance.weight", C, C)
+        mat(f + "key.weight", F, C)
+        mat(f + "value.weight", C, F)
+    vec("ln_out.weight", C, 1.0)
+    vec("ln_out.bias", C)
+    mat("head.weight", V, C)
     return t
+
+
+def synth_st(name: str, seed: int = 20251024, fast: bool = True):
+    """Generate a synthetic checkpoint straight into one `.st` file image.
+    Returns (file: np.uint8 array, tensors: {name: fp16 view into file})."""
+    cfg = CONFIGS[name]
+    shapes = synth_checkpoint(*cfg, seed=seed, shapes_only=True)
+    header, off = {}, 0
+    for k, shp in shapes.items():
+        n = int(np.prod(shp)) * 2
+        header[k] = {"dtype": "F16", "shape": list(shp), "data_offsets": [off, off + n]}
+        off += n
+    hj = json.dumps(header, separators=(",", ":")).encode()
+    hj += b" " * ((8 - len(hj) % 8) % 8)
+    buf = big_empty((8 + len(hj) + off,), np.uint8)
+    buf[:8] = np.frombuffer(struct.pack("<Q", len(hj)), np.uint8)
+    buf[8:8 + len(hj)] = np.frombuffer(hj, np.uint8)
+    base = 8 + len(hj)
+
+    def alloc(k, shp):
+        a, b = header[k]["data_offsets"]
+        return buf[base + a:base + b].view(np.float16).reshape(shp)
+
+    tensors = synth_checkpoint(*cfg, seed=seed, fast=fast, alloc=alloc)
+    return buf, tensors
 
 
 def synth_named(name: str, seed: int = 20251024, fast: bool = False):
