@@ -1,0 +1,136 @@
+"""Mirror of the ai00-core code that *calls* the hot path (crates/ai00-core/src/run.rs), for tests and benches.
+
+    InferLoop.run_pending     the `infer` task        run.rs:1072-1162  (per-slot FIFO, one request per slot per
+                                                       step, loop until the RnnInput is consumed)
+    greedy_process            `process` decode loop   run.rs:788-1020   with the arg-max sampler (Nucleus top_k=1,
+                                                       sampler/nucleus.rs:77-89) and token 0 = stop (run.rs:855)
+    perplexity                `perplexity`            run.rs:699-755    (RnnOption::Full consumer)
+    ReplicaRouter             SURVEY 8(e)             request-level sharding over N independent engines (no collective)
+
+Works against anything that has `.max_batch`, `.infer(RnnInput)` and `.state` like `runtime.Runtime`.
+"""
+from __future__ import annotations
+
+import math
+from collections import deque
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .runtime import RnnInput, RnnInputBatch, RnnOption
+
+
+@dataclass
+class InferRequest:            # InferBatch::Run {batch, tokens, option, sender}  run.rs:1091-1098
+    batch: int
+    tokens: list
+    option: RnnOption = RnnOption.Last
+    outputs: list = field(default_factory=list)     # what `sender` would receive: one array per emitting infer call
+
+
+class InferLoop:
+    """The single consumer of InferBatch messages (run.rs:1072-1162)."""
+
+    def __init__(self, runtime):
+        self.rt = runtime
+        self.queues: dict[int, deque] = {}
+
+    def submit(self, req: InferRequest) -> InferRequest:          # schedule(): Run -> per-slot VecDeque
+        self.queues.setdefault(req.batch, deque()).append(req)
+        return req
+
+    def run_pending(self) -> int:
+        """`while batches.values().map(len).sum() > 0 { ... }` (run.rs:1120-1157). Returns #infer calls."""
+        calls = 0
+        while sum(len(q) for q in self.queues.values()) > 0:
+            inference = [RnnInputBatch() for _ in range(self.rt.max_batch)]
+            senders: dict[int, InferRequest] = {}
+            for b, q in self.queues.items():                      # pop <= 1 request per slot (run.rs:1124-1130)
+                if not q:
+                    continue
+                req = q.popleft()
+                inference[b] = RnnInputBatch(list(req.tokens), req.option)
+                senders[b] = req
+            inp = RnnInput(inference)
+            while inp.num_token() > 0:                            # run.rs:1134-1156
+                inp, out = self.rt.infer(inp)
+                calls += 1
+                for b, o in enumerate(out):
+                    if len(o) and b in senders:
+                        senders[b].outputs.append(o)
+        return calls
+
+
+def greedy_process(loop: InferLoop, batch: int, prompt, max_tokens: int) -> list[int]:
+    """Decode loop of one slot with the arg-max sampler; empty prompt => [0] (run.rs:489-492); token 0 stops."""
+    tokens = list(prompt) if len(prompt) else [0]
+    out = []
+    for _ in range(max_tokens):
+        req = loop.submit(InferRequest(batch, tokens, RnnOption.Last))
+        loop.run_pending()
+        logits = req.outputs[-1][-1]
+        tok = int(np.argmax(logits))
+        if tok == 0:                                              # run.rs:855
+            break
+        out.append(tok)
+        tokens = [tok]
+    return out
+
+
+def perplexity(loop: InferLoop, batch: int, tokens, head: float | None = None) -> float:
+    """run.rs:699-755: Full outputs, softmax without max-subtraction, ppl = -sum(ln p) / len(tokens')."""
+    p = []
+    toks = list(tokens) if head is not None else [0] + list(tokens)
+    n = len(tokens)
+    if head is not None:
+        p.append(head)
+    req = loop.submit(InferRequest(batch, toks, RnnOption.Full))
+    loop.run_pending()
+    index = 1
+    for chunk in req.outputs:                                     # one array per infer call, split(1) per token
+        for row in chunk:
+            if len(p) >= n:
+                break
+            if index < len(toks):
+                e = np.exp(row.astype(np.float32))
+                p.append(float(e[toks[index]] / e.sum(dtype=np.float32)))
+            index += 1
+    return float(-sum(math.log(x) for x in p) / len(toks))
+
+
+class ReplicaRouter:
+    """Request-level sharding over independent engines (one per GPU): round-robin for batch jobs, least-busy for
+    interactive requests.  No collective: each replica owns its weights, slots and stream."""
+
+    def __init__(self, runtimes: list):
+        self.loops = [InferLoop(r) for r in runtimes]
+        self.busy = [0] * len(runtimes)
+
+    def pick(self) -> int:
+        i = min(range(len(self.busy)), key=lambda j: self.busy[j])
+        self.busy[i] += 1
+        return i
+
+    def release(self, i: int):
+        self.busy[i] -= 1
+
+    @staticmethod
+    def shard(n_items: int, rank: int, world: int) -> range:
+        """Indices of a batch job owned by `rank` (documents round-robin)."""
+        return range(rank, n_items, world)
+
+    def embed_documents(self, docs: list, layer: int) -> list:
+        """`/embeddings`-style job: prefill each document, return one layer's WKV rows as its embedding."""
+        out = [None] * len(docs)
+        for r, loop in enumerate(self.loops):
+            mine = list(self.shard(len(docs), r, len(self.loops)))
+            B = loop.rt.max_batch
+            for g in range(0, len(mine), B):
+                group = mine[g:g + B]
+                for slot, d in enumerate(group):
+                    loop.rt.state.load(loop.rt.state.init(), slot)
+                    loop.submit(InferRequest(slot, list(docs[d]), RnnOption.Last))
+                loop.run_pending()
+                for slot, d in enumerate(group):
+                    out[d] = loop.rt.state.embed(layer, slot)
+        return out

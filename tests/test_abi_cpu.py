@@ -1,0 +1,90 @@
+"""CPU: the C-ABI library loads, exports every symbol include/rwkv_abi.h declares, and its host-only entry points
+(model info, tokenizer, error reporting) behave.  No compute call is made without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ai00_server_amd import runtime as rt
+from oracle import rwkv_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VOCAB = os.path.join(ROOT, "tests", "golden", "vocab_sample.json")
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, "include", "rwkv_abi.h")).read()
+    declared = set(re.findall(r"\b(rwkv_[a-z0-9_]+)\s*\(", header))
+    l = C.CDLL(built_lib)
+    for name in sorted(declared):
+        assert hasattr(l, name), f"{name} declared in rwkv_abi.h but not exported"
+    assert declared == set(rt.ABI_SYMBOLS), declared ^ set(rt.ABI_SYMBOLS)
+    assert rt.lib().rwkv_abi_version() == 1
+
+
+def test_model_info_and_format_errors(built_lib):
+    for name, ver in [("v5-tiny", 5), ("v6-tiny", 6), ("v7-tiny", 7)]:
+        t = R.synth_named(name)
+        i = rt.Loader.info(R.st_serialize(t))
+        o = R.model_info(t)
+        assert (int(i.version), i.num_layer, i.num_emb, i.num_hidden, i.num_vocab, i.num_head) == \
+               (ver, o.num_layer, o.num_emb, o.num_hidden, o.num_vocab, o.num_head)
+    with pytest.raises(rt.RwkvError) as e:
+        rt.Loader.info(b"\x10\x00\x00\x00\x00\x00\x00\x00{not json")
+    assert e.value.code == -2                                    # RWKV_ERR_FORMAT
+    with pytest.raises(rt.RwkvError) as e:                       # v4-style checkpoint: no ln_x / time_mix_x
+        rt.Loader.info(R.st_serialize({"emb.weight": np.zeros((16, 64), np.float16),
+                                       "blocks.0.ln1.weight": np.zeros(64, np.float16)}))
+    assert e.value.code == -3                                    # RWKV_ERR_UNSUPPORTED
+    t = R.synth_named("v6-tiny")
+    trunc = R.st_serialize(t)[:-100]
+    with pytest.raises(rt.RwkvError):
+        rt.Loader.info(trunc)
+
+
+def test_engine_create_fails_loudly_without_gpu(built_lib):
+    if rt.lib().rwkv_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(rt.RwkvError) as e:
+        rt.ModelBuilder(R.st_serialize(R.synth_named("v6-tiny"))).build()
+    assert e.value.code == -4 and "no CPU fallback" in str(e.value)
+
+
+def _py_encode(vocab: dict, text: bytes):
+    """Reference greedy longest-match (the published RWKV World tokenizer algorithm)."""
+    toks = {v: k for k, v in vocab.items()}
+    maxlen = max(len(b) for b in toks)
+    out, i = [], 0
+    while i < len(text):
+        for n in range(min(maxlen, len(text) - i), 0, -1):
+            if text[i:i + n] in toks:
+                out.append(toks[text[i:i + n]])
+                i += n
+                break
+        else:
+            raise ValueError("no match")
+    return out
+
+
+def test_tokenizer_matches_reference_algorithm(built_lib):
+    import json
+    raw = open(VOCAB, encoding="utf-8").read()
+    tk = rt.Tokenizer(raw)
+    vocab = {}
+    for k, v in json.loads(raw).items():
+        vocab[int(k)] = v.encode("utf-8") if isinstance(v, str) else bytes(v)
+    table = tk.token_index_to_bytes()
+    for i, b in vocab.items():
+        assert table[i] == b
+    samples = ["Hello world!\n\nUser: hi", "The quick brown fox; 12345 + 67 = ?", "你好，世界 — naïve café", "\t\n  x  ",
+               "def f(x):\n    return x**2\n"]
+    for s in samples:
+        data = s.encode("utf-8")
+        ids = tk.encode(data)
+        assert ids == _py_encode(vocab, data)
+        assert tk.decode(ids) == data
+    assert tk.encode(b"") == []
+    with pytest.raises(rt.RwkvError):
+        tk.decode([10 ** 7])

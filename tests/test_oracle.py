@@ -1,0 +1,145 @@
+"""CPU: the oracle against its golden fixtures, against an independent literal transcription of the published
+BlinkDL functions, and its own invariants (chunking, state round trip, quantisation bounds)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import rwkv_ref as R
+from tests.blinkdl_literal import Literal
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def _prompt(ref, slot, n):
+    return [t % ref.info.num_vocab for t in R.synth_prompt(slot, n)]
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_oracle_matches_golden(path):
+    g = np.load(path)
+    ref = R.RwkvRef(R.synth_named(str(g["name"])), int(g["quant_layers"]), int(g["quant_type"]))
+    st = ref.init_state()
+    logits = ref.forward(list(g["prompt"]), st)[-1]
+    np.testing.assert_allclose(logits, g["logits"], rtol=0, atol=2e-5)
+    toks, st = ref.greedy(list(g["prompt"]), 16)
+    assert toks == list(g["greedy"])
+    assert abs(st.astype(np.float64).sum() - float(g["state_sum"])) <= 1e-3 * max(1.0, float(g["state_abs"])) * 1e-2
+
+
+@pytest.mark.parametrize("name", ["v5-tiny", "v6-tiny", "v7-tiny"])
+def test_oracle_matches_literal_blinkdl(name):
+    t = R.synth_named(name)
+    ref, lit = R.RwkvRef(t), Literal(t)
+    st, ls = ref.init_state(), lit.new_state()
+    for tok in _prompt(ref, 1, 12):
+        a = ref.forward([tok], st)[-1]
+        b = lit.forward(tok, ls)
+        np.testing.assert_allclose(a, b, rtol=0, atol=5e-5)
+    # state conventions: slab[l][1+i][h*N+j] = S_h[i][j] in BlinkDL's own [H,N,N] indexing
+    N, H = ref.info.head_size, ref.info.num_head
+    for l in range(ref.info.num_layer):
+        S = st[l, 1:1 + N].reshape(N, H, N).transpose(1, 0, 2)
+        np.testing.assert_allclose(S, ls[l][1].numpy(), rtol=0, atol=5e-5)
+        np.testing.assert_allclose(st[l, 0], ls[l][0].numpy(), atol=5e-5)
+        np.testing.assert_allclose(st[l, N + 1], ls[l][2].numpy(), atol=5e-5)
+
+
+@pytest.mark.parametrize("name", ["v5-tiny", "v6-tiny", "v7-tiny"])
+def test_chunking_is_exact_and_state_roundtrips(name):
+    ref = R.RwkvRef(R.synth_named(name))
+    p = _prompt(ref, 0, 30)
+    s1 = ref.init_state()
+    full = ref.forward(p, s1, full=True)
+    s2 = ref.init_state()
+    a = ref.forward(p[:7], s2, full=True)
+    saved = s2.copy()                                  # "back" ...
+    s3 = saved.copy()                                  # ... "load" into another slot
+    b = ref.forward(p[7:], s3, full=True)
+    np.testing.assert_array_equal(np.concatenate([a, b]), full)
+    np.testing.assert_array_equal(s1, s3)
+    assert full.shape == (30, ref.info.num_vocab) and np.isfinite(full).all()
+
+
+def test_long_run_stays_finite():
+    ref = R.RwkvRef(R.synth_named("v6-tiny"))
+    toks, st = ref.greedy(_prompt(ref, 5, 4), 300)
+    assert np.isfinite(st).all() and np.abs(st).max() < 1e4 and len(toks) == 300
+
+
+def test_quant_reference_bounds_and_layout():
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal((32, 512)) * 0.05).astype(np.float16)
+    q, a, b = R.quant_int8(w)
+    d = R.dequant_int8(q, a, b).astype(np.float32)
+    step = a.astype(np.float32).repeat(128, axis=1)
+    assert np.all(np.abs(d - w.astype(np.float32)) <= 0.51 * step + 2e-3 * np.abs(w.astype(np.float32)) + 1e-6)
+    idx, am = R.quant_nf4(w)
+    d4 = R.dequant_nf4(idx, am).astype(np.float32)
+    assert idx.max() <= 15 and np.all(np.abs(d4) <= am.astype(np.float32).repeat(64, axis=1) * 1.001)
+    # the block absmax element decodes exactly to +-absmax
+    blk = w.reshape(32, 8, 64).astype(np.float32)
+    pos = np.abs(blk).argmax(axis=2)
+    dd = d4.reshape(32, 8, 64)
+    np.testing.assert_array_equal(np.abs(np.take_along_axis(dd, pos[..., None], 2))[..., 0], am.astype(np.float32))
+    # only the big projection matrices of layers < quant are quantised (lib.rs:465)
+    t = R.synth_named("v6-small")
+    r0, r1 = R.RwkvRef(t), R.RwkvRef(t, 1, R.QUANT_INT8)
+    assert not np.array_equal(r0.w["blocks.0.att.key.weight"], r1.w["blocks.0.att.key.weight"])
+    np.testing.assert_array_equal(r0.w["blocks.1.att.key.weight"], r1.w["blocks.1.att.key.weight"])
+    np.testing.assert_array_equal(r0.w["head.weight"], r1.w["head.weight"])
+    np.testing.assert_array_equal(r0.w["blocks.0.att.time_mix_w1"], r1.w["blocks.0.att.time_mix_w1"])
+
+
+def test_mix_convention_trap_v5_vs_v6():
+    """Both versions store `time_mix_k`, with opposite meaning: mu_v6 == 1 - mu_v5."""
+    t5 = R.synth_named("v5-tiny")
+    ref = R.RwkvRef(t5)
+    xx, sx = np.ones(128, np.float32), np.zeros(128, np.float32)
+    mu = ref.w["blocks.0.ffn.time_mix_k"].reshape(-1)
+    v5 = xx * mu + sx * (1 - mu)
+    v6 = xx + (sx - xx) * mu
+    np.testing.assert_allclose(v5, 1 - v6, atol=1e-6)
+
+
+def test_safetensors_roundtrip_and_info():
+    t = R.synth_named("v7-tiny")
+    data = R.st_serialize(t, metadata={"format": "pt"})
+    back = R.st_deserialize(data)
+    assert set(back) == set(t) and all(np.array_equal(back[k], t[k]) for k in t)
+    i = R.model_info(back)
+    assert (i.version, i.num_layer, i.num_emb, i.num_hidden, i.num_vocab, i.num_head) == (7, 2, 128, 512, 512, 2)
+    buf, views = R.synth_st("v6-tiny", fast=False)
+    assert all(np.array_equal(views[k], R.synth_named("v6-tiny")[k]) for k in views)
+
+
+def test_init_state_perplexity_softmax_helpers():
+    ref = R.RwkvRef(R.synth_named("v6-tiny"))
+    st = R.synth_init_state(ref.info)
+    slab = ref.read_init_state(st)
+    N, H = ref.info.head_size, ref.info.num_head
+    ts = np.asarray(st["blocks.1.att.time_state"], np.float32).transpose(0, 2, 1)     # [H, i, j]
+    assert slab[1, 1 + 5, 1 * N + 9] == ts[1, 5, 9] and not slab[:, 0].any() and not slab[:, N + 1].any()
+    p = _prompt(ref, 2, 6)
+    s = ref.init_state()
+    rows = ref.forward([0] + p, s, full=True)
+    ppl = R.perplexity_ref(rows, p)
+    sm = R.softmax_ref(rows)
+    want = -np.mean([np.log(sm[i, p[i]]) for i in range(len(p))] ) * len(p) / (len(p) + 1)
+    assert abs(ppl - want) < 1e-4
+    np.testing.assert_allclose(sm.sum(axis=1), 1.0, atol=1e-5)
+
+
+def test_algorithmic_bytes_match_survey_table():
+    for name, wq_fp16 in [("v6-3b", 5.865e9), ("v6-1.6b", 2.932e9), ("v5-0.4b", 0.790e9), ("v6-7b", 14.736e9)]:
+        cfg = R.CONFIGS[name]
+        shapes = R.synth_checkpoint(*cfg, shapes_only=True)
+        info = R.ModelInfo(cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[2] // 64)
+        ab = R.algorithmic_bytes(info, shapes, 0, R.QUANT_NONE, 1)
+        assert abs(ab["W_q"] - wq_fp16) / wq_fp16 < 0.01, (name, ab["W_q"])
+    cfg = R.CONFIGS["v6-3b"]
+    shapes = R.synth_checkpoint(*cfg, shapes_only=True)
+    info = R.ModelInfo(6, 32, 2560, 8960, 65536, 40)
+    ab = R.algorithmic_bytes(info, shapes, 32, R.QUANT_INT8, 32)
+    assert abs(ab["W_q"] - 3.224e9) / 3.224e9 < 0.01 and ab["S"] == 21626880
