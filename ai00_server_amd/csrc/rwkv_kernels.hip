@@ -199,17 +199,19 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
     Nf4Lut lut;
     if constexpr (FMT == W_NF4) lut = make_nf4_lut();
 
-    // one 256-k round of MFMAs: acc += W(round) * X(sub)
-    auto mma_round = [&](const WRound<FMT> &w, f32x4 (&acc)[NT], const f16x8 (&xb)[NT][KSW], const f16x8 (*xl)[HILO ? KSW : 1],
-                         int sub, int k0) {
+    // one 256-k round of MFMAs: acc += W(round) * X(sub).  Two accumulators per n-tile (even / odd k-steps) halve the
+    // MFMA read-after-write stalls of the otherwise serial chain.
+    auto mma_round = [&](const WRound<FMT> &w, f32x4 (&acc)[NT], f32x4 (&acc2)[NT], const f16x8 (&xb)[NT][KSW],
+                         const f16x8 (*xl)[HILO ? KSW : 1], int sub, int k0) {
 #pragma unroll
         for (int ks = 0; ks < RS; ++ks) {
             if (!TAIL || k0 + (sub * RS + ks) * 32 < kend) {
                 const f16x8 a = frag<FMT>(w, ks, lut);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[nt][sub * RS + ks], acc[nt], 0, 0, 0);
-                    if constexpr (HILO) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xl[nt][sub * RS + ks], acc[nt], 0, 0, 0);
+                    f32x4 &d = (ks & 1) ? acc2[nt] : acc[nt];
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[nt][sub * RS + ks], d, 0, 0, 0);
+                    if constexpr (HILO) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xl[nt][sub * RS + ks], d, 0, 0, 0);
                 }
             }
         }
@@ -252,12 +254,13 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
             // weights after X: the X fragments are L2 hits and complete first, so (in-order vmcnt) the MFMAs of round r
             // only wait for rounds <= r while later rounds are still streaming in from HBM
             load_round<FMT, TAIL>(cur, P, strip0, k0, kend, true, lane);
-            f32x4 acc[NT];
+            f32x4 acc[NT], acc2[NT];
             auto park = [&](int s) {                               // partial sums of strip s -> LDS slot of this wave
                 f32x4 *slot = red + ((s * nw + wave) * NT) * 64 + lane;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    if (sl == wave) slot[nt * 64] = acc[nt]; else slot[nt * 64] += acc[nt];
+                    const f32x4 v = acc[nt] + acc2[nt];
+                    if (sl == wave) slot[nt * 64] = v; else slot[nt * 64] += v;
                 }
             };
             if constexpr (SHOT) {
@@ -277,9 +280,9 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                     if (s < nstrip) {
                         if (sub == 0) {
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            for (int nt = 0; nt < NT; ++nt) acc[nt] = acc2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                         }
-                        if (sub < nsub) mma_round(w[r], acc, xb, xl, sub, k0);
+                        if (sub < nsub) mma_round(w[r], acc, acc2, xb, xl, sub, k0);
                         if (sub == SUB - 1) park(s);
                     }
                 }
@@ -293,9 +296,9 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                                 load_round<FMT, TAIL>(nxt, P, strip0 + (more_sub ? s : s + 1), k0 + (more_sub ? sub + 1 : 0) * RK, kend, true, lane);
                             if (sub == 0) {
 #pragma unroll
-                                for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                                for (int nt = 0; nt < NT; ++nt) acc[nt] = acc2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                             }
-                            mma_round(cur, acc, xb, xl, sub, k0);
+                            mma_round(cur, acc, acc2, xb, xl, sub, k0);
                             cur = nxt;
                         }
                     }
