@@ -177,7 +177,8 @@ struct rwkv_engine {
     // row meta (device + pinned host)
     int *d_meta = nullptr, *h_meta = nullptr;
     size_t meta_cap = 0;
-    int *d_tok_feedback = nullptr, *d_hist = nullptr, *d_counter = nullptr;
+    int *d_tok_feedback = nullptr, *d_hist = nullptr, *d_counter = nullptr, *d_amax_i = nullptr;
+    float *d_amax_v = nullptr;
     size_t hist_cap = 0;
 
     // profiling
@@ -210,6 +211,7 @@ struct rwkv_engine {
         if (s_main) (void)hipStreamSynchronize(s_main);
         if (s_soft) (void)hipStreamSynchronize(s_soft);
         for (auto &g : graphs) if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+        for (auto ev : prof_ev) (void)hipEventDestroy(ev);
         for (void *p : allocs) (void)hipFree(p);
         if (slab_host) (void)hipHostFree(slab_host);
         if (logits_host) (void)hipHostFree(logits_host);
@@ -221,21 +223,39 @@ struct rwkv_engine {
         if (s_soft) (void)hipStreamDestroy(s_soft);
     }
 
-    // ---- launch wrapper: optional per-family hipEvent timing on the compute stream ----
+    // ---- launch wrapper: optional per-family hipEvent timing on the compute stream.  Event pairs are recorded
+    // around every launch WITHOUT host synchronisation (the stream stays busy like in the captured step); the
+    // elapsed times are read back once the step has drained (prof_collect).
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_fam;
     template <class F>
     void launch(int fam, F &&f) {
         if (profiling) {
-            HIP_CHECK(hipEventRecord(ev0, s_main));
+            const size_t i = prof_fam.size();
+            if (prof_ev.size() < 2 * (i + 1)) {
+                hipEvent_t a, b;
+                HIP_CHECK(hipEventCreate(&a));
+                HIP_CHECK(hipEventCreate(&b));
+                prof_ev.push_back(a);
+                prof_ev.push_back(b);
+            }
+            HIP_CHECK(hipEventRecord(prof_ev[2 * i], s_main));
             f();
-            HIP_CHECK(hipEventRecord(ev1, s_main));
-            HIP_CHECK(hipEventSynchronize(ev1));
-            float ms = 0;
-            HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
-            prof_ms[fam] += ms;
-            prof_n[fam] += 1;
+            HIP_CHECK(hipEventRecord(prof_ev[2 * i + 1], s_main));
+            prof_fam.push_back(fam);
         } else {
             f();
         }
+    }
+    void prof_collect() {
+        HIP_CHECK(hipStreamSynchronize(s_main));
+        for (size_t i = 0; i < prof_fam.size(); ++i) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, prof_ev[2 * i], prof_ev[2 * i + 1]));
+            prof_ms[prof_fam[i]] += ms;
+            prof_n[prof_fam[i]] += 1;
+        }
+        prof_fam.clear();
     }
 
     void load(const rwkv_load_desc &d);
@@ -482,6 +502,8 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
     HIP_CHECK(hipHostMalloc((void **)&h_meta, meta_cap * 4, hipHostMallocDefault));
     d_tok_feedback = dalloc<int>(chunk);
     d_counter = dalloc<int>(4);
+    d_amax_v = dalloc<float>((size_t)chunk * 32);
+    d_amax_i = dalloc<int>((size_t)chunk * 32);
     HIP_CHECK(hipDeviceSynchronize());
 }
 
@@ -541,6 +563,7 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
         const long cap = 256L * std::max(1, 8 / nw);           // measured: 5-wave blocks are resident one per CU
         int spb = (int)((total_strips * ksb + cap - 1) / cap);
         if ((total_strips * ksb + spb - 1) / spb > 1024) spb = 8;            // huge matrices (head): long pipelined blocks
+        else if (spb * sub > maxr && strips * ksb <= 64) spb = std::max(1, maxr / sub);   // tiny member of a group
         spb = std::max(1, std::min(spb, 8));
         if (force_spb) spb = force_spb; else if (f_spb) spb = f_spb;
         spb = std::min(spb, std::max(1, 150 / (nw * NT)));                     // LDS: spb*nw*NT KiB <= 150 KiB
@@ -913,8 +936,10 @@ rwkv_status rwkv_profile_infer(rwkv_engine *e, const rwkv_slot_input *in, rwkv_s
         std::fill(e->prof_ms, e->prof_ms + RWKV_PROFILE_FAMILIES, 0.f);
         std::fill(e->prof_n, e->prof_n + RWKV_PROFILE_FAMILIES, 0);
         e->profiling = true;
+        e->prof_fam.clear();
         try {
             e->infer(in, out);
+            e->prof_collect();
         } catch (...) {
             e->profiling = false;
             throw;
@@ -1103,7 +1128,7 @@ rwkv_status rwkv_decode_greedy(rwkv_engine *e, int32_t n_slots, const uint32_t *
         HIP_CHECK(hipStreamBeginCapture(e->s_main, hipStreamCaptureModeThreadLocal));
         try {
             e->run_layers(pl.T, pl.n_seq, pl.n_out, e->d_tok_feedback);
-            launch_argmax(e->logits, n_slots, e->info.num_vocab, e->d_tok_feedback, e->s_main);
+            launch_argmax(e->logits, n_slots, e->info.num_vocab, e->d_tok_feedback, e->d_amax_v, e->d_amax_i, e->s_main);
         } catch (...) {
             (void)hipStreamEndCapture(e->s_main, &g);
             if (g) (void)hipGraphDestroy(g);

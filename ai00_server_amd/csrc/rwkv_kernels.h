@@ -159,7 +159,8 @@ struct StatePackArgs {
 void launch_state_pack(const StatePackArgs &a, hipStream_t s);
 
 void launch_softmax(const float *in, float *out, int n_rows, int V, hipStream_t s);
-void launch_argmax(const float *logits, int n_rows, int V, int *out_tok, hipStream_t s);
+// two-stage arg-max; scratch_v / scratch_i hold n_rows*32 partial (value, index) pairs
+void launch_argmax(const float *logits, int n_rows, int V, int *out_tok, float *scratch_v, int *scratch_i, hipStream_t s);
 
 // ---- load-time: raw fp16 [rows][K] -> tiled / quantised --------------------------------
 void launch_tile_f16(const _Float16 *raw, int rows_valid, int rows, int K, void *out, hipStream_t s);

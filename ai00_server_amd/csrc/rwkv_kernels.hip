@@ -403,9 +403,16 @@ __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_fl
 template <int PT>
 __device__ __forceinline__ void row_load_sum(const float *__restrict__ x_in, const float *__restrict__ P, int np, long pstride,
                                              int row, int C, float4 (&v)[PT]) {
+    constexpr int MAXNP = 8;                                       // all loads in flight at once, summed in fixed order
+    float4 pp[MAXNP][PT];
     ROW_FOR(i, c) v[i] = ld4(x_in + (long)row * C + c);
-    for (int j = 0; j < np; ++j) {
-        ROW_FOR(i, c) v[i] = v[i] + ld4(P + j * pstride + (long)row * C + c);
+#pragma unroll
+    for (int j = 0; j < MAXNP; ++j) {
+        if (j < np) { ROW_FOR(i, c) pp[j][i] = ld4(P + j * pstride + (long)row * C + c); }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXNP; ++j) {
+        if (j < np) { ROW_FOR(i, c) v[i] = v[i] + pp[j][i]; }
     }
 }
 // two-pass LayerNorm (mean, then centred variance), eps 1e-5 — same order as the oracle's _ln
@@ -590,10 +597,14 @@ __global__ __launch_bounds__(256) void wkv_kernel(const WkvArgs a) {
             __syncthreads();
             // decay LoRA stage 2: d_c = time_decay_c + sum_d D2[c][d] td[d];  w = exp(-exp(d)).  4 threads / channel
             const int ch = tid >> 2, part = tid & 3;
-            const int per = a.Dd >> 2;
+            const int per = a.Dd >> 2;                             // 16 (Dd=64) or 32 (Dd=128): multiples of 8 halfs
             const _Float16 *d2 = a.D2 + (long)(cb + ch) * a.Dd + part * per;
             float s = 0.f;
-            for (int d = 0; d < per; ++d) s += (float)d2[d] * sh_td[part * per + d];
+            for (int d = 0; d < per; d += 8) {
+                const f16x8 wv = *(const f16x8 *)(d2 + d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += (float)wv[e] * sh_td[part * per + d + e];
+            }
             s += __shfl_xor(s, 1, 64);
             s += __shfl_xor(s, 2, 64);
             if (part == 0) sh_w[ch] = expf(-expf(a.wdec_or_decay[cb + ch] + s));
@@ -715,16 +726,8 @@ void launch_softmax(const float *in, float *out, int n_rows, int V, hipStream_t 
     hipLaunchKernelGGL(softmax_kernel, dim3(n_rows), dim3(256), 0, s, in, out, V);
 }
 
-__global__ __launch_bounds__(256) void argmax_kernel(const float *logits, int V, int *out_tok) {
-    __shared__ float bv[4];
-    __shared__ int bi[4];
-    const float *x = logits + (long)blockIdx.x * V;
-    float best = -INFINITY;
-    int idx = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += 256) {
-        const float v = x[i];
-        if (v > best) { best = v; idx = i; }               // strided ascending: first max kept per thread
-    }
+constexpr int ARGMAX_SEG = 32;                                  // segments per row in stage 1
+__device__ __forceinline__ void argmax_block(float &best, int &idx, float *bv, int *bi) {
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) {
         const float ov = __shfl_xor(best, k, 64);
@@ -736,11 +739,39 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float *logits, int V,
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w)
             if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-        out_tok[blockIdx.x] = idx;                          // lowest index on ties == np.argmax
     }
 }
-void launch_argmax(const float *logits, int n_rows, int V, int *out_tok, hipStream_t s) {
-    hipLaunchKernelGGL(argmax_kernel, dim3(n_rows), dim3(256), 0, s, logits, V, out_tok);
+__global__ __launch_bounds__(256) void argmax_stage1(const float *logits, int V, float *pv, int *pi) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int row = blockIdx.x, seg = blockIdx.y;
+    const int per = (V + ARGMAX_SEG - 1) / ARGMAX_SEG;
+    const int lo = seg * per, hi = min(V, lo + per);
+    const float *x = logits + (long)row * V;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        const float v = x[i];
+        if (v > best) { best = v; idx = i; }               // ascending per thread: first max kept
+    }
+    argmax_block(best, idx, bv, bi);
+    if (threadIdx.x == 0) { pv[row * ARGMAX_SEG + seg] = best; pi[row * ARGMAX_SEG + seg] = idx; }
+}
+__global__ __launch_bounds__(64) void argmax_stage2(const float *pv, const int *pi, int *out_tok) {
+    const int row = blockIdx.x;
+    float best = threadIdx.x < ARGMAX_SEG ? pv[row * ARGMAX_SEG + threadIdx.x] : -INFINITY;
+    int idx = threadIdx.x < ARGMAX_SEG ? pi[row * ARGMAX_SEG + threadIdx.x] : 0x7fffffff;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) {
+        const float ov = __shfl_xor(best, k, 64);
+        const int oi = __shfl_xor(idx, k, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if (threadIdx.x == 0) out_tok[row] = idx;                // lowest index on ties == np.argmax
+}
+void launch_argmax(const float *logits, int n_rows, int V, int *out_tok, float *scratch_v, int *scratch_i, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_stage1, dim3(n_rows, ARGMAX_SEG), dim3(256), 0, s, logits, V, scratch_v, scratch_i);
+    hipLaunchKernelGGL(argmax_stage2, dim3(n_rows), dim3(64), 0, s, (const float *)scratch_v, (const int *)scratch_i, out_tok);
 }
 
 // =====================================================================================
