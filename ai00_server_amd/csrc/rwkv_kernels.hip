@@ -557,9 +557,9 @@ __device__ __forceinline__ float sum16(float v) {       // reduce across the 16 
     return v;
 }
 
-__global__ __launch_bounds__(256) void wkv_kernel(const WkvArgs a) {
+__global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {   // <= 102 VGPRs: 5 blocks per CU = 1280 (B=32 x 40 heads) in one generation
     __shared__ __attribute__((aligned(16))) float sh_r[64], sh_k[64], sh_v[64], sh_w[64], sh_u[64], sh_kk[64], sh_ka[64];
-    __shared__ float sh_out[64], sh_td[128], sh_red[4], sh_stat[2];
+    __shared__ float sh_out[64];
     const int seq = blockIdx.x, h = blockIdx.y;
     const int tid = threadIdx.x, ig = tid >> 4, jg = tid & 15;
     const int slot = a.seq_slot[seq], row0 = a.seq_begin[seq], nrow = a.seq_len[seq];
@@ -572,43 +572,58 @@ __global__ __launch_bounds__(256) void wkv_kernel(const WkvArgs a) {
     if (a.version != 7 && tid < 64) sh_u[tid] = a.u[cb + tid];
     if (a.version == 5 && tid < 64) sh_w[tid] = a.wdec_or_decay[cb + tid];
 
+    // loop-invariant per-channel parameters of wave 0 (tid < 64)
+    float lnw = 0.f, lnb = 0.f, kk_p = 0.f, ka_p = 0.f, rk_p = 0.f;
+    if (tid < 64) {
+        lnw = a.lnx_w[cb + tid]; lnb = a.lnx_b[cb + tid];
+        if (a.version == 7) { kk_p = a.k_k[cb + tid]; ka_p = a.k_a[cb + tid]; rk_p = a.r_k[cb + tid]; }
+    }
+    const int ch = tid >> 2, part = tid & 3;                 // v6 decay LoRA: 4 threads per channel
+    const int per = a.Dd >> 2;
+    const float decay0 = a.version == 6 ? a.wdec_or_decay[cb + ch] : 0.f;
+
     for (int it = 0; it < nrow; ++it) {
         const int t = row0 + it;
         const long rb = (long)t * C + cb;
-        __syncthreads();                                   // previous iteration's readers done
+        // ---- issue every global load of this token before the first barrier
+        float r = 0.f, k = 0.f, v = 0.f, gt = 0.f, av = 0.f, vg = 0.f, w7 = 0.f, vf = 0.f;
         if (tid < 64) {
-            float r = a.r[rb + tid], k = a.k[rb + tid], v = a.v[rb + tid];
+            r = a.r[rb + tid]; k = a.k[rb + tid]; v = a.v[rb + tid]; gt = a.g[rb + tid];
             if (a.version == 7) {
-                const float av = a.a7[rb + tid];
-                float kk = k * a.k_k[cb + tid];
+                av = a.a7[rb + tid]; w7 = a.w7[rb + tid];
+                if (a.layer != 0) { vg = a.vg7[rb + tid]; vf = a.v_first[rb + tid]; }
+            }
+        }
+        float dsum = 0.f;
+        if (a.version == 6) {
+            // decay LoRA stage 2: d_c = time_decay_c + sum_d D2[c][d] td[d];  w = exp(-exp(d))
+            const _Float16 *d2 = a.D2 + (long)(cb + ch) * a.Dd + part * per;
+            const float *tdp = a.td + (long)t * a.Dd + part * per;
+            for (int d = 0; d < per; d += 8) {
+                const f16x8 wv = *(const f16x8 *)(d2 + d);
+                const float4 t0v = *(const float4 *)(tdp + d), t1v = *(const float4 *)(tdp + d + 4);
+                dsum += (float)wv[0] * t0v.x + (float)wv[1] * t0v.y + (float)wv[2] * t0v.z + (float)wv[3] * t0v.w +
+                        (float)wv[4] * t1v.x + (float)wv[5] * t1v.y + (float)wv[6] * t1v.z + (float)wv[7] * t1v.w;
+            }
+            dsum += __shfl_xor(dsum, 1, 64);
+            dsum += __shfl_xor(dsum, 2, 64);
+        }
+        __syncthreads();                                   // previous iteration's LDS readers done
+        if (tid < 64) {
+            if (a.version == 7) {
+                float kk = k * kk_p;
                 const float ss = wave_sum(kk * kk);        // tid<64 == wave 0: L2 norm over the head
                 kk = kk / fmaxf(sqrtf(ss), 1e-12f);
-                k = k * (1.0f + (av - 1.0f) * a.k_a[cb + tid]);
+                k = k * (1.0f + (av - 1.0f) * ka_p);
                 if (a.layer == 0) a.v_first[rb + tid] = v;
-                else v = v + (a.v_first[rb + tid] - v) * a.vg7[rb + tid];
+                else v = v + (vf - v) * vg;
                 sh_kk[tid] = -kk;                          // -kappa
                 sh_ka[tid] = kk * av;                      // kappa * a
-                sh_w[tid] = a.w7[rb + tid];
+                sh_w[tid] = w7;
             }
             sh_r[tid] = r; sh_k[tid] = k; sh_v[tid] = v;
         }
-        if (a.version == 6) {
-            if (tid < a.Dd) sh_td[tid] = a.td[(long)t * a.Dd + tid];
-            __syncthreads();
-            // decay LoRA stage 2: d_c = time_decay_c + sum_d D2[c][d] td[d];  w = exp(-exp(d)).  4 threads / channel
-            const int ch = tid >> 2, part = tid & 3;
-            const int per = a.Dd >> 2;                             // 16 (Dd=64) or 32 (Dd=128): multiples of 8 halfs
-            const _Float16 *d2 = a.D2 + (long)(cb + ch) * a.Dd + part * per;
-            float s = 0.f;
-            for (int d = 0; d < per; d += 8) {
-                const f16x8 wv = *(const f16x8 *)(d2 + d);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s += (float)wv[e] * sh_td[part * per + d + e];
-            }
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            if (part == 0) sh_w[ch] = expf(-expf(a.wdec_or_decay[cb + ch] + s));
-        }
+        if (a.version == 6 && part == 0) sh_w[ch] = expf(-expf(decay0 + dsum));
         __syncthreads();
         const float4 rq = *(const float4 *)(sh_r + jg * 4);
         const float4 kq = *(const float4 *)(sh_k + jg * 4);
@@ -655,12 +670,12 @@ __global__ __launch_bounds__(256) void wkv_kernel(const WkvArgs a) {
             const float mean = wave_sum(o) * (1.0f / 64.0f);
             const float d = o - mean;
             const float var = wave_sum(d * d) * (1.0f / 64.0f);
-            float y = d / sqrtf(var + 64e-5f) * a.lnx_w[cb + tid] + a.lnx_b[cb + tid];
+            float y = d / sqrtf(var + 64e-5f) * lnw + lnb;
             if (a.version == 7) {
-                const float bonus = wave_sum(sh_r[tid] * sh_k[tid] * a.r_k[cb + tid]);
+                const float bonus = wave_sum(sh_r[tid] * sh_k[tid] * rk_p);
                 y += bonus * sh_v[tid];
             }
-            y *= a.g[rb + tid];
+            y *= gt;
             _Float16 hh, ll;
             split_hilo(y, hh, ll);
             a.yhi[(long)t * a.ldh + cb + tid] = hh;

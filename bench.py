@@ -40,6 +40,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BENCH_SHARE_GPU"):       # test hook: all ranks on device 0 (validates the N>1 code path on a 1-GPU box)
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
@@ -47,7 +49,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo" if os.environ.get("BENCH_SHARE_GPU") else "nccl")
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
@@ -89,7 +91,7 @@ def main():
         dt = time.perf_counter() - t
         barrier()
         if dist is not None:
-            x = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            x = torch.tensor([dt], dtype=torch.float64, device="cpu" if os.environ.get("BENCH_SHARE_GPU") else "cuda")
             dist.all_reduce(x, op=dist.ReduceOp.MAX)
             dt = float(x.item())
         return dt, dev_ms, toks
