@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librwkv_hip.so")
 SOURCES = ["rwkv_kernels.hip", "rwkv_engine.cpp", "tokenizer.cpp"]
-DEPS = SOURCES + ["rwkv_kernels.h", "safetensors.hpp", os.path.join("..", "..", "include", "rwkv_abi.h")]
+DEPS = SOURCES + ["rwkv_kernels.h", "safetensors.hpp", os.path.join("..", "..", "include", "rwkv_abi.h"),
+               os.path.join("..", "..", "include", "rwkv_runtime.hpp"), os.path.join("..", "..", "harness", "decode_loop.cpp")]
 
 
 def _hipcc() -> str:
@@ -23,7 +24,7 @@ def _hipcc() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(HARNESS_BIN):
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
@@ -48,7 +49,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    build_harness(verbose)
     return LIB
+
+
+HARNESS_SRC = os.path.join(HERE, "..", "harness", "decode_loop.cpp")
+HARNESS_BIN = os.path.join(HERE, "..", "harness", "decode_loop")
+
+
+def build_harness(verbose: bool = True) -> str:
+    """C++ mirror of ai00-core's infer task + greedy loop (harness/decode_loop.cpp), linked against the .so."""
+    cmd = ["g++", "-O2", "-std=c++17", HARNESS_SRC, "-o", HARNESS_BIN, "-L" + HERE, "-lrwkv_hip", "-Wl,-rpath," + HERE]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HARNESS_BIN
 
 
 if __name__ == "__main__":

@@ -592,6 +592,38 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
 
 int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam) {
     GemmLaunch Lh;
+    static const int no_tile = env_int("RWKV_NO_TILE");
+    if (T >= GEMM_TILE_MIN_T && !no_tile) {
+        // prefill: LDS-tiled MFMA GEMM, no K split (partial problems write one slab)
+        if (ps.empty() || ps.size() > GEMM_MAXP) throw RwkvError(RWKV_ERR_INVALID, "gemm: bad problem count");
+        Lh = GemmLaunch{};
+        Lh.nprob = (int)ps.size();
+        Lh.T = T;
+        // largest tile shape that still gives >= ~1024 blocks over the launch (else the smallest)
+        int shape = GEMM_TILE_SHAPES - 1;
+        for (int sh = 0; sh < GEMM_TILE_SHAPES; ++sh) {
+            long tot = 0;
+            for (auto &s : ps) tot += gemm_tile_blocks(sh, s.W->rows, T);
+            static const int min_blocks = env_int("RWKV_TILE_MIN_BLOCKS") ? env_int("RWKV_TILE_MIN_BLOCKS") : 1024;   // chunks are latency-bound: favour many small blocks
+            if (tot >= min_blocks) { shape = sh; break; }
+        }
+        int blocks = 0;
+        for (size_t i = 0; i < ps.size(); ++i) {
+            const ProbSpec &s = ps[i];
+            GemmProb &g = Lh.p[i];
+            g.W = s.W->data; g.S = s.W->scales; g.fmt = s.W->fmt; g.rows = s.W->rows; g.K = s.W->K;
+            g.xhi = s.x.hi + s.xoff; g.xlo = s.x.lo ? s.x.lo + s.xoff : nullptr; g.ldx = s.x.ld;
+            g.spb = 16; g.nw = 8; g.ksb = 1; g.nblk_strip = 0;
+            g.block_begin = blocks;
+            blocks += gemm_tile_blocks(shape, s.W->rows, T);
+            g.act = s.act; g.post = s.post; g.bias = s.bias; g.m0 = s.m0; g.m1 = s.m1; g.ldm = s.ldm;
+            g.out_f32 = s.out; g.ldo = s.ldo; g.partial_stride = pstride;
+            g.out_hi = s.oh.hi; g.out_lo = s.oh.lo; g.ldh = s.oh.ld;
+        }
+        Lh.total_blocks = blocks;
+        launch(fam, [&] { launch_gemm_tile(Lh, shape, hilo, s_main); });
+        return 1;
+    }
     const int np = plan_gemm(Lh, ps, T, hilo, pstride);
     launch(fam, [&] { launch_gemm(Lh, hilo, s_main); });
     return np;

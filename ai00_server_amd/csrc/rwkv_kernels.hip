@@ -391,6 +391,241 @@ void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
 int gemm_max_rounds(int fmt) { return fmt == W_F16 ? 2 : 4; }
 
 // =====================================================================================
+// Prefill GEMM (T >= 64): LDS-tiled MFMA GEMM over the same pre-tiled weights.
+// Block = 8 waves; wave w owns strips {2w, 2w+1} of the block's 16 strips (256 output rows) and all 8 n-tiles of
+// the block's 128-token tile (64 accumulator registers).  K is walked in chunks of 128: the X chunk
+// [128 tokens][128 k] is staged through LDS (register-staged, double-buffered, one barrier per chunk) and shared
+// by all waves; the wave's weight tiles go HBM/L2 -> registers (prefetched one chunk ahead) and every
+// dequantised A fragment feeds 8 MFMAs.  Bound: MFMA (2*rows*K*T flops), weights re-read T/128 times from L2/MALL.
+// =====================================================================================
+constexpr int TG_KC = 128, TG_STRIDE = TG_KC + 8;
+
+template <int FMT, int SPW> struct TRound { u32x4 q[SPW][4 / Fmt<FMT>::KS]; uint2 s[SPW]; };    // SPW strips x 128 k
+
+template <int FMT, int SPW>
+__device__ __forceinline__ void tg_load(TRound<FMT, SPW> &w, const GemmProb &P, int strip, int nstrips, int k0, int lane) {
+    constexpr int NTILE = 4 / Fmt<FMT>::KS, TK = Fmt<FMT>::TK, SH = Fmt<FMT>::SH;
+    const int KT = P.K >> SH;
+#pragma unroll
+    for (int h = 0; h < SPW; ++h) {
+        const bool ok = strip + h < nstrips;
+        const u32x4 *base = (const u32x4 *)P.W + ((long)(strip + h) * KT + (k0 >> SH)) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < NTILE; ++j) {
+            if (ok && k0 + j * TK < P.K) w.q[h][j] = base[j * 64];
+            else w.q[h][j] = (u32x4){0u, 0u, 0u, 0u};
+        }
+        if constexpr (FMT != W_F16) {
+            const int NG = P.K >> 8;
+            w.s[h] = (ok && k0 < P.K) ? *((const uint2 *)P.S + ((long)(strip + h) * NG + (k0 >> 8)) * 16 + (lane & 15)) : make_uint2(0, 0);
+        } else {
+            w.s[h] = make_uint2(0, 0);
+        }
+    }
+}
+
+// A fragment of k-step ks (0..3) of the 128-k chunk starting at k0
+template <int FMT, int SPW>
+__device__ __forceinline__ f16x8 tg_frag(const TRound<FMT, SPW> &w, int h, int ks, int k0, const Nf4Lut &lut) {
+    if constexpr (FMT == W_F16) {
+        return __builtin_bit_cast(f16x8, w.q[h][ks]);
+    } else if constexpr (FMT == W_INT8) {
+        const u32x4 q = w.q[h][ks >> 1];
+        const u32 d0 = (ks & 1) ? q.z : q.x, d1 = (ks & 1) ? q.w : q.y;
+        const u32 ab = ((k0 >> 7) & 1) ? w.s[h].y : w.s[h].x;    // the chunk is one 128-block of its 256-group
+        const f16x2 abh = as_h2(ab);
+        const f16x2 a2 = {abh[0], abh[0]}, b2 = {abh[1], abh[1]};
+        u32x4 r;
+        r.x = dq8(d0, 0x04010400u, a2, b2);
+        r.y = dq8(d0, 0x04030402u, a2, b2);
+        r.z = dq8(d1, 0x04010400u, a2, b2);
+        r.w = dq8(d1, 0x04030402u, a2, b2);
+        return __builtin_bit_cast(f16x8, r);
+    } else {
+        const u32x4 q = w.q[h][0];
+        const u32 d = ks == 0 ? q.x : ks == 1 ? q.y : ks == 2 ? q.z : q.w;
+        const u32 sw = ((k0 >> 7) & 1) ? w.s[h].y : w.s[h].x;    // 64-blocks 2*((k0>>7)&1) + (ks>>1)
+        const f16x2 sh = as_h2(sw);
+        const _Float16 am = (ks >> 1) ? sh[1] : sh[0];
+        const f16x2 am2 = {am, am};
+        u32x4 r;
+        u32 a, b;
+        nf4_lookup4(d & 0x0F0F0F0Fu, lut, a, b);
+        r.x = as_u32(as_h2(a) * am2);
+        r.y = as_u32(as_h2(b) * am2);
+        nf4_lookup4((d >> 4) & 0x0F0F0F0Fu, lut, a, b);
+        r.z = as_u32(as_h2(a) * am2);
+        r.w = as_u32(as_h2(b) * am2);
+        return __builtin_bit_cast(f16x8, r);
+    }
+}
+
+// Tile shape: WAVES waves x SPW strips per wave (rows = WAVES*SPW*16) x NTL n-tiles (tokens = NTL*16)
+template <bool HILO, int WAVES, int SPW, int NTL, int FMT>
+__device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
+    constexpr int BT = NTL * 16, THREADS = WAVES * 64, STRIPS = WAVES * SPW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lb = (int)blockIdx.x - P.block_begin;
+    const int ntt = (L.T + BT - 1) / BT;                          // token tiles
+    const int rb = lb / ntt, tt = lb - rb * ntt;
+    const int nstrips = P.rows >> 4;
+    const int strip = rb * STRIPS + wave * SPW;
+    const int t0 = tt * BT;
+    const int rows_valid = min(BT, L.T - t0);
+    const int K = P.K;
+    const int nchunk = (K + TG_KC - 1) / TG_KC;
+    constexpr int PART = BT * TG_STRIDE;                          // halfs per (buffer, hi|lo)
+    _Float16 *xs = (_Float16 *)smem;                              // [buf][hi|lo][BT][TG_STRIDE]
+    constexpr int XP = BT * TG_KC / 8 / THREADS;                  // 16-byte pieces per thread per part
+    Nf4Lut lut;
+    if constexpr (FMT == W_NF4) lut = make_nf4_lut();
+
+    f32x4 acc[SPW][NTL];
+#pragma unroll
+    for (int h = 0; h < SPW; ++h)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) acc[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 xh[XP], xl[HILO ? XP : 1];
+    auto stage_load = [&](int c) {
+        const int k0 = c * TG_KC;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int p = tid + i * THREADS;
+            const int r = p >> 4, c8 = p & 15;                    // 16 pieces per 128-k row
+            const int k = k0 + c8 * 8;
+            xh[i] = make_uint4(0, 0, 0, 0);
+            if constexpr (HILO) xl[i] = make_uint4(0, 0, 0, 0);
+            if (r < rows_valid && k < K) {
+                xh[i] = *(const uint4 *)(P.xhi + (long)(t0 + r) * P.ldx + k);
+                if constexpr (HILO) xl[i] = *(const uint4 *)(P.xlo + (long)(t0 + r) * P.ldx + k);
+            }
+        }
+    };
+    auto stage_store = [&](int buf) {
+        _Float16 *bh = xs + (HILO ? buf * 2 : buf) * PART;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int p = tid + i * THREADS;
+            const int r = p >> 4, c8 = p & 15;
+            *(uint4 *)(bh + r * TG_STRIDE + c8 * 8) = xh[i];
+            if constexpr (HILO) *(uint4 *)(bh + PART + r * TG_STRIDE + c8 * 8) = xl[i];
+        }
+    };
+
+    TRound<FMT, SPW> cur, nxt;
+    tg_load<FMT, SPW>(cur, P, strip, nstrips, 0, lane);
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int k0 = c * TG_KC;
+        if (c + 1 < nchunk) {
+            tg_load<FMT, SPW>(nxt, P, strip, nstrips, k0 + TG_KC, lane);
+            stage_load(c + 1);
+        }
+        const _Float16 *bh = xs + (HILO ? (c & 1) * 2 : (c & 1)) * PART;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (k0 + ks * 32 < K) {
+                f16x8 af[SPW];
+#pragma unroll
+                for (int h = 0; h < SPW; ++h) af[h] = tg_frag<FMT, SPW>(cur, h, ks, k0, lut);
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) {
+                    const int off = (nt * 16 + (lane & 15)) * TG_STRIDE + ks * 32 + (lane >> 4) * 8;
+                    const f16x8 xb = *(const f16x8 *)(bh + off);
+#pragma unroll
+                    for (int h = 0; h < SPW; ++h) acc[h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[h], xb, acc[h][nt], 0, 0, 0);
+                    if constexpr (HILO) {
+                        const f16x8 xc = *(const f16x8 *)(bh + PART + off);
+#pragma unroll
+                        for (int h = 0; h < SPW; ++h) acc[h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[h], xc, acc[h][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (c + 1 < nchunk) {
+            stage_store((c + 1) & 1);
+            __syncthreads();
+            cur = nxt;
+        }
+    }
+    // ---- epilogue
+#pragma unroll
+    for (int h = 0; h < SPW; ++h) {
+        if (strip + h < nstrips) {
+            const int row0 = (strip + h) * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) {
+                const int t = t0 + nt * 16 + (lane & 15);
+                if (t < L.T) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = acc[h][nt][r];
+                        if (P.bias) x += P.bias[row0 + r];
+                        x = apply_act(P.act, x);
+                        if (P.post == POST_MUL) x *= P.m0[(long)t * P.ldm + row0 + r];
+                        else if (P.post == POST_MIX)
+                            x = P.m0[(long)t * P.ldm + row0 + r] + P.m1[(long)t * P.ldm + row0 + r] * x;
+                        v[r] = x;
+                    }
+                    if (P.out_f32) *(float4 *)(P.out_f32 + (long)t * P.ldo + row0) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (P.out_hi) {
+                        f16x4 hh, ll;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { _Float16 a, b; split_hilo(v[r], a, b); hh[r] = a; ll[r] = b; }
+                        *(f16x4 *)(P.out_hi + (long)t * P.ldh + row0) = hh;
+                        if (P.out_lo) *(f16x4 *)(P.out_lo + (long)t * P.ldh + row0) = ll;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <bool HILO, int WAVES, int SPW, int NTL>
+__global__ __launch_bounds__(WAVES * 64) void gemm_tile_kernel(const GemmLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int pi = 0;
+    for (int i = 1; i < L.nprob; ++i)
+        if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
+    const GemmProb &P = L.p[pi];
+    if (P.fmt == W_F16) tg_body<HILO, WAVES, SPW, NTL, W_F16>(L, P, smem);
+    else if (P.fmt == W_INT8) tg_body<HILO, WAVES, SPW, NTL, W_INT8>(L, P, smem);
+    else tg_body<HILO, WAVES, SPW, NTL, W_NF4>(L, P, smem);
+}
+
+// tile shapes, largest first: {waves, strips per wave, n-tiles}
+static const int kTileShapes[4][3] = {{8, 2, 8}, {8, 1, 8}, {4, 1, 8}, {4, 1, 4}};
+int gemm_tile_blocks(int shape, int rows, int T) {
+    const int strips = kTileShapes[shape][0] * kTileShapes[shape][1], bt = kTileShapes[shape][2] * 16;
+    return ((rows / 16 + strips - 1) / strips) * ((T + bt - 1) / bt);
+}
+
+void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s) {
+    const int bt = kTileShapes[shape][2] * 16;
+    const size_t lds = (size_t)2 * (hilo ? 2 : 1) * bt * TG_STRIDE * 2;
+    static bool attr_done[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+#define TG_VARIANTS(X) X(true, 8, 2, 8, 0) X(true, 8, 1, 8, 1) X(true, 4, 1, 8, 2) X(true, 4, 1, 4, 3) \
+                       X(false, 8, 2, 8, 0) X(false, 8, 1, 8, 1) X(false, 4, 1, 8, 2) X(false, 4, 1, 4, 3)
+    if (!attr_done[dev & 15]) {
+#define SET_ATTR(h, w, p, n, i) (void)hipFuncSetAttribute((const void *)gemm_tile_kernel<h, w, p, n>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        TG_VARIANTS(SET_ATTR)
+#undef SET_ATTR
+        attr_done[dev & 15] = true;
+    }
+#define LAUNCH(h, w, p, n, i) if (hilo == h && shape == i) hipLaunchKernelGGL((gemm_tile_kernel<h, w, p, n>), dim3(L.total_blocks), dim3(w * 64), lds, s, L);
+    TG_VARIANTS(LAUNCH)
+#undef LAUNCH
+#undef TG_VARIANTS
+}
+
+// =====================================================================================
 // Row kernels (one 256-thread block per row)
 // =====================================================================================
 // PT = float4 groups per thread (C <= PT*1024).  Everything stays in registers (fully unrolled, predicated),

@@ -88,3 +88,19 @@ def test_tokenizer_matches_reference_algorithm(built_lib):
     assert tk.encode(b"") == []
     with pytest.raises(rt.RwkvError):
         tk.decode([10 ** 7])
+
+
+def test_cpp_mirror_builds_and_reports_errors(built_lib, tmp_path):
+    """The C++ host mirror (include/rwkv_runtime.hpp + harness/decode_loop.cpp) compiles against the header and
+    surfaces engine errors as exit code 1 (no GPU here) instead of aborting."""
+    import subprocess
+    from ai00_server_amd import build as B
+    exe = B.build_harness(verbose=False)
+    assert subprocess.run([exe], capture_output=True).returncode == 2
+    path = tmp_path / "m.st"
+    path.write_bytes(R.st_serialize(R.synth_named("v6-tiny")))
+    r = subprocess.run([exe, str(path), "0", "0", "1", "8", "2", "5", "6"], capture_output=True, text=True)
+    if rt.lib().rwkv_device_count() == 0:
+        assert r.returncode == 1 and "no HIP device" in r.stderr
+    else:
+        assert r.returncode == 0
