@@ -502,6 +502,10 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
     HIP_CHECK(hipHostMalloc((void **)&h_meta, meta_cap * 4, hipHostMallocDefault));
     d_tok_feedback = dalloc<int>(chunk);
     d_counter = dalloc<int>(4);
+    soft_rows_cap = (size_t)std::max(1, max_batch);
+    soft_in = dalloc<float>(soft_rows_cap * V);
+    soft_out = dalloc<float>(soft_rows_cap * V);
+    HIP_CHECK(hipHostMalloc((void **)&soft_host, soft_rows_cap * V * 4, hipHostMallocDefault));
     d_amax_v = dalloc<float>((size_t)chunk * 32);
     d_amax_i = dalloc<int>((size_t)chunk * 32);
     HIP_CHECK(hipDeviceSynchronize());
@@ -1111,24 +1115,20 @@ rwkv_status rwkv_softmax(rwkv_engine *e, const float *const *in, float *const *o
         const size_t V = (size_t)e->info.num_vocab;
         static std::mutex mu;                                  // one softmax task per engine by contract; guard the staging
         std::lock_guard<std::mutex> lk(mu);
-        if (n_rows > e->soft_rows_cap) {
-            if (e->soft_host) (void)hipHostFree(e->soft_host);
-            e->soft_host = nullptr;
-            const size_t cap = std::max<size_t>(n_rows, (size_t)e->max_batch);
-            e->soft_in = e->dalloc<float>(cap * V);
-            e->soft_out = e->dalloc<float>(cap * V);
-            HIP_CHECK(hipHostMalloc((void **)&e->soft_host, cap * V * 4, hipHostMallocDefault));
-            e->soft_rows_cap = cap;
+        // staging for max_batch rows is allocated at load (never from this thread: the allocator belongs to the infer
+        // thread); larger requests are processed in groups
+        for (size_t r0 = 0; r0 < n_rows; r0 += e->soft_rows_cap) {
+            const size_t n = std::min(e->soft_rows_cap, n_rows - r0);
+            for (size_t r = 0; r < n; ++r) {
+                if (!in[r0 + r] || !out[r0 + r]) throw RwkvError(RWKV_ERR_INVALID, "null row");
+                std::memcpy(e->soft_host + r * V, in[r0 + r], V * 4);
+            }
+            HIP_CHECK(hipMemcpyAsync(e->soft_in, e->soft_host, n * V * 4, hipMemcpyHostToDevice, e->s_soft));
+            launch_softmax(e->soft_in, e->soft_out, (int)n, (int)V, e->s_soft);
+            HIP_CHECK(hipMemcpyAsync(e->soft_host, e->soft_out, n * V * 4, hipMemcpyDeviceToHost, e->s_soft));
+            HIP_CHECK(hipStreamSynchronize(e->s_soft));
+            for (size_t r = 0; r < n; ++r) std::memcpy(out[r0 + r], e->soft_host + r * V, V * 4);
         }
-        for (size_t r = 0; r < n_rows; ++r) {
-            if (!in[r] || !out[r]) throw RwkvError(RWKV_ERR_INVALID, "null row");
-            std::memcpy(e->soft_host + r * V, in[r], V * 4);
-        }
-        HIP_CHECK(hipMemcpyAsync(e->soft_in, e->soft_host, n_rows * V * 4, hipMemcpyHostToDevice, e->s_soft));
-        launch_softmax(e->soft_in, e->soft_out, (int)n_rows, (int)V, e->s_soft);
-        HIP_CHECK(hipMemcpyAsync(e->soft_host, e->soft_out, n_rows * V * 4, hipMemcpyDeviceToHost, e->s_soft));
-        HIP_CHECK(hipStreamSynchronize(e->s_soft));
-        for (size_t r = 0; r < n_rows; ++r) std::memcpy(out[r], e->soft_host + r * V, V * 4);
     });
 }
 
@@ -1217,6 +1217,23 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
                 ps[0].W = &mats[i % nmat]; ps[0].x = x; ps[0].out = K > 5120 ? pbuf : out; ps[0].ldo = rows;
                 ps[0].partial = K > 5120;
                 GemmLaunch Lh;
+                if (T >= GEMM_TILE_MIN_T) {                      // prefill path; `spb` selects the tile shape (0..3), -1 = auto
+                    int shape = spb;
+                    if (shape < 0 || shape >= GEMM_TILE_SHAPES) {
+                        shape = GEMM_TILE_SHAPES - 1;
+                        for (int sh = 0; sh < GEMM_TILE_SHAPES; ++sh) if (gemm_tile_blocks(sh, rows, T) >= 1024) { shape = sh; break; }
+                    }
+                    Lh = GemmLaunch{};
+                    Lh.nprob = 1; Lh.T = T;
+                    GemmProb &g = Lh.p[0];
+                    g.W = ps[0].W->data; g.S = ps[0].W->scales; g.fmt = fmt; g.rows = rows; g.K = K;
+                    g.xhi = x.hi; g.xlo = x.lo; g.ldx = K; g.ksb = 1; g.block_begin = 0;
+                    g.out_f32 = out; g.ldo = rows;
+                    Lh.total_blocks = gemm_tile_blocks(shape, rows, T);
+                    if (lds_kib) *lds_kib = (float)Lh.total_blocks;
+                    launch_gemm_tile(Lh, shape, hilo != 0, st);
+                    continue;
+                }
                 plan_gemm(Lh, ps, T, hilo != 0, (long)T * rows, spb);
                 if (lds_kib) *lds_kib = (float)Lh.total_blocks;
                 launch_gemm(Lh, hilo != 0, st);

@@ -13,6 +13,7 @@
 //
 // gfx950 only: wave = 64 lanes, v_mfma_f32_16x16x32_f16, no portability shims.
 #include "rwkv_kernels.h"
+#include <type_traits>
 
 namespace rwkv {
 
@@ -402,22 +403,24 @@ constexpr int TG_KC = 128, TG_STRIDE = TG_KC + 8;
 
 template <int FMT, int SPW> struct TRound { u32x4 q[SPW][4 / Fmt<FMT>::KS]; uint2 s[SPW]; };    // SPW strips x 128 k
 
-template <int FMT, int SPW>
+// FULL = true: the whole 128-k chunk lies inside K -> no predicates (strips beyond the matrix are clamped to the last
+// strip: their results are never stored), so the compiler can count the loads in flight (s_waitcnt vmcnt(N)).
+template <int FMT, int SPW, bool FULL>
 __device__ __forceinline__ void tg_load(TRound<FMT, SPW> &w, const GemmProb &P, int strip, int nstrips, int k0, int lane) {
     constexpr int NTILE = 4 / Fmt<FMT>::KS, TK = Fmt<FMT>::TK, SH = Fmt<FMT>::SH;
     const int KT = P.K >> SH;
 #pragma unroll
     for (int h = 0; h < SPW; ++h) {
-        const bool ok = strip + h < nstrips;
-        const u32x4 *base = (const u32x4 *)P.W + ((long)(strip + h) * KT + (k0 >> SH)) * 64 + lane;
+        const int sidx = min(strip + h, nstrips - 1);
+        const u32x4 *base = (const u32x4 *)P.W + ((long)sidx * KT + (k0 >> SH)) * 64 + lane;
 #pragma unroll
         for (int j = 0; j < NTILE; ++j) {
-            if (ok && k0 + j * TK < P.K) w.q[h][j] = base[j * 64];
+            if (FULL || k0 + j * TK < P.K) w.q[h][j] = base[j * 64];
             else w.q[h][j] = (u32x4){0u, 0u, 0u, 0u};
         }
         if constexpr (FMT != W_F16) {
             const int NG = P.K >> 8;
-            w.s[h] = (ok && k0 < P.K) ? *((const uint2 *)P.S + ((long)(strip + h) * NG + (k0 >> 8)) * 16 + (lane & 15)) : make_uint2(0, 0);
+            w.s[h] = (FULL || k0 < P.K) ? *((const uint2 *)P.S + ((long)sidx * NG + (k0 >> 8)) * 16 + (lane & 15)) : make_uint2(0, 0);
         } else {
             w.s[h] = make_uint2(0, 0);
         }
@@ -487,69 +490,97 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) acc[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    uint4 xh[XP], xl[HILO ? XP : 1];
-    auto stage_load = [&](int c) {
+    // X staging registers (one chunk ahead of the LDS buffer being multiplied).  Rows beyond the step are clamped
+    // to its last row (never stored); FULL chunks carry no predicates at all.
+    struct XRegs { uint4 h[XP], l[HILO ? XP : 1]; };
+    auto stage_load = [&](XRegs &x, int c, auto full) {
+        constexpr bool FULL = decltype(full)::value;
         const int k0 = c * TG_KC;
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int p = tid + i * THREADS;
-            const int r = p >> 4, c8 = p & 15;                    // 16 pieces per 128-k row
+            const int r = min(p >> 4, rows_valid - 1), c8 = p & 15;   // 16 pieces per 128-k row
             const int k = k0 + c8 * 8;
-            xh[i] = make_uint4(0, 0, 0, 0);
-            if constexpr (HILO) xl[i] = make_uint4(0, 0, 0, 0);
-            if (r < rows_valid && k < K) {
-                xh[i] = *(const uint4 *)(P.xhi + (long)(t0 + r) * P.ldx + k);
-                if constexpr (HILO) xl[i] = *(const uint4 *)(P.xlo + (long)(t0 + r) * P.ldx + k);
+            if (FULL || k < K) {
+                x.h[i] = *(const uint4 *)(P.xhi + (long)(t0 + r) * P.ldx + k);
+                if constexpr (HILO) x.l[i] = *(const uint4 *)(P.xlo + (long)(t0 + r) * P.ldx + k);
+            } else {
+                x.h[i] = make_uint4(0, 0, 0, 0);
+                if constexpr (HILO) x.l[i] = make_uint4(0, 0, 0, 0);
             }
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](const XRegs &x, int buf) {
         _Float16 *bh = xs + (HILO ? buf * 2 : buf) * PART;
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int p = tid + i * THREADS;
             const int r = p >> 4, c8 = p & 15;
-            *(uint4 *)(bh + r * TG_STRIDE + c8 * 8) = xh[i];
-            if constexpr (HILO) *(uint4 *)(bh + PART + r * TG_STRIDE + c8 * 8) = xl[i];
+            *(uint4 *)(bh + r * TG_STRIDE + c8 * 8) = x.h[i];
+            if constexpr (HILO) *(uint4 *)(bh + PART + r * TG_STRIDE + c8 * 8) = x.l[i];
         }
     };
-
-    TRound<FMT, SPW> cur, nxt;
-    tg_load<FMT, SPW>(cur, P, strip, nstrips, 0, lane);
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
+    auto mma_chunk = [&](const TRound<FMT, SPW> &w, int c, auto full) {
+        constexpr bool FULL = decltype(full)::value;
         const int k0 = c * TG_KC;
-        if (c + 1 < nchunk) {
-            tg_load<FMT, SPW>(nxt, P, strip, nstrips, k0 + TG_KC, lane);
-            stage_load(c + 1);
-        }
         const _Float16 *bh = xs + (HILO ? (c & 1) * 2 : (c & 1)) * PART;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (k0 + ks * 32 < K) {
-                f16x8 af[SPW];
-#pragma unroll
-                for (int h = 0; h < SPW; ++h) af[h] = tg_frag<FMT, SPW>(cur, h, ks, k0, lut);
+            if (FULL || k0 + ks * 32 < K) {
+                f16x8 xv[NTL], xc[HILO ? NTL : 1];                  // all B fragments of the k-step in flight at once
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt) {
                     const int off = (nt * 16 + (lane & 15)) * TG_STRIDE + ks * 32 + (lane >> 4) * 8;
-                    const f16x8 xb = *(const f16x8 *)(bh + off);
+                    xv[nt] = *(const f16x8 *)(bh + off);
+                    if constexpr (HILO) xc[nt] = *(const f16x8 *)(bh + PART + off);
+                }
+                f16x8 af[SPW];
 #pragma unroll
-                    for (int h = 0; h < SPW; ++h) acc[h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[h], xb, acc[h][nt], 0, 0, 0);
-                    if constexpr (HILO) {
-                        const f16x8 xc = *(const f16x8 *)(bh + PART + off);
+                for (int h = 0; h < SPW; ++h) af[h] = tg_frag<FMT, SPW>(w, h, ks, k0, lut);
 #pragma unroll
-                        for (int h = 0; h < SPW; ++h) acc[h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[h], xc, acc[h][nt], 0, 0, 0);
+                for (int nt = 0; nt < NTL; ++nt) {
+#pragma unroll
+                    for (int h = 0; h < SPW; ++h) {
+                        acc[h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[h], xv[nt], acc[h][nt], 0, 0, 0);
+                        if constexpr (HILO) acc[h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[h], xc[nt], acc[h][nt], 0, 0, 0);
                     }
                 }
             }
         }
-        if (c + 1 < nchunk) {
-            stage_store((c + 1) & 1);
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+
+    // software pipeline: while chunk c is multiplied, the weights and the X rows of chunk c+1 are in flight to
+    // registers (unpredicated in the steady state so the compiler can count them); they go to the other LDS buffer
+    // after the MFMAs; one barrier per chunk.  (A distance-2 variant was measured slower: the register-set rotation
+    // forces the waits anyway and the extra sets spill.)
+    const int nfull = K / TG_KC;                                   // chunks entirely inside K
+    TRound<FMT, SPW> cur, nxt;
+    XRegs xa;
+    if (nfull > 0) { tg_load<FMT, SPW, true>(cur, P, strip, nstrips, 0, lane); stage_load(xa, 0, T_{}); }
+    else { tg_load<FMT, SPW, false>(cur, P, strip, nstrips, 0, lane); stage_load(xa, 0, F_{}); }
+    stage_store(xa, 0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        if (c + 1 < nfull) {                                       // steady state: everything unpredicated
+            tg_load<FMT, SPW, true>(nxt, P, strip, nstrips, (c + 1) * TG_KC, lane);
+            stage_load(xa, c + 1, T_{});
+            mma_chunk(cur, c, T_{});
+            stage_store(xa, (c + 1) & 1);
             __syncthreads();
             cur = nxt;
+        } else {
+            if (c + 1 < nchunk) {
+                tg_load<FMT, SPW, false>(nxt, P, strip, nstrips, (c + 1) * TG_KC, lane);
+                stage_load(xa, c + 1, F_{});
+            }
+            if (c < nfull) mma_chunk(cur, c, T_{}); else mma_chunk(cur, c, F_{});
+            if (c + 1 < nchunk) {
+                stage_store(xa, (c + 1) & 1);
+                __syncthreads();
+                cur = nxt;
+            }
         }
     }
     // ---- epilogue
