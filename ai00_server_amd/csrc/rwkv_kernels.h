@@ -164,6 +164,7 @@ struct StatePackArgs {
 void launch_state_pack(const StatePackArgs &a, hipStream_t s);
 
 void launch_softmax(const float *in, float *out, int n_rows, int V, hipStream_t s);
+void launch_empty(hipStream_t s);                        // measurement calibration (event-pair overhead)
 // two-stage arg-max; scratch_v / scratch_i hold n_rows*32 partial (value, index) pairs
 void launch_argmax(const float *logits, int n_rows, int V, int *out_tok, float *scratch_v, int *scratch_i, hipStream_t s);
 

@@ -14,6 +14,7 @@
 // gfx950 only: wave = 64 lanes, v_mfma_f32_16x16x32_f16, no portability shims.
 #include "rwkv_kernels.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace rwkv {
 
@@ -359,8 +360,9 @@ __global__ __launch_bounds__(GEMM_MAX_WAVES * 64) void gemm_kernel(const GemmLau
 }
 
 void gemm_variant(int T, bool hilo, int &NT, int &KSW) {
+    static const int ksw8 = std::getenv("RWKV_KSW8") ? std::atoi(std::getenv("RWKV_KSW8")) : 0;
     if (hilo) { NT = 1; KSW = 8; }
-    else if (T <= 16) { NT = 1; KSW = 16; }
+    else if (T <= 16) { NT = 1; KSW = ksw8 ? 8 : 16; }
     else { NT = 2; KSW = 8; }
 }
 
@@ -372,7 +374,7 @@ void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
     static bool attr_done[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
-#define GEMM_V3(X, sh, tl) X(1, 8, true, sh, tl) X(1, 16, false, sh, tl) X(2, 8, false, sh, tl)
+#define GEMM_V3(X, sh, tl) X(1, 8, true, sh, tl) X(1, 16, false, sh, tl) X(2, 8, false, sh, tl) X(1, 8, false, sh, tl)
 #define GEMM_VARIANTS(X) GEMM_V3(X, true, true) GEMM_V3(X, true, false) GEMM_V3(X, false, true) GEMM_V3(X, false, false)
     if (!attr_done[dev & 15]) {                               // allow > 64 KiB dynamic LDS (gfx950: 160 KiB / CU)
         const int cap = 160 * 1024;
@@ -1003,6 +1005,9 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float *in, float *ou
     const float inv = 1.0f / s;
     for (int i = threadIdx.x; i < V; i += 256) y[i] = expf(x[i] - m) * inv;
 }
+__global__ void empty_kernel() {}
+void launch_empty(hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s); }
+
 void launch_softmax(const float *in, float *out, int n_rows, int V, hipStream_t s) {
     hipLaunchKernelGGL(softmax_kernel, dim3(n_rows), dim3(256), 0, s, in, out, V);
 }
