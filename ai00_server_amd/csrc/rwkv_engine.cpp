@@ -603,14 +603,14 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam) {
         Lh = GemmLaunch{};
         Lh.nprob = (int)ps.size();
         Lh.T = T;
-        // largest tile shape that still gives >= ~1024 blocks over the launch (else the smallest)
-        int shape = GEMM_TILE_SHAPES - 1;
-        for (int sh = 0; sh < GEMM_TILE_SHAPES; ++sh) {
-            long tot = 0;
-            for (auto &s : ps) tot += gemm_tile_blocks(sh, s.W->rows, T);
-            static const int min_blocks = env_int("RWKV_TILE_MIN_BLOCKS") ? env_int("RWKV_TILE_MIN_BLOCKS") : 1024;   // chunks are latency-bound: favour many small blocks
-            if (tot >= min_blocks) { shape = sh; break; }
-        }
+        // 64x64 tiles measured best everywhere (tile_bench): with 256-k chunks while the launch is latency-bound
+        // (few blocks: one L2 round trip per chunk dominates), with 128-k chunks (more blocks per CU) once it is
+        // throughput-bound.  RWKV_TILE_SHAPE overrides (0..5) for experiments.
+        static const int f_shape = std::getenv("RWKV_TILE_SHAPE") ? env_int("RWKV_TILE_SHAPE") : -1;
+        long tot64 = 0;
+        for (auto &s : ps) tot64 += gemm_tile_blocks(3, s.W->rows, T);
+        int shape = tot64 <= 1536 ? 4 : 3;
+        if (f_shape >= 0 && f_shape < GEMM_TILE_SHAPES) shape = f_shape;
         int blocks = 0;
         for (size_t i = 0; i < ps.size(); ++i) {
             const ProbSpec &s = ps[i];

@@ -401,15 +401,14 @@ int gemm_max_rounds(int fmt) { return fmt == W_F16 ? 2 : 4; }
 // by all waves; the wave's weight tiles go HBM/L2 -> registers (prefetched one chunk ahead) and every
 // dequantised A fragment feeds 8 MFMAs.  Bound: MFMA (2*rows*K*T flops), weights re-read T/128 times from L2/MALL.
 // =====================================================================================
-constexpr int TG_KC = 128, TG_STRIDE = TG_KC + 8;
+// KC = k per chunk (128 or 256); LDS row stride KC + 8 halfs (16 B pad: conflict-free ds_read_b128)
+template <int FMT, int SPW, int KC> struct TRound { u32x4 q[SPW][(KC / 32) / Fmt<FMT>::KS]; uint2 s[SPW]; };
 
-template <int FMT, int SPW> struct TRound { u32x4 q[SPW][4 / Fmt<FMT>::KS]; uint2 s[SPW]; };    // SPW strips x 128 k
-
-// FULL = true: the whole 128-k chunk lies inside K -> no predicates (strips beyond the matrix are clamped to the last
+// FULL = true: the whole chunk lies inside K -> no predicates (strips beyond the matrix are clamped to the last
 // strip: their results are never stored), so the compiler can count the loads in flight (s_waitcnt vmcnt(N)).
-template <int FMT, int SPW, bool FULL>
-__device__ __forceinline__ void tg_load(TRound<FMT, SPW> &w, const GemmProb &P, int strip, int nstrips, int k0, int lane) {
-    constexpr int NTILE = 4 / Fmt<FMT>::KS, TK = Fmt<FMT>::TK, SH = Fmt<FMT>::SH;
+template <int FMT, int SPW, int KC, bool FULL>
+__device__ __forceinline__ void tg_load(TRound<FMT, SPW, KC> &w, const GemmProb &P, int strip, int nstrips, int k0, int lane) {
+    constexpr int NTILE = (KC / 32) / Fmt<FMT>::KS, TK = Fmt<FMT>::TK, SH = Fmt<FMT>::SH;
     const int KT = P.K >> SH;
 #pragma unroll
     for (int h = 0; h < SPW; ++h) {
@@ -421,7 +420,7 @@ __device__ __forceinline__ void tg_load(TRound<FMT, SPW> &w, const GemmProb &P, 
             else w.q[h][j] = (u32x4){0u, 0u, 0u, 0u};
         }
         if constexpr (FMT != W_F16) {
-            const int NG = P.K >> 8;
+            const int NG = P.K >> 8;                              // quantised K is a multiple of 256: one scale word per chunk
             w.s[h] = (FULL || k0 < P.K) ? *((const uint2 *)P.S + ((long)sidx * NG + (k0 >> 8)) * 16 + (lane & 15)) : make_uint2(0, 0);
         } else {
             w.s[h] = make_uint2(0, 0);
@@ -429,15 +428,16 @@ __device__ __forceinline__ void tg_load(TRound<FMT, SPW> &w, const GemmProb &P, 
     }
 }
 
-// A fragment of k-step ks (0..3) of the 128-k chunk starting at k0
-template <int FMT, int SPW>
-__device__ __forceinline__ f16x8 tg_frag(const TRound<FMT, SPW> &w, int h, int ks, int k0, const Nf4Lut &lut) {
+// A fragment of k-step ks (0..KC/32) of the chunk starting at k0
+template <int FMT, int SPW, int KC>
+__device__ __forceinline__ f16x8 tg_frag(const TRound<FMT, SPW, KC> &w, int h, int ks, int k0, const Nf4Lut &lut) {
+    const int kk = k0 + ks * 32;                                  // absolute k of this k-step
     if constexpr (FMT == W_F16) {
         return __builtin_bit_cast(f16x8, w.q[h][ks]);
     } else if constexpr (FMT == W_INT8) {
         const u32x4 q = w.q[h][ks >> 1];
         const u32 d0 = (ks & 1) ? q.z : q.x, d1 = (ks & 1) ? q.w : q.y;
-        const u32 ab = ((k0 >> 7) & 1) ? w.s[h].y : w.s[h].x;    // the chunk is one 128-block of its 256-group
+        const u32 ab = ((kk >> 7) & 1) ? w.s[h].y : w.s[h].x;    // 128-block inside the 256-group
         const f16x2 abh = as_h2(ab);
         const f16x2 a2 = {abh[0], abh[0]}, b2 = {abh[1], abh[1]};
         u32x4 r;
@@ -447,11 +447,12 @@ __device__ __forceinline__ f16x8 tg_frag(const TRound<FMT, SPW> &w, int h, int k
         r.w = dq8(d1, 0x04030402u, a2, b2);
         return __builtin_bit_cast(f16x8, r);
     } else {
-        const u32x4 q = w.q[h][0];
-        const u32 d = ks == 0 ? q.x : ks == 1 ? q.y : ks == 2 ? q.z : q.w;
-        const u32 sw = ((k0 >> 7) & 1) ? w.s[h].y : w.s[h].x;    // 64-blocks 2*((k0>>7)&1) + (ks>>1)
+        const u32x4 q = w.q[h][ks >> 2];
+        const int wsel = ks & 3;
+        const u32 d = wsel == 0 ? q.x : wsel == 1 ? q.y : wsel == 2 ? q.z : q.w;
+        const u32 sw = ((kk >> 7) & 1) ? w.s[h].y : w.s[h].x;    // 64-blocks 2*((kk>>7)&1) + ((kk>>6)&1)
         const f16x2 sh = as_h2(sw);
-        const _Float16 am = (ks >> 1) ? sh[1] : sh[0];
+        const _Float16 am = ((kk >> 6) & 1) ? sh[1] : sh[0];
         const f16x2 am2 = {am, am};
         u32x4 r;
         u32 a, b;
@@ -466,9 +467,9 @@ __device__ __forceinline__ f16x8 tg_frag(const TRound<FMT, SPW> &w, int h, int k
 }
 
 // Tile shape: WAVES waves x SPW strips per wave (rows = WAVES*SPW*16) x NTL n-tiles (tokens = NTL*16)
-template <bool HILO, int WAVES, int SPW, int NTL, int FMT>
+template <bool HILO, int WAVES, int SPW, int NTL, int KC, int FMT>
 __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
-    constexpr int BT = NTL * 16, THREADS = WAVES * 64, STRIPS = WAVES * SPW;
+    constexpr int BT = NTL * 16, THREADS = WAVES * 64, STRIPS = WAVES * SPW, TG_KC = KC, TG_STRIDE = KC + 8, PPR = KC / 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lb = (int)blockIdx.x - P.block_begin;
@@ -501,7 +502,7 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int p = tid + i * THREADS;
-            const int r = min(p >> 4, rows_valid - 1), c8 = p & 15;   // 16 pieces per 128-k row
+            const int r = min(p / PPR, rows_valid - 1), c8 = p % PPR;  // PPR 16-byte pieces per row of the chunk
             const int k = k0 + c8 * 8;
             if (FULL || k < K) {
                 x.h[i] = *(const uint4 *)(P.xhi + (long)(t0 + r) * P.ldx + k);
@@ -517,17 +518,17 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int p = tid + i * THREADS;
-            const int r = p >> 4, c8 = p & 15;
+            const int r = p / PPR, c8 = p % PPR;
             *(uint4 *)(bh + r * TG_STRIDE + c8 * 8) = x.h[i];
             if constexpr (HILO) *(uint4 *)(bh + PART + r * TG_STRIDE + c8 * 8) = x.l[i];
         }
     };
-    auto mma_chunk = [&](const TRound<FMT, SPW> &w, int c, auto full) {
+    auto mma_chunk = [&](const TRound<FMT, SPW, KC> &w, int c, auto full) {
         constexpr bool FULL = decltype(full)::value;
         const int k0 = c * TG_KC;
         const _Float16 *bh = xs + (HILO ? (c & 1) * 2 : (c & 1)) * PART;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KC / 32; ++ks) {
             if (FULL || k0 + ks * 32 < K) {
                 f16x8 xv[NTL], xc[HILO ? NTL : 1];                  // all B fragments of the k-step in flight at once
 #pragma unroll
@@ -538,7 +539,7 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
                 }
                 f16x8 af[SPW];
 #pragma unroll
-                for (int h = 0; h < SPW; ++h) af[h] = tg_frag<FMT, SPW>(w, h, ks, k0, lut);
+                for (int h = 0; h < SPW; ++h) af[h] = tg_frag<FMT, SPW, KC>(w, h, ks, k0, lut);
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt) {
 #pragma unroll
@@ -558,15 +559,15 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
     // after the MFMAs; one barrier per chunk.  (A distance-2 variant was measured slower: the register-set rotation
     // forces the waits anyway and the extra sets spill.)
     const int nfull = K / TG_KC;                                   // chunks entirely inside K
-    TRound<FMT, SPW> cur, nxt;
+    TRound<FMT, SPW, KC> cur, nxt;
     XRegs xa;
-    if (nfull > 0) { tg_load<FMT, SPW, true>(cur, P, strip, nstrips, 0, lane); stage_load(xa, 0, T_{}); }
-    else { tg_load<FMT, SPW, false>(cur, P, strip, nstrips, 0, lane); stage_load(xa, 0, F_{}); }
+    if (nfull > 0) { tg_load<FMT, SPW, KC, true>(cur, P, strip, nstrips, 0, lane); stage_load(xa, 0, T_{}); }
+    else { tg_load<FMT, SPW, KC, false>(cur, P, strip, nstrips, 0, lane); stage_load(xa, 0, F_{}); }
     stage_store(xa, 0);
     __syncthreads();
     for (int c = 0; c < nchunk; ++c) {
         if (c + 1 < nfull) {                                       // steady state: everything unpredicated
-            tg_load<FMT, SPW, true>(nxt, P, strip, nstrips, (c + 1) * TG_KC, lane);
+            tg_load<FMT, SPW, KC, true>(nxt, P, strip, nstrips, (c + 1) * TG_KC, lane);
             stage_load(xa, c + 1, T_{});
             mma_chunk(cur, c, T_{});
             stage_store(xa, (c + 1) & 1);
@@ -574,7 +575,7 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
             cur = nxt;
         } else {
             if (c + 1 < nchunk) {
-                tg_load<FMT, SPW, false>(nxt, P, strip, nstrips, (c + 1) * TG_KC, lane);
+                tg_load<FMT, SPW, KC, false>(nxt, P, strip, nstrips, (c + 1) * TG_KC, lane);
                 stage_load(xa, c + 1, F_{});
             }
             if (c < nfull) mma_chunk(cur, c, T_{}); else mma_chunk(cur, c, F_{});
@@ -619,43 +620,44 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
     }
 }
 
-template <bool HILO, int WAVES, int SPW, int NTL>
+template <bool HILO, int WAVES, int SPW, int NTL, int KC>
 __global__ __launch_bounds__(WAVES * 64) void gemm_tile_kernel(const GemmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int pi = 0;
     for (int i = 1; i < L.nprob; ++i)
         if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
     const GemmProb &P = L.p[pi];
-    if (P.fmt == W_F16) tg_body<HILO, WAVES, SPW, NTL, W_F16>(L, P, smem);
-    else if (P.fmt == W_INT8) tg_body<HILO, WAVES, SPW, NTL, W_INT8>(L, P, smem);
-    else tg_body<HILO, WAVES, SPW, NTL, W_NF4>(L, P, smem);
+    if (P.fmt == W_F16) tg_body<HILO, WAVES, SPW, NTL, KC, W_F16>(L, P, smem);
+    else if (P.fmt == W_INT8) tg_body<HILO, WAVES, SPW, NTL, KC, W_INT8>(L, P, smem);
+    else tg_body<HILO, WAVES, SPW, NTL, KC, W_NF4>(L, P, smem);
 }
 
-// tile shapes, largest first: {waves, strips per wave, n-tiles}
-static const int kTileShapes[4][3] = {{8, 2, 8}, {8, 1, 8}, {4, 1, 8}, {4, 1, 4}};
+// tile shapes, largest first: {waves, strips per wave, n-tiles, k per chunk}
+static const int kTileShapes[GEMM_TILE_SHAPES][4] = {{8, 2, 8, 128}, {8, 1, 8, 128}, {4, 1, 8, 128}, {4, 1, 4, 128}, {4, 1, 4, 256}, {8, 1, 8, 256}};
 int gemm_tile_blocks(int shape, int rows, int T) {
     const int strips = kTileShapes[shape][0] * kTileShapes[shape][1], bt = kTileShapes[shape][2] * 16;
     return ((rows / 16 + strips - 1) / strips) * ((T + bt - 1) / bt);
 }
 
 void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s) {
-    const int bt = kTileShapes[shape][2] * 16;
-    const size_t lds = (size_t)2 * (hilo ? 2 : 1) * bt * TG_STRIDE * 2;
+    const int bt = kTileShapes[shape][2] * 16, kc = kTileShapes[shape][3];
+    const size_t lds = (size_t)2 * (hilo ? 2 : 1) * bt * (kc + 8) * 2;
     static bool attr_done[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
-#define TG_VARIANTS(X) X(true, 8, 2, 8, 0) X(true, 8, 1, 8, 1) X(true, 4, 1, 8, 2) X(true, 4, 1, 4, 3) \
-                       X(false, 8, 2, 8, 0) X(false, 8, 1, 8, 1) X(false, 4, 1, 8, 2) X(false, 4, 1, 4, 3)
+#define TG_SH(X, h) X(h, 8, 2, 8, 128, 0) X(h, 8, 1, 8, 128, 1) X(h, 4, 1, 8, 128, 2) X(h, 4, 1, 4, 128, 3) X(h, 4, 1, 4, 256, 4) X(h, 8, 1, 8, 256, 5)
+#define TG_VARIANTS(X) TG_SH(X, true) TG_SH(X, false)
     if (!attr_done[dev & 15]) {
-#define SET_ATTR(h, w, p, n, i) (void)hipFuncSetAttribute((const void *)gemm_tile_kernel<h, w, p, n>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define SET_ATTR(h, w, p, n, k, i) (void)hipFuncSetAttribute((const void *)gemm_tile_kernel<h, w, p, n, k>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         TG_VARIANTS(SET_ATTR)
 #undef SET_ATTR
         attr_done[dev & 15] = true;
     }
-#define LAUNCH(h, w, p, n, i) if (hilo == h && shape == i) hipLaunchKernelGGL((gemm_tile_kernel<h, w, p, n>), dim3(L.total_blocks), dim3(w * 64), lds, s, L);
+#define LAUNCH(h, w, p, n, k, i) if (hilo == h && shape == i) hipLaunchKernelGGL((gemm_tile_kernel<h, w, p, n, k>), dim3(L.total_blocks), dim3(w * 64), lds, s, L);
     TG_VARIANTS(LAUNCH)
 #undef LAUNCH
 #undef TG_VARIANTS
+#undef TG_SH
 }
 
 // =====================================================================================
