@@ -178,6 +178,12 @@ struct rwkv_engine {
     int *d_meta = nullptr, *h_meta = nullptr;
     size_t meta_cap = 0;
     int *d_tok_feedback = nullptr, *d_hist = nullptr, *d_counter = nullptr, *d_amax_i = nullptr;
+    // sampling front-end: per-row params, sparse adjustments (row, token, value), outputs; pinned host mirror
+    SampleRow *d_samp = nullptr;
+    int *d_adj_row = nullptr, *d_adj_tok = nullptr, *d_samp_tok = nullptr;
+    float *d_adj_val = nullptr, *d_samp_prob = nullptr;
+    unsigned char *h_samp = nullptr;
+    static constexpr size_t ADJ_CAP = 1 << 16;
     float *d_amax_v = nullptr;
     size_t hist_cap = 0;
 
@@ -217,6 +223,7 @@ struct rwkv_engine {
         if (logits_host) (void)hipHostFree(logits_host);
         if (soft_host) (void)hipHostFree(soft_host);
         if (h_meta) (void)hipHostFree(h_meta);
+        if (h_samp) (void)hipHostFree(h_samp);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (s_main) (void)hipStreamDestroy(s_main);
@@ -264,6 +271,9 @@ struct rwkv_engine {
     void upload_plan(const StepPlan &pl);
     void run_layers(int T, int n_seq, int n_out, const int *d_token);
     void infer(const rwkv_slot_input *in, rwkv_slot_output *out);
+    void run_plan(const StepPlan &pl);
+    void infer_sample(const rwkv_slot_input *in, const rwkv_sample_params *sp, uint32_t *out_tokens, float *out_probs,
+                      uint8_t *emitted, size_t *n_consumed);
     RowMeta meta_ptrs(int T) const;
     const int *d_seq_slot, *d_seq_begin, *d_seq_len, *d_out_rows;
 };
@@ -506,6 +516,10 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
     soft_in = dalloc<float>(soft_rows_cap * V);
     soft_out = dalloc<float>(soft_rows_cap * V);
     HIP_CHECK(hipHostMalloc((void **)&soft_host, soft_rows_cap * V * 4, hipHostMallocDefault));
+    d_samp = dalloc<SampleRow>(chunk);
+    d_adj_row = dalloc<int>(ADJ_CAP); d_adj_tok = dalloc<int>(ADJ_CAP); d_adj_val = dalloc<float>(ADJ_CAP);
+    d_samp_tok = dalloc<int>(chunk); d_samp_prob = dalloc<float>(chunk);
+    HIP_CHECK(hipHostMalloc((void **)&h_samp, (size_t)chunk * (sizeof(SampleRow) + 8) + ADJ_CAP * 12, hipHostMallocDefault));
     d_amax_v = dalloc<float>((size_t)chunk * 32);
     d_amax_i = dalloc<int>((size_t)chunk * 32);
     HIP_CHECK(hipDeviceSynchronize());
@@ -838,21 +852,8 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token) {
     }
 }
 
-void rwkv_engine::infer(const rwkv_slot_input *in, rwkv_slot_output *out) {
-    HIP_CHECK(hipSetDevice(device));
-    for (int b = 0; b < max_batch; ++b) {
-        out[b].n_rows = 0;
-        out[b].n_consumed = 0;
-        if (in[b].n_tokens && !in[b].tokens) throw RwkvError(RWKV_ERR_INVALID, "slot has n_tokens>0 but tokens==NULL");
-        if (in[b].option != RWKV_OPTION_LAST && in[b].option != RWKV_OPTION_FULL)
-            throw RwkvError(RWKV_ERR_INVALID, "bad RnnOption");
-    }
-    StepPlan pl;
-    plan_step(in, pl);
-    if (pl.T == 0) return;
-    for (int b = 0; b < max_batch; ++b)
-        if (pl.slot_out_rows[b] > 0 && (!out[b].logits || out[b].logits_capacity_rows < (size_t)pl.slot_out_rows[b]))
-            throw RwkvError(RWKV_ERR_INVALID, "logits buffer too small for slot " + std::to_string(b));
+// upload the row metadata and enqueue the step (graph replay when this shape was seen before)
+void rwkv_engine::run_plan(const StepPlan &pl) {
     upload_plan(pl);
     const uint64_t key = ((uint64_t)pl.T << 40) | ((uint64_t)pl.n_seq << 20) | (uint64_t)pl.n_out;
     if (use_graphs && !profiling) {
@@ -881,6 +882,83 @@ void rwkv_engine::infer(const rwkv_slot_input *in, rwkv_slot_output *out) {
     } else {
         run_layers(pl.T, pl.n_seq, pl.n_out, d_meta);
     }
+}
+
+void rwkv_engine::infer_sample(const rwkv_slot_input *in, const rwkv_sample_params *sp, uint32_t *out_tokens, float *out_probs,
+                               uint8_t *emitted, size_t *n_consumed) {
+    HIP_CHECK(hipSetDevice(device));
+    if (info.num_vocab > 65536) throw RwkvError(RWKV_ERR_UNSUPPORTED, "on-device sampling needs num_vocab <= 65536");
+    std::vector<rwkv_slot_input> last(in, in + max_batch);
+    for (int b = 0; b < max_batch; ++b) {
+        last[b].option = RWKV_OPTION_LAST;
+        if (emitted) emitted[b] = 0;
+        if (n_consumed) n_consumed[b] = 0;
+        if (in[b].n_tokens && !in[b].tokens) throw RwkvError(RWKV_ERR_INVALID, "slot has n_tokens>0 but tokens==NULL");
+    }
+    StepPlan pl;
+    plan_step(last.data(), pl);
+    if (pl.T == 0) return;
+    // pack per-row sampler params + sparse adjustments (rows are in out_rows order == ascending slot order)
+    SampleRow *hs = (SampleRow *)h_samp;
+    int *h_row = (int *)(h_samp + (size_t)chunk * sizeof(SampleRow));
+    int *h_tok = h_row + ADJ_CAP;
+    float *h_val = (float *)(h_tok + ADJ_CAP);
+    size_t nadj = 0;
+    for (int b = 0; b < max_batch; ++b) {
+        if (pl.slot_out_rows[b] == 0) continue;
+        const int r = pl.slot_out_begin[b];
+        const rwkv_sample_params &p = sp[b];
+        if (p.top_k > 256) throw RwkvError(RWKV_ERR_UNSUPPORTED, "on-device sampling supports top_k <= 256");
+        if (!(p.temperature > 0.f)) throw RwkvError(RWKV_ERR_INVALID, "temperature must be > 0");
+        if (p.n_adj && (!p.adj_tokens || !p.adj_values)) throw RwkvError(RWKV_ERR_INVALID, "null adjustment arrays");
+        if (nadj + p.n_adj > ADJ_CAP) throw RwkvError(RWKV_ERR_INVALID, "too many logit adjustments");
+        hs[r] = SampleRow{p.top_p, p.top_k, p.temperature, p.uniform};
+        for (size_t i = 0; i < p.n_adj; ++i, ++nadj) { h_row[nadj] = r; h_tok[nadj] = (int)p.adj_tokens[i]; h_val[nadj] = p.adj_values[i]; }
+    }
+    run_plan(pl);
+    if (pl.n_out > 0) {
+        HIP_CHECK(hipMemcpyAsync(d_samp, hs, (size_t)pl.n_out * sizeof(SampleRow), hipMemcpyHostToDevice, s_main));
+        if (nadj) {
+            HIP_CHECK(hipMemcpyAsync(d_adj_row, h_row, nadj * 4, hipMemcpyHostToDevice, s_main));
+            HIP_CHECK(hipMemcpyAsync(d_adj_tok, h_tok, nadj * 4, hipMemcpyHostToDevice, s_main));
+            HIP_CHECK(hipMemcpyAsync(d_adj_val, h_val, nadj * 4, hipMemcpyHostToDevice, s_main));
+            launch_logit_adjust(logits, info.num_vocab, d_adj_row, d_adj_tok, d_adj_val, (int)nadj, s_main);
+        }
+        launch_nucleus(logits, pl.n_out, info.num_vocab, d_samp, d_samp_tok, d_samp_prob, s_main);
+        int *ht = (int *)h_meta;                                   // reuse the pinned meta buffer for the 8 bytes per row
+        float *hp = (float *)(h_meta + chunk);
+        HIP_CHECK(hipMemcpyAsync(ht, d_samp_tok, (size_t)pl.n_out * 4, hipMemcpyDeviceToHost, s_main));
+        HIP_CHECK(hipMemcpyAsync(hp, d_samp_prob, (size_t)pl.n_out * 4, hipMemcpyDeviceToHost, s_main));
+        HIP_CHECK(hipStreamSynchronize(s_main));
+        for (int b = 0; b < max_batch; ++b) {
+            if (pl.slot_out_rows[b] == 0) continue;
+            const int r = pl.slot_out_begin[b];
+            if (out_tokens) out_tokens[b] = (uint32_t)ht[r];
+            if (out_probs) out_probs[b] = hp[r];
+            if (emitted) emitted[b] = 1;
+        }
+    } else {
+        HIP_CHECK(hipStreamSynchronize(s_main));
+    }
+    if (n_consumed) for (int b = 0; b < max_batch; ++b) n_consumed[b] = (size_t)pl.slot_consumed[b];
+}
+
+void rwkv_engine::infer(const rwkv_slot_input *in, rwkv_slot_output *out) {
+    HIP_CHECK(hipSetDevice(device));
+    for (int b = 0; b < max_batch; ++b) {
+        out[b].n_rows = 0;
+        out[b].n_consumed = 0;
+        if (in[b].n_tokens && !in[b].tokens) throw RwkvError(RWKV_ERR_INVALID, "slot has n_tokens>0 but tokens==NULL");
+        if (in[b].option != RWKV_OPTION_LAST && in[b].option != RWKV_OPTION_FULL)
+            throw RwkvError(RWKV_ERR_INVALID, "bad RnnOption");
+    }
+    StepPlan pl;
+    plan_step(in, pl);
+    if (pl.T == 0) return;
+    for (int b = 0; b < max_batch; ++b)
+        if (pl.slot_out_rows[b] > 0 && (!out[b].logits || out[b].logits_capacity_rows < (size_t)pl.slot_out_rows[b]))
+            throw RwkvError(RWKV_ERR_INVALID, "logits buffer too small for slot " + std::to_string(b));
+    run_plan(pl);
     const int V = info.num_vocab;
     if (pl.n_out > 0)
         HIP_CHECK(hipMemcpyAsync(logits_host, logits, (size_t)pl.n_out * V * 4, hipMemcpyDeviceToHost, s_main));
@@ -961,6 +1039,14 @@ rwkv_status rwkv_infer(rwkv_engine *e, const rwkv_slot_input *in, rwkv_slot_outp
     return guard([&] {
         if (!e || !in || !out) throw RwkvError(RWKV_ERR_INVALID, "null argument");
         e->infer(in, out);
+    });
+}
+
+rwkv_status rwkv_infer_sample(rwkv_engine *e, const rwkv_slot_input *in, const rwkv_sample_params *sp, uint32_t *out_tokens,
+                              float *out_probs, uint8_t *emitted, size_t *n_consumed) {
+    return guard([&] {
+        if (!e || !in || !sp || !out_tokens || !emitted) throw RwkvError(RWKV_ERR_INVALID, "null argument");
+        e->infer_sample(in, sp, out_tokens, out_probs, emitted, n_consumed);
     });
 }
 

@@ -1063,6 +1063,146 @@ void launch_argmax(const float *logits, int n_rows, int V, int *out_tok, float *
 }
 
 // =====================================================================================
+// On-device sampling front-end: sparse logit adjustments + softmax + nucleus (top-k / top-p /
+// temperature) sampling with a caller-supplied uniform draw — crates/ai00-core/src/sampler/nucleus.rs:69-101 after
+// run.rs:664-697.  One 1024-thread block per row; the row's probabilities live in registers (V <= 65536).
+// =====================================================================================
+__global__ void logit_adjust_kernel(float *logits, int V, const int *rows, const int *toks, const float *vals, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && toks[i] >= 0 && toks[i] < V) logits[(long)rows[i] * V + toks[i]] += vals[i];   // host merges duplicates
+}
+
+constexpr int NUC_THREADS = 1024, NUC_EPT = 64, NUC_CAND = 1024;
+
+__device__ __forceinline__ float block_reduce_1024(float v, float *red, bool is_max) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const float o = __shfl_xor(v, m, 64); v = is_max ? fmaxf(v, o) : v + o; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int w = 1; w < NUC_THREADS / 64; ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+    return r;
+}
+
+__global__ __launch_bounds__(NUC_THREADS) void nucleus_kernel(const float *logits, int V, const SampleRow *sp, int *out_tok,
+                                                               float *out_prob) {
+    __shared__ float red[16];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel[3];                                    // prefix, remaining k, candidate counter
+    __shared__ unsigned long long cand[NUC_CAND];                  // (prob bits << 32) | ~id  -> sort descending
+    __shared__ float qv[256];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const SampleRow P = sp[row];
+    const float *x = logits + (long)row * V;
+    float p[NUC_EPT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NUC_EPT; ++j) {
+        const int i = j * NUC_THREADS + tid;
+        p[j] = i < V ? x[i] : -INFINITY;
+        m = fmaxf(m, p[j]);
+    }
+    m = block_reduce_1024(m, red, true);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NUC_EPT; ++j) { p[j] = (j * NUC_THREADS + tid) < V ? expf(p[j] - m) : 0.f; s += p[j]; }
+    s = block_reduce_1024(s, red, false);
+#pragma unroll
+    for (int j = 0; j < NUC_EPT; ++j) p[j] = p[j] / s;
+
+    // ---- radix select of the k-th largest probability (positive floats: bit patterns are order-preserving)
+    int k = P.top_k < 1 ? 1 : (P.top_k > 256 ? 256 : P.top_k);
+    if (k > V) k = V;
+    if (tid == 0) { sel[0] = 0u; sel[1] = (unsigned)k; sel[2] = 0u; }
+    unsigned prefix = 0u, mask = 0u;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NUC_EPT; ++j) {
+            const unsigned key = __float_as_uint(p[j]);
+            if ((j * NUC_THREADS + tid) < V && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned need = sel[1], cum = 0u;
+            int b = 255;
+            for (; b > 0; --b) {
+                if (cum + hist[b] >= need) break;
+                cum += hist[b];
+            }
+            sel[0] = prefix | ((unsigned)b << shift);
+            sel[1] = need - cum;
+        }
+        __syncthreads();
+        prefix = sel[0];
+        mask |= 255u << shift;
+    }
+    const unsigned thr = prefix;                                    // bits of the k-th largest probability
+    // ---- gather everything >= thr (ties included; zero-probability ties are skipped), sort, keep k
+    for (int i = tid; i < NUC_CAND; i += NUC_THREADS) cand[i] = 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NUC_EPT; ++j) {
+        const int i = j * NUC_THREADS + tid;
+        const unsigned key = __float_as_uint(p[j]);
+        if (i < V && key >= thr && key != 0u) {
+            const unsigned slot = atomicAdd(&sel[2], 1u);
+            if (slot < NUC_CAND) cand[slot] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+        }
+    }
+    __syncthreads();
+    for (int size = 2; size <= NUC_CAND; size <<= 1) {              // bitonic sort, descending
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int i = tid, j = i ^ stride;
+            if (j > i) {
+                const bool desc = (i & size) == 0;
+                const unsigned long long a = cand[i], b = cand[j];
+                if ((a < b) == desc) { cand[i] = b; cand[j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const int ncand = min((int)min(sel[2], (unsigned)NUC_CAND), k);
+    // ---- nucleus: keep while the cumulative probability BEFORE the element is <= top_p (nucleus.rs:84-91)
+    if (tid == 0) {
+        float cum = 0.f;
+        int n = 0;
+        for (; n < ncand; ++n) {
+            if (cum > P.top_p) break;
+            cum += __uint_as_float((unsigned)(cand[n] >> 32));
+        }
+        sel[0] = (unsigned)(n < 1 ? 1 : n);
+    }
+    __syncthreads();
+    const int n = (int)sel[0];
+    if (tid < n) qv[tid] = powf(__uint_as_float((unsigned)(cand[tid] >> 32)), 1.0f / P.temperature);   // nucleus.rs:92
+    __syncthreads();
+    if (tid == 0) {
+        float sum = 0.f;
+        for (int i = 0; i < n; ++i) sum += qv[i];
+        float c = 0.f;
+        int pick = 0;                                               // find_or_first: nothing found -> first element
+        for (int i = 0; i < n; ++i) {
+            c += qv[i] / sum;
+            if (P.uniform <= c) { pick = i; break; }
+        }
+        const unsigned long long e = cand[pick];
+        out_tok[row] = (int)(0xFFFFFFFFu - (unsigned)(e & 0xFFFFFFFFull));
+        if (out_prob) out_prob[row] = __uint_as_float((unsigned)(e >> 32));
+    }
+}
+
+void launch_logit_adjust(float *logits, int V, const int *rows, const int *toks, const float *vals, int n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(logit_adjust_kernel, dim3((n + 255) / 256), dim3(256), 0, s, logits, V, rows, toks, vals, n);
+}
+void launch_nucleus(const float *logits, int n_rows, int V, const SampleRow *sp, int *out_tok, float *out_prob, hipStream_t s) {
+    hipLaunchKernelGGL(nucleus_kernel, dim3(n_rows), dim3(NUC_THREADS), 0, s, logits, V, sp, out_tok, out_prob);
+}
+
+// =====================================================================================
 // Load-time layout kernels
 // =====================================================================================
 // fp16 tile: out uint4 index ((strip*KT + kt)*64 + lane) <- W[strip*16 + (lane&15)][kt*32 + (lane>>4)*8 .. +8]

@@ -98,6 +98,35 @@ def perplexity(loop: InferLoop, batch: int, tokens, head: float | None = None) -
     return float(-sum(math.log(x) for x in p) / len(toks))
 
 
+class NucleusSampler:
+    """Host-side STATE of `NucleusSampler` (sampler/nucleus.rs:13-122) for the on-device sampling front-end: the
+    penalty map lives here, its effect reaches the device as sparse logit adjustments (`adjustments()`), and the
+    token the device picked is fed back through `update()` (nucleus.rs:104-119)."""
+
+    def __init__(self, top_p=0.5, top_k=128, temperature=1.0, presence_penalty=0.3, frequency_penalty=0.3,
+                 penalty_decay=0.99654026, bias: dict | None = None):
+        self.top_p, self.top_k, self.temperature = float(top_p), int(top_k), float(temperature)
+        self.ap, self.af, self.ad = np.float32(presence_penalty), np.float32(frequency_penalty), np.float32(penalty_decay)
+        self.penalties: dict[int, np.float32] = {}
+        self.bias = dict(bias or {})
+
+    def init(self, model_tokens):                                    # nucleus.rs:49-59
+        for index, token in enumerate(reversed(list(model_tokens))):
+            pen = self.penalties.pop(int(token), self.ap)
+            self.penalties[int(token)] = np.float32(pen + self.af * self.ad ** np.float32(index))
+
+    def adjustments(self) -> dict:                                    # transform (nucleus.rs:61-67) + bias (run.rs:681-683)
+        adj = {t: np.float32(-p) for t, p in self.penalties.items()}
+        for t, b in self.bias.items():
+            adj[t] = np.float32(adj.get(t, np.float32(0)) + np.float32(b))
+        return adj
+
+    def update(self, token: int):                                     # nucleus.rs:104-119
+        for t in self.penalties:
+            self.penalties[t] = np.float32(self.penalties[t] * self.ad)
+        self.penalties[token] = np.float32(self.penalties[token] + self.af) if token in self.penalties else self.ap
+
+
 class ReplicaRouter:
     """Request-level sharding over independent engines (one per GPU): round-robin for batch jobs, least-busy for
     interactive requests.  No collective: each replica owns its weights, slots and stream."""

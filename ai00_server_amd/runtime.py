@@ -52,6 +52,11 @@ class _SlotInC(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class _SampleC(C.Structure):
+    _fields_ = [("top_p", C.c_float), ("top_k", C.c_int32), ("temperature", C.c_float), ("uniform", C.c_float),
+                ("adj_tokens", C.POINTER(C.c_uint32)), ("adj_values", C.POINTER(C.c_float)), ("n_adj", C.c_size_t)]
+
+
 class _SlotOutC(C.Structure):
     _fields_ = [("logits", C.POINTER(C.c_float)), ("logits_capacity_rows", C.c_size_t), ("n_rows", C.c_size_t),
                 ("n_consumed", C.c_size_t)]
@@ -71,6 +76,8 @@ ABI_SYMBOLS = {
     "rwkv_engine_max_batch": (C.c_int32, [C.c_void_p]),
     "rwkv_engine_weight_bytes": (C.c_uint64, [C.c_void_p]),
     "rwkv_infer": (C.c_int32, [C.c_void_p, C.POINTER(_SlotInC), C.POINTER(_SlotOutC)]),
+    "rwkv_infer_sample": (C.c_int32, [C.c_void_p, C.POINTER(_SlotInC), C.POINTER(_SampleC), C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_size_t)]),
     "rwkv_state_len": (C.c_size_t, [C.c_void_p]),
     "rwkv_state_shape": (None, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "rwkv_state_init": (C.c_int32, [C.c_void_p, C.c_void_p]),
@@ -374,6 +381,40 @@ class Runtime:
         _check(lib().rwkv_infer(self._h, self._ins, self._outs))
         del keep
         return self._collect(inp)
+
+    def infer_sample(self, inp: RnnInput, samplers: list, uniforms: list):
+        """On-device sampling front-end (rwkv_infer_sample).  `samplers[b]` is None or an object with `.top_p`,
+        `.top_k`, `.temperature` and `.adjustments() -> {token: delta_logit}` (penalties and bias merged);
+        `uniforms[b]` is the draw `fastrand::f32()` would make.  Returns (inp, [(token, prob) or None per slot])."""
+        if len(inp.batches) != self.max_batch:
+            raise RwkvError(-1, f"RnnInput must have max_batch={self.max_batch} entries")
+        B = self.max_batch
+        ins, sps = (_SlotInC * B)(), (_SampleC * B)()
+        keep = []
+        for b, ib in enumerate(inp.batches):
+            toks = np.asarray(ib.tokens, dtype=np.uint32)
+            keep.append(toks)
+            ins[b] = _SlotInC(toks.ctypes.data_as(C.POINTER(C.c_uint32)) if toks.size else None, toks.size, 0, 0)
+            s = samplers[b]
+            if s is None:
+                sps[b] = _SampleC(0.0, 1, 1.0, 0.0, None, None, 0)
+                continue
+            adj = s.adjustments()
+            at = np.fromiter(adj.keys(), dtype=np.uint32, count=len(adj))
+            av = np.fromiter(adj.values(), dtype=np.float32, count=len(adj))
+            keep += [at, av]
+            sps[b] = _SampleC(s.top_p, s.top_k, s.temperature, uniforms[b],
+                              at.ctypes.data_as(C.POINTER(C.c_uint32)) if at.size else None,
+                              av.ctypes.data_as(C.POINTER(C.c_float)) if av.size else None, at.size)
+        toks_o, probs_o = (C.c_uint32 * B)(), (C.c_float * B)()
+        emitted, consumed = (C.c_uint8 * B)(), (C.c_size_t * B)()
+        _check(lib().rwkv_infer_sample(self._h, ins, sps, toks_o, probs_o, emitted, consumed))
+        del keep
+        out = []
+        for b, ib in enumerate(inp.batches):
+            ib.tokens = list(ib.tokens[consumed[b]:])
+            out.append((int(toks_o[b]), float(probs_o[b])) if emitted[b] else None)
+        return inp, out
 
     def profile_infer(self, inp: RnnInput):
         keep = self._prepare(inp)

@@ -156,6 +156,24 @@ def main():
             _, outs = eng.infer(inp)
         pcie = B * nst / (time.perf_counter() - t)
 
+    # serving path with the on-device sampling front-end (rwkv_infer_sample: nucleus defaults, 8 bytes/slot over PCIe)
+    sampled = None
+    if rank == 0 and V <= 65536:
+        from ai00_server_amd.harness import NucleusSampler
+        smp = [NucleusSampler() for _ in range(eng.max_batch)]
+        rng = np.random.default_rng(0)
+        cur = [int(x) for x in first]
+        nst = max(5, min(30, args.steps))
+        t = time.perf_counter()
+        for _ in range(nst):
+            inp = rt.RnnInput([rt.RnnInputBatch([cur[b]] if b < B else []) for b in range(eng.max_batch)])
+            _, outs = eng.infer_sample(inp, [smp[b] if b < B else None for b in range(eng.max_batch)],
+                                       [float(u) for u in rng.random(eng.max_batch)])
+            for b in range(B):
+                cur[b] = outs[b][0]
+                smp[b].update(cur[b])
+        sampled = B * nst / (time.perf_counter() - t)
+
     # second half of BASELINE's metric: embeddings/s = documents prefilled (256 tokens each, one per slot) and read
     # back as one layer's WKV rows (rwkv_state_back_layer) per second, same engine, rank 0 only
     emb = None
@@ -205,7 +223,7 @@ def main():
                            "quant": args.quant, "batch_per_gpu": B, "precision": args.precision,
                            "parallelism": f"replicas x{world} (no collective)"},
                 "tokens_per_s_per_gpu": value / world, "device_ms_per_step": dev_ms / args.steps,
-                "roofline": roof, "cpu_baseline": cpu, "embeddings": emb, "pcie_inclusive_tokens_per_s": pcie, "sweep": sweep or None,
+                "roofline": roof, "cpu_baseline": cpu, "embeddings": emb, "pcie_inclusive_tokens_per_s": pcie, "on_device_sampling_tokens_per_s": sampled, "sweep": sweep or None,
                 "load_s": t_load, "synth_s": t_synth}
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -136,6 +136,25 @@ rwkv_status rwkv_read_init_state(const rwkv_engine *e, const uint8_t *st_bytes, 
  * concurrently with rwkv_infer from the second caller thread. */
 rwkv_status rwkv_softmax(rwkv_engine *e, const float *const *in, float *const *out, size_t n_rows);
 
+/* ---- on-device sampling front-end: what `sample()` run.rs:664-697 + NucleusSampler::sample
+ * (sampler/nucleus.rs:69-101) do with three PCIe hops and a 65,536-element CPU sort, done on the device.
+ * The caller keeps the sampler STATE (penalty map, nucleus.rs:104-119) and passes its effect as sparse logit
+ * adjustments (-penalty[token] + bias[token], duplicates merged) plus the uniform draw `fastrand::f32()` would make. */
+typedef struct rwkv_sample_params {
+    float top_p;                   /* NucleusParams defaults: 0.5 / 128 / 1.0 (nucleus.rs:13-26); top_k <= 256 */
+    int32_t top_k;
+    float temperature;
+    float uniform;                 /* u in [0,1) */
+    const uint32_t *adj_tokens;    /* may be NULL when n_adj == 0 */
+    const float *adj_values;       /* added to logits[adj_tokens[i]] before the softmax */
+    size_t n_adj;
+} rwkv_sample_params;
+/* Like rwkv_infer with RWKV_OPTION_LAST on every slot, but slots whose pending tokens are exhausted by this call
+ * get a sampled token id (out_tokens[b], emitted[b] = 1, out_probs[b] = its softmax probability) instead of a
+ * logits row; only 8 bytes per slot cross PCIe.  n_consumed[b] as in rwkv_slot_output.  num_vocab <= 65536. */
+rwkv_status rwkv_infer_sample(rwkv_engine *e, const rwkv_slot_input *in, const rwkv_sample_params *sp,
+                              uint32_t *out_tokens, float *out_probs, uint8_t *emitted, size_t *n_consumed);
+
 /* ---- `Tokenizer` lib.rs:375; run.rs:157-168,856; sampler/bnf.rs:14-27 ---------------------- */
 typedef struct rwkv_tokenizer rwkv_tokenizer;
 rwkv_status rwkv_tokenizer_create(const char *vocab_json, size_t len, rwkv_tokenizer **out);

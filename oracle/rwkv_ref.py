@@ -655,3 +655,69 @@ def algorithmic_bytes(info: ModelInfo, tensors_shapes: dict[str, tuple], quant_l
         wq += n * (width[quant_type] if k in qn else 2.0)
     S = info.num_layer * (info.head_size + 2) * info.num_emb * 4
     return {"W_q": wq, "S": S, "per_step": wq + batch * (2 * S + info.num_vocab * 4)}
+
+
+# --------------------------------------------------------------------------------------
+# sampler reference (crates/ai00-core/src/sampler/nucleus.rs) — for the on-device front-end
+# --------------------------------------------------------------------------------------
+def nucleus_ref(probs: np.ndarray, top_p: float, top_k: int, temperature: float, u: float):
+    """`NucleusSampler::sample` (nucleus.rs:69-101) with the random draw `u` made explicit.
+    Sort descending (ties: lower id first), take top_k, keep while the cumulative sum BEFORE the element is <= top_p
+    (the first is always kept), p^(1/T), renormalise, first element with u <= cumulative, else the FIRST element
+    (`find_or_first`).  Returns (token, margin) where margin is the distance of the decisive comparison."""
+    p = probs.astype(np.float32)
+    order = np.lexsort((np.arange(p.size), -p))[:max(1, top_k)]
+    kept, cum = [], np.float32(0.0)
+    for i in order:
+        if cum > np.float32(top_p):
+            break
+        cum = np.float32(cum + p[i])
+        kept.append(i)
+    q = np.array([np.float32(p[i]) ** np.float32(1.0 / temperature) for i in kept], dtype=np.float32)
+    s = np.float32(0.0)
+    for x in q:
+        s = np.float32(s + x)
+    c, margin = np.float32(0.0), 1.0
+    for i, x in zip(kept, q):
+        c = np.float32(c + np.float32(x / s))
+        margin = min(margin, abs(float(c) - u))
+        if np.float32(u) <= c:
+            return int(i), margin
+    return int(kept[0]), margin
+
+
+class NucleusRef:
+    """State machine of `NucleusSampler` (nucleus.rs:13-122): penalties map, init/transform/update."""
+
+    def __init__(self, top_p=0.5, top_k=128, temperature=1.0, presence_penalty=0.3, frequency_penalty=0.3,
+                 penalty_decay=0.99654026):
+        self.top_p, self.top_k, self.temperature = top_p, top_k, temperature
+        self.ap, self.af, self.ad = presence_penalty, frequency_penalty, penalty_decay
+        self.penalties: dict[int, float] = {}
+
+    def init(self, model_tokens):                                    # nucleus.rs:49-59
+        for index, token in enumerate(reversed(list(model_tokens))):
+            pen = self.penalties.pop(int(token), np.float32(self.ap))
+            self.penalties[int(token)] = np.float32(pen + np.float32(self.af) * np.float32(self.ad) ** np.float32(index))
+
+    def transform(self, logits: np.ndarray) -> np.ndarray:            # nucleus.rs:61-67
+        out = logits.astype(np.float32).copy()
+        for t, pen in self.penalties.items():
+            out[t] -= np.float32(pen)
+        return out
+
+    def update(self, token: int):                                     # nucleus.rs:104-119
+        for t in self.penalties:
+            self.penalties[t] = np.float32(self.penalties[t] * np.float32(self.ad))
+        if token in self.penalties:
+            self.penalties[token] = np.float32(self.penalties[token] + np.float32(self.af))
+        else:
+            self.penalties[token] = np.float32(self.ap)
+
+    def sample(self, logits: np.ndarray, bias: dict | None, u: float) -> int:   # run.rs:664-697 + nucleus.rs:69-122
+        x = self.transform(logits)
+        for t, b in (bias or {}).items():
+            x[t] += np.float32(b)
+        tok, _ = nucleus_ref(softmax_ref(x[None])[0], self.top_p, self.top_k, self.temperature, u)
+        self.update(tok)
+        return tok

@@ -358,3 +358,72 @@ def test_full_v6_3b_greedy_ids_match_oracle():
     c = run_prompts(e8, [p])[0][0]
     assert np.abs(a - c).max() <= 1e-3 * max(1.0, float(np.abs(a).max()))
     e8.close()
+
+
+def test_on_device_nucleus_sampling_matches_reference_sampler():
+    """rwkv_infer_sample (penalties/bias -> softmax -> top-k -> top-p -> temperature -> inverse CDF on the device)
+    against the restatement of sampler/nucleus.rs on the SAME logits: every step the state is snapshotted, the host
+    path produces the logits the oracle sampler sees, the snapshot is restored and the device samples."""
+    from ai00_server_amd.harness import NucleusSampler
+    t, eng = build("v6-small", rt.Precision.Fp16, B=3, chunk=16)
+    ref = R.RwkvRef(t)
+    rng = np.random.default_rng(77)
+    cfgs = [dict(top_p=0.5, top_k=128, temperature=1.0), dict(top_p=0.9, top_k=40, temperature=0.7),
+            dict(top_p=0.3, top_k=256, temperature=1.5, presence_penalty=0.6, frequency_penalty=0.1)]
+    dev = [NucleusSampler(bias={5: 1.5, 9: -2.0}, **c) for c in cfgs]
+    orc = [R.NucleusRef(**c) for c in cfgs]
+    prompts = [prompt(ref, 70 + b, 6 + b) for b in range(3)]
+    for b in range(3):
+        dev[b].init(prompts[b][-3:])
+        orc[b].init(prompts[b][-3:])
+    pending = [list(p) for p in prompts]
+    checked = skipped = 0
+    for step in range(24):
+        snaps = [eng.state.read(b) for b in range(3)]
+        inp = rt.RnnInput([rt.RnnInputBatch(list(pending[b]), rt.RnnOption.Last) for b in range(3)])
+        rows = [None] * 3
+        while inp.num_token() > 0:
+            inp, outs = eng.infer(inp)
+            for b, o in enumerate(outs):
+                if len(o):
+                    rows[b] = o[-1]
+        us = [float(rng.random()) for _ in range(3)]
+        want, margin = [], []
+        for b in range(3):
+            x = orc[b].transform(rows[b])
+            for tk, bv in {5: 1.5, 9: -2.0}.items():
+                x[tk] += np.float32(bv)
+            tok, mg = R.nucleus_ref(R.softmax_ref(x[None])[0], orc[b].top_p, orc[b].top_k, orc[b].temperature, us[b])
+            want.append(tok)
+            margin.append(mg)
+        for b in range(3):
+            eng.state.write(snaps[b], b)
+        inp = rt.RnnInput([rt.RnnInputBatch(list(pending[b]), rt.RnnOption.Last) for b in range(3)])
+        got = [None] * 3
+        while inp.num_token() > 0:
+            inp, outs = eng.infer_sample(inp, dev, us)
+            for b, o in enumerate(outs):
+                if o is not None:
+                    got[b] = o
+        for b in range(3):
+            if margin[b] > 1e-4:                                   # away from a CDF boundary: ids must agree
+                assert got[b][0] == want[b], (step, b, got[b], want[b], margin[b])
+                checked += 1
+            else:
+                skipped += 1
+            tok = want[b]                                          # follow the reference trajectory
+            dev[b].update(tok)
+            orc[b].update(tok)
+            pending[b] = [tok]
+            assert 0.0 < got[b][1] <= 1.0
+    assert checked >= 60 and skipped <= 6
+    # greedy corner: top_k = 1 always returns the arg-max regardless of the draw
+    g = NucleusSampler(top_p=0.0, top_k=1, presence_penalty=0.0, frequency_penalty=0.0)
+    inp = rt.RnnInput([rt.RnnInputBatch([3, 4, 5]), rt.RnnInputBatch(), rt.RnnInputBatch()])
+    snap = eng.state.read(0)
+    _, outs = eng.infer(inp)
+    eng.state.write(snap, 0)
+    inp = rt.RnnInput([rt.RnnInputBatch([3, 4, 5]), rt.RnnInputBatch(), rt.RnnInputBatch()])
+    _, sm = eng.infer_sample(inp, [g, None, None], [0.99, 0.0, 0.0])
+    assert sm[0][0] == int(np.argmax(outs[0][-1])) and sm[1] is None
+    eng.close()

@@ -143,3 +143,24 @@ def test_algorithmic_bytes_match_survey_table():
     info = R.ModelInfo(6, 32, 2560, 8960, 65536, 40)
     ab = R.algorithmic_bytes(info, shapes, 32, R.QUANT_INT8, 32)
     assert abs(ab["W_q"] - 3.224e9) / 3.224e9 < 0.01 and ab["S"] == 21626880
+
+
+def test_nucleus_reference_semantics():
+    """Restatement of sampler/nucleus.rs: first element always kept, top_p compared BEFORE adding, find_or_first."""
+    p = np.array([0.5, 0.3, 0.1, 0.06, 0.04], np.float32)
+    assert R.nucleus_ref(p, 0.0, 128, 1.0, 0.99)[0] == 0                 # top_p = 0 keeps exactly the first element
+    assert R.nucleus_ref(p, 0.5, 128, 1.0, 0.99)[0] == 1                 # cum(before 2nd) = 0.5 <= 0.5 -> 2 kept
+    assert R.nucleus_ref(p, 0.5, 128, 1.0, 0.50)[0] == 0                 # u <= 0.5/0.8
+    assert R.nucleus_ref(p, 1.0, 2, 1.0, 0.99)[0] == 1                   # top_k cut
+    assert R.nucleus_ref(p, 1.0, 128, 1.0, 1.5)[0] == 0                  # nothing found -> FIRST (find_or_first)
+    hot = R.nucleus_ref(p, 1.0, 128, 0.1, 0.93)[0]                       # low temperature sharpens
+    assert hot == 0
+    s = R.NucleusRef()
+    s.init([7, 8, 7])
+    assert abs(s.penalties[7] - (0.3 + 0.3 + 0.3 * 0.99654026 ** 2)) < 1e-6 and abs(s.penalties[8] - (0.3 + 0.3 * 0.99654026)) < 1e-6
+    lg = np.zeros(16, np.float32)
+    assert s.transform(lg)[7] == -s.penalties[7]
+    s.update(8)
+    assert abs(s.penalties[8] - ((0.3 + 0.3 * 0.99654026) * 0.99654026 + 0.3)) < 1e-6
+    s.update(3)
+    assert abs(s.penalties[3] - 0.3) < 1e-7
