@@ -23,11 +23,24 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+STAMP = os.path.join(HERE, ".build_stamp")
+
+
+def _sources_digest() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(DEPS):
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(d.encode())
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB) or not os.path.exists(HARNESS_BIN):
+    """Content-based (mtimes do not survive the copy to a GPU box): rebuild when a source differs from the stamp."""
+    if not os.path.exists(LIB) or not os.path.exists(HARNESS_BIN) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    return open(STAMP).read().strip() != _sources_digest()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -50,6 +63,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     build_harness(verbose)
+    with open(STAMP, "w") as f:
+        f.write(_sources_digest())
     return LIB
 
 

@@ -650,29 +650,36 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam) {
 // ------------------------------------------------------------------------------------------------
 // step planning (RnnInput::new(batches, token_chunk_size), run.rs:1132) — which tokens ride this call
 // ------------------------------------------------------------------------------------------------
-void rwkv_engine::plan_step(const rwkv_slot_input *in, StepPlan &pl) {
-    const int B = max_batch;
-    pl.slot_consumed.assign(B, 0);
-    pl.slot_out_begin.assign(B, 0);
-    pl.slot_out_rows.assign(B, 0);
-    // water-filling of the chunk budget across slots with pending tokens: short (decode) requests are
-    // never starved by a long prefill (any split is result-equivalent: slots are independent)
-    long budget = chunk;
+// water-filling of the chunk budget across slots with pending tokens: short (decode) requests are never starved by
+// a long prefill (any split is result-equivalent: slots are independent, RNN chunking is exact)
+static void water_fill(long budget, const std::vector<size_t> &pending, std::vector<int> &take_out) {
+    const int B = (int)pending.size();
+    take_out.assign(B, 0);
     std::vector<int> act;
-    for (int b = 0; b < B; ++b) if (in[b].n_tokens > 0) act.push_back(b);
+    for (int b = 0; b < B; ++b) if (pending[b] > 0) act.push_back(b);
     while (budget > 0 && !act.empty()) {
         const long share = std::max<long>(1, budget / (long)act.size());
         std::vector<int> next;
         for (int b : act) {
             if (budget <= 0) break;
-            const long want = (long)in[b].n_tokens - pl.slot_consumed[b];
+            const long want = (long)pending[b] - take_out[b];
             const long take = std::min({want, share, budget});
-            pl.slot_consumed[b] += (int)take;
+            take_out[b] += (int)take;
             budget -= take;
-            if (pl.slot_consumed[b] < (long)in[b].n_tokens) next.push_back(b);
+            if (take_out[b] < (long)pending[b]) next.push_back(b);
         }
         act.swap(next);
     }
+}
+
+void rwkv_engine::plan_step(const rwkv_slot_input *in, StepPlan &pl) {
+    const int B = max_batch;
+    pl.slot_consumed.assign(B, 0);
+    pl.slot_out_begin.assign(B, 0);
+    pl.slot_out_rows.assign(B, 0);
+    std::vector<size_t> pending(B);
+    for (int b = 0; b < B; ++b) pending[b] = in[b].n_tokens;
+    water_fill(chunk, pending, pl.slot_consumed);
     pl.token.clear(); pl.slot.clear(); pl.prev.clear(); pl.last.clear();
     pl.seq_slot.clear(); pl.seq_begin.clear(); pl.seq_len.clear(); pl.out_rows.clear();
     for (int b = 0; b < B; ++b) {
@@ -1047,6 +1054,16 @@ rwkv_status rwkv_infer_sample(rwkv_engine *e, const rwkv_slot_input *in, const r
     return guard([&] {
         if (!e || !in || !sp || !out_tokens || !emitted) throw RwkvError(RWKV_ERR_INVALID, "null argument");
         e->infer_sample(in, sp, out_tokens, out_probs, emitted, n_consumed);
+    });
+}
+
+rwkv_status rwkv_plan_chunk(int32_t max_batch, int32_t token_chunk_size, const size_t *n_tokens, int32_t *consumed) {
+    return guard([&] {
+        if (max_batch <= 0 || token_chunk_size <= 0 || !n_tokens || !consumed) throw RwkvError(RWKV_ERR_INVALID, "bad arguments");
+        std::vector<size_t> pending(n_tokens, n_tokens + max_batch);
+        std::vector<int> take;
+        water_fill(token_chunk_size, pending, take);
+        for (int b = 0; b < max_batch; ++b) consumed[b] = take[b];
     });
 }
 

@@ -78,6 +78,7 @@ ABI_SYMBOLS = {
     "rwkv_infer": (C.c_int32, [C.c_void_p, C.POINTER(_SlotInC), C.POINTER(_SlotOutC)]),
     "rwkv_infer_sample": (C.c_int32, [C.c_void_p, C.POINTER(_SlotInC), C.POINTER(_SampleC), C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_size_t)]),
+    "rwkv_plan_chunk": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]),
     "rwkv_state_len": (C.c_size_t, [C.c_void_p]),
     "rwkv_state_shape": (None, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "rwkv_state_init": (C.c_int32, [C.c_void_p, C.c_void_p]),
@@ -184,6 +185,15 @@ class Loader:
         out = _ModelInfoC()
         _check(lib().rwkv_model_info_from_st(p, n, C.byref(out)))
         return _info_from_c(out)
+
+
+def plan_chunk(n_tokens: list[int], token_chunk_size: int) -> list[int]:
+    """Tokens of each slot that one `infer` call consumes (host-only mirror of the engine's chunk policy)."""
+    n = len(n_tokens)
+    a = (C.c_size_t * n)(*n_tokens)
+    out = (C.c_int32 * n)()
+    _check(lib().rwkv_plan_chunk(n, token_chunk_size, a, out))
+    return list(out)
 
 
 def list_adapters() -> list[str]:

@@ -115,6 +115,12 @@ typedef struct rwkv_slot_output {  /* RnnOutputBatch, run.rs:1146-1155 */
  * consumed.  State of each touched slot is updated in place on the device. */
 rwkv_status rwkv_infer(rwkv_engine *e, const rwkv_slot_input *in, rwkv_slot_output *out);
 
+/* The chunk policy of rwkv_infer as a pure host function (no device needed): how many of each slot's pending tokens one
+ * call consumes — water-filling of `token_chunk_size`, so decode slots are never starved by a long prefill
+ * (web-rwkv's own split inside `RnnInput::new(batches, chunk)` run.rs:1132 is not visible; any split is
+ * result-equivalent). */
+rwkv_status rwkv_plan_chunk(int32_t max_batch, int32_t token_chunk_size, const size_t *n_tokens, int32_t *consumed);
+
 /* ---- `State` trait: run.rs:477,950 (init) 1099 (load) 1101 (back) 1104 (write) 1106 (read) -- */
 size_t rwkv_state_len(const rwkv_engine *e);                       /* floats in one slab      */
 void rwkv_state_shape(const rwkv_engine *e, size_t shape[4]);      /* [C, N+2, L, 1] run.rs:987 */

@@ -104,3 +104,26 @@ def test_cpp_mirror_builds_and_reports_errors(built_lib, tmp_path):
         assert r.returncode == 1 and "no HIP device" in r.stderr
     else:
         assert r.returncode == 0
+
+
+def test_chunk_policy_water_filling(built_lib):
+    """Host logic of rwkv_infer's chunk split: budget respected, decode slots never starved, everything consumed."""
+    assert rt.plan_chunk([1, 1, 1, 0], 128) == [1, 1, 1, 0]
+    assert rt.plan_chunk([4096, 1, 1, 0], 128) == [126, 1, 1, 0]              # long prefill cannot starve decode slots
+    assert rt.plan_chunk([300, 300], 128) == [64, 64]
+    assert rt.plan_chunk([10, 500, 3], 128) == [10, 115, 3]
+    assert sum(rt.plan_chunk([50] * 8, 32)) == 32 and max(rt.plan_chunk([50] * 8, 32)) == 4
+    got = rt.plan_chunk([1] * 40, 16)                                        # more slots than budget: first come first
+    assert sum(got) == 16 and set(got) == {0, 1}
+    assert rt.plan_chunk([0, 0], 8) == [0, 0]
+    with pytest.raises(rt.RwkvError):
+        rt.plan_chunk([1], 0)
+    # repeated calls drain any workload in a bounded number of steps
+    pending = [1000, 7, 0, 64, 1]
+    calls = 0
+    while sum(pending):
+        take = rt.plan_chunk(pending, 128)
+        assert 0 < sum(take) <= 128 and all(t <= p for t, p in zip(take, pending))
+        pending = [p - t for p, t in zip(pending, take)]
+        calls += 1
+    assert calls == -(-1072 // 128)
