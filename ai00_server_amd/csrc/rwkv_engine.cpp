@@ -177,7 +177,7 @@ struct rwkv_engine {
     // row meta (device + pinned host)
     int *d_meta = nullptr, *h_meta = nullptr;
     size_t meta_cap = 0;
-    int *d_tok_feedback = nullptr, *d_hist = nullptr, *d_counter = nullptr, *d_amax_i = nullptr;
+    int *d_tok_feedback = nullptr, *d_hist = nullptr, *d_amax_i = nullptr;
     // sampling front-end: per-row params, sparse adjustments (row, token, value), outputs; pinned host mirror
     SampleRow *d_samp = nullptr;
     int *d_adj_row = nullptr, *d_adj_tok = nullptr, *d_samp_tok = nullptr;
@@ -511,7 +511,6 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
     d_meta = dalloc<int>(meta_cap);
     HIP_CHECK(hipHostMalloc((void **)&h_meta, meta_cap * 4, hipHostMallocDefault));
     d_tok_feedback = dalloc<int>(chunk);
-    d_counter = dalloc<int>(4);
     soft_rows_cap = (size_t)std::max(1, max_batch);
     soft_in = dalloc<float>(soft_rows_cap * V);
     soft_out = dalloc<float>(soft_rows_cap * V);

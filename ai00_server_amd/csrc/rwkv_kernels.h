@@ -168,7 +168,6 @@ void launch_softmax(const float *in, float *out, int n_rows, int V, hipStream_t 
 struct SampleRow { float top_p; int top_k; float temperature; float uniform; };
 void launch_logit_adjust(float *logits, int V, const int *rows, const int *toks, const float *vals, int n, hipStream_t s);
 void launch_nucleus(const float *logits, int n_rows, int V, const SampleRow *sp, int *out_tok, float *out_prob, hipStream_t s);
-void launch_empty(hipStream_t s);                        // measurement calibration (event-pair overhead)
 // two-stage arg-max; scratch_v / scratch_i hold n_rows*32 partial (value, index) pairs
 void launch_argmax(const float *logits, int n_rows, int V, int *out_tok, float *scratch_v, int *scratch_i, hipStream_t s);
 

@@ -1007,9 +1007,6 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float *in, float *ou
     const float inv = 1.0f / s;
     for (int i = threadIdx.x; i < V; i += 256) y[i] = expf(x[i] - m) * inv;
 }
-__global__ void empty_kernel() {}
-void launch_empty(hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s); }
-
 void launch_softmax(const float *in, float *out, int n_rows, int V, hipStream_t s) {
     hipLaunchKernelGGL(softmax_kernel, dim3(n_rows), dim3(256), 0, s, in, out, V);
 }

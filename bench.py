@@ -146,7 +146,7 @@ def main():
 
     # PCIe-inclusive rate through rwkv_infer (logits D2H every token, as run.rs:809-832 does) — never `value`
     pcie = None
-    if rank == 0:
+    if rank == 0 and world == 1:
         nst = max(5, min(30, args.steps))
         inp_tok = [int(x) for x in first]
         t = time.perf_counter()
@@ -158,7 +158,7 @@ def main():
 
     # serving path with the on-device sampling front-end (rwkv_infer_sample: nucleus defaults, 8 bytes/slot over PCIe)
     sampled = None
-    if rank == 0 and V <= 65536:
+    if rank == 0 and world == 1 and V <= 65536:
         from ai00_server_amd.harness import NucleusSampler
         smp = [NucleusSampler() for _ in range(eng.max_batch)]
         rng = np.random.default_rng(0)
@@ -177,7 +177,7 @@ def main():
     # second half of BASELINE's metric: embeddings/s = documents prefilled (256 tokens each, one per slot) and read
     # back as one layer's WKV rows (rwkv_state_back_layer) per second, same engine, rank 0 only
     emb = None
-    if rank == 0:
+    if rank == 0 and world == 1:
         doc_len, layer = 256, info.num_layer - 1
         docs = [[t % V for t in R.synth_prompt(100 + b, doc_len)] for b in range(B)]
         zero = eng.state.init()
