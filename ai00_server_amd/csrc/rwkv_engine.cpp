@@ -764,21 +764,32 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token) {
             a.mode = 1; a.nmix = 1; a.mu[0] = w.mu[0]; a.ohi[0] = opA[0].hi; a.olo[0] = opA[0].lo;
             a.xx_out = xx; a.dx_out = dx;
             launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
-            {   // m = tanh(W1 z)  ->  operand [T][5*Dm]
-                ProbSpec s = prob(w.W1, opA[0], ACT_TANH, nullptr, 0);
-                s.oh = opM;
-                ps = {s};
+            static const int no_fuse = env_int("RWKV_NO_V6_FUSE");
+            if (v6_mix_supported(T, C, Dm) && !no_fuse) {
+                // fused: x_c = xx + dx * (mu_c + W2_c tanh(W1_c z)) in one launch
+                V6MixArgs m{};
+                m.W1 = w.W1->data;
+                for (int c = 0; c < 5; ++c) { m.W2[c] = w.W2[c]->data; m.mu[c] = w.mu[1 + c]; m.ohi[c] = opA[1 + c].hi; m.olo[c] = opA[1 + c].lo; }
+                m.zhi = opA[0].hi; m.zlo = opA[0].lo; m.ldz = C;
+                m.xx = xx; m.dx = dx; m.ldh = C; m.T = T; m.C = C; m.Dm = Dm;
+                launch(FAM_GEMM, [&] { launch_v6_mix(m, hilo, s_main); });
+            } else {
+                {   // m = tanh(W1 z)  ->  operand [T][5*Dm]
+                    ProbSpec s = prob(w.W1, opA[0], ACT_TANH, nullptr, 0);
+                    s.oh = opM;
+                    ps = {s};
+                    gemm(ps, T, FAM_GEMM);
+                }
+                ps.clear();
+                for (int c = 0; c < 5; ++c) {   // x_c = xx + dx * (mu_c + W2_c m_c),  c in (w,k,v,r,g)
+                    ProbSpec s = prob(w.W2[c], opM, ACT_NONE, nullptr, 0);
+                    s.xoff = c * Dm;
+                    s.bias = w.mu[1 + c]; s.post = POST_MIX; s.m0 = xx; s.m1 = dx; s.ldm = C;
+                    s.oh = opA[1 + c];
+                    ps.push_back(s);
+                }
                 gemm(ps, T, FAM_GEMM);
             }
-            ps.clear();
-            for (int c = 0; c < 5; ++c) {   // x_c = xx + dx * (mu_c + W2_c m_c),  c in (w,k,v,r,g)
-                ProbSpec s = prob(w.W2[c], opM, ACT_NONE, nullptr, 0);
-                s.xoff = c * Dm;
-                s.bias = w.mu[1 + c]; s.post = POST_MIX; s.m0 = xx; s.m1 = dx; s.ldm = C;
-                s.oh = opA[1 + c];
-                ps.push_back(s);
-            }
-            gemm(ps, T, FAM_GEMM);
             ps = {prob(w.Wk, opA[2], ACT_NONE, fk, C), prob(w.Wv, opA[3], ACT_NONE, fv, C),
                   prob(w.Wr, opA[4], ACT_NONE, fr, C), prob(w.Wg, opA[5], ACT_SILU, fg, C),
                   prob(w.D1, opA[1], ACT_TANH, ftd, Dd)};

@@ -74,6 +74,20 @@ constexpr int GEMM_TILE_SHAPES = 6;                      // 256x128, 128x128, 64
 int gemm_tile_blocks(int shape, int rows, int T);
 void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s);                             // rounds of 256 k a wave can hold at once (single-shot)
 
+// V6 fused time-mix LoRA (tanh(W1 z) -> W2 -> lerp), decode-shaped steps only
+struct V6MixArgs {
+    const void *W1;                 // tiled fp16 [5*Dm x C]
+    const void *W2[5];              // tiled fp16 [C x Dm] each, order (w,k,v,r,g)
+    const _Float16 *zhi, *zlo;      // operand z = xx + dx*mu_x  [T][ldz]
+    int ldz;
+    const float *xx, *dx;           // fp32 [T][C]
+    const float *mu[5];
+    _Float16 *ohi[5], *olo[5];      // outputs: the five GEMM operands [T][ldh]
+    int ldh, T, C, Dm;
+};
+bool v6_mix_supported(int T, int C, int Dm);
+void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s);
+
 struct RowMeta {                    // device arrays, one entry per row of this step
     const int *token;               // token id
     const int *slot;                // state slot

@@ -393,6 +393,141 @@ void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
 
 int gemm_max_rounds(int fmt) { return fmt == W_F16 ? 2 : 4; }
 
+__device__ __forceinline__ void store_operand4(_Float16 *__restrict__ hi, _Float16 *__restrict__ lo, long off, float4 o);
+
+// =====================================================================================
+// V6 data-dependent token-shift, fused (decode, T <= 32):  x_c = xx + dx * (mu_c + W2_c * tanh(W1_c * z)),
+// c in (w,k,v,r,g) — SURVEY A.4.  One launch instead of two dependent GEMMs: a block owns one mix c and 8 strips
+// of W2_c; its 8 waves first split K to compute the block's OWN copy of m_c = tanh(W1_c z) ([T][Dm], W1_c is
+// Dm x C fp16 = 164 KiB from L2, recomputed by the C/128 blocks of that c), park the partials in LDS, reduce,
+// apply tanh and keep m_c in LDS as the f16 (hi, lo) operand; then wave w multiplies strip w of W2_c (K = Dm)
+// with it and applies the lerp epilogue, emitting the five GEMM operands.
+// =====================================================================================
+template <int NT, bool HILO>
+__global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = blockIdx.y;                                     // mix index
+    const int sg = blockIdx.x;                                    // strip group (8 strips of W2_c)
+    const int C = a.C, Dm = a.Dm, T = a.T;
+    const int DS = Dm >> 4;                                       // strips of W1_c (2 or 4)
+    const int KT1 = C >> 5;                                       // k-tiles of W1 per strip
+    const int kst = KT1 >> 3;                                     // k-steps per wave in phase 1 (C/8/32)
+    f32x4 *red = (f32x4 *)smem;                                   // [8 waves][DS][NT][64]
+    const int mstride = Dm + 8;                                   // halfs per token row of m_c
+    _Float16 *m_hi = (_Float16 *)(smem + (size_t)8 * 4 * NT * 64 * 16);
+    _Float16 *m_lo = m_hi + NT * 16 * mstride;
+
+    // ---- phase 1: partial m_c over this wave's K slice
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[d][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const u32x4 *w1 = (const u32x4 *)a.W1;
+    constexpr int KB = 5;                                          // k-steps per batch: all loads of a batch in flight at once
+    for (int k0 = 0; k0 < kst; k0 += KB) {
+        f16x8 zb[KB][NT], zl[HILO ? KB : 1][HILO ? NT : 1];
+        u32x4 wt[KB][4];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            if (k0 + j < kst) {                                    // wave-uniform
+                const int kt = wave * kst + k0 + j;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    int row = nt * 16 + (lane & 15);
+                    row = row < T ? row : T - 1;
+                    zb[j][nt] = *(const f16x8 *)(a.zhi + (long)row * a.ldz + kt * 32 + (lane >> 4) * 8);
+                    if constexpr (HILO) zl[j][nt] = *(const f16x8 *)(a.zlo + (long)row * a.ldz + kt * 32 + (lane >> 4) * 8);
+                }
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    if (d < DS) wt[j][d] = w1[((long)(c * DS + d) * KT1 + kt) * 64 + lane];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            if (k0 + j < kst) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (d < DS) {
+                        const f16x8 af = __builtin_bit_cast(f16x8, wt[j][d]);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[d][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, zb[j][nt], acc[d][nt], 0, 0, 0);
+                            if constexpr (HILO) acc[d][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, zl[j][nt], acc[d][nt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            if (d < DS) red[((wave * 4 + d) * NT + nt) * 64 + lane] = acc[d][nt];
+    __syncthreads();
+    // reduce the 8 K-partials, tanh, park m_c[t][d] as f16 hi/lo
+    for (int item = wave; item < DS * NT; item += 8) {
+        const int d = item / NT, nt = item - d * NT;
+        f32x4 v = red[((0 * 4 + d) * NT + nt) * 64 + lane];
+        for (int w2 = 1; w2 < 8; ++w2) v += red[((w2 * 4 + d) * NT + nt) * 64 + lane];
+        const int t = nt * 16 + (lane & 15);
+        f16x4 hh, ll;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { _Float16 x, y; split_hilo(tanhf(v[r]), x, y); hh[r] = x; ll[r] = y; }
+        *(f16x4 *)(m_hi + t * mstride + d * 16 + (lane >> 4) * 4) = hh;
+        if constexpr (HILO) *(f16x4 *)(m_lo + t * mstride + d * 16 + (lane >> 4) * 4) = ll;
+    }
+    __syncthreads();
+    // ---- phase 2: strip (sg*8 + wave) of W2_c times m_c, lerp epilogue
+    const int strip = sg * 8 + wave;
+    if (strip < (C >> 4)) {
+        const int KT2 = Dm >> 5;
+        const u32x4 *w2p = (const u32x4 *)a.W2[c];
+        f32x4 o[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < KT2; ++ks) {
+            const f16x8 af = __builtin_bit_cast(f16x8, w2p[((long)strip * KT2 + ks) * 64 + lane]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int off = (nt * 16 + (lane & 15)) * mstride + ks * 32 + (lane >> 4) * 8;
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, *(const f16x8 *)(m_hi + off), o[nt], 0, 0, 0);
+                if constexpr (HILO) o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, *(const f16x8 *)(m_lo + off), o[nt], 0, 0, 0);
+            }
+        }
+        const int row0 = strip * 16 + (lane >> 4) * 4;
+        const float4 mu = *(const float4 *)(a.mu[c] + row0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int t = nt * 16 + (lane & 15);
+            if (t < T) {
+                const float4 xx = *(const float4 *)(a.xx + (long)t * C + row0);
+                const float4 dx = *(const float4 *)(a.dx + (long)t * C + row0);
+                float4 r;
+                r.x = xx.x + dx.x * (mu.x + o[nt][0]);
+                r.y = xx.y + dx.y * (mu.y + o[nt][1]);
+                r.z = xx.z + dx.z * (mu.z + o[nt][2]);
+                r.w = xx.w + dx.w * (mu.w + o[nt][3]);
+                store_operand4(a.ohi[c], a.olo[c], (long)t * a.ldh + row0, r);
+            }
+        }
+    }
+}
+
+bool v6_mix_supported(int T, int C, int Dm) { return T <= 32 && C % 256 == 0 && (Dm == 32 || Dm == 64); }
+
+void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
+    const int NT = a.T <= 16 ? 1 : 2;
+    const size_t lds = (size_t)8 * 4 * NT * 64 * 16 + (size_t)2 * NT * 16 * (a.Dm + 8) * 2;
+    dim3 grid((a.C / 16 + 7) / 8, 5), block(512);
+    if (hilo) { if (NT == 1) hipLaunchKernelGGL((v6_mix_kernel<1, true>), grid, block, lds, s, a); else hipLaunchKernelGGL((v6_mix_kernel<2, true>), grid, block, lds, s, a); }
+    else { if (NT == 1) hipLaunchKernelGGL((v6_mix_kernel<1, false>), grid, block, lds, s, a); else hipLaunchKernelGGL((v6_mix_kernel<2, false>), grid, block, lds, s, a); }
+}
+
 // =====================================================================================
 // Prefill GEMM (T >= 64): LDS-tiled MFMA GEMM over the same pre-tiled weights.
 // Block = 8 waves; wave w owns strips {2w, 2w+1} of the block's 16 strips (256 output rows) and all 8 n-tiles of
