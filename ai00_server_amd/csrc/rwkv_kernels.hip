@@ -403,7 +403,7 @@ __device__ __forceinline__ void store_operand4(_Float16 *__restrict__ hi, _Float
 // apply tanh and keep m_c in LDS as the f16 (hi, lo) operand; then wave w multiplies strip w of W2_c (K = Dm)
 // with it and applies the lerp epilogue, emitting the five GEMM operands.
 // =====================================================================================
-template <int NT, bool HILO>
+template <int NT, bool HILO, int DS>
 __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     const int c = blockIdx.y;                                     // mix index
     const int sg = blockIdx.x;                                    // strip group (8 strips of W2_c)
     const int C = a.C, Dm = a.Dm, T = a.T;
-    const int DS = Dm >> 4;                                       // strips of W1_c (2 or 4)
+    // DS = Dm/16 strips of W1_c (2 or 4)
     const int KT1 = C >> 5;                                       // k-tiles of W1 per strip
     const int kst = KT1 >> 3;                                     // k-steps per wave in phase 1 (C/8/32)
     f32x4 *red = (f32x4 *)smem;                                   // [8 waves][DS][NT][64]
@@ -420,16 +420,16 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     _Float16 *m_lo = m_hi + NT * 16 * mstride;
 
     // ---- phase 1: partial m_c over this wave's K slice
-    f32x4 acc[4][NT];
+    f32x4 acc[DS][NT];
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < DS; ++d)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[d][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const u32x4 *w1 = (const u32x4 *)a.W1;
-    constexpr int KB = 5;                                          // k-steps per batch: all loads of a batch in flight at once
+    constexpr int KB = DS == 2 ? 10 : 4;                                          // k-steps per batch: all loads of a batch in flight at once
     for (int k0 = 0; k0 < kst; k0 += KB) {
         f16x8 zb[KB][NT], zl[HILO ? KB : 1][HILO ? NT : 1];
-        u32x4 wt[KB][4];
+        u32x4 wt[KB][DS];
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             if (k0 + j < kst) {                                    // wave-uniform
@@ -442,32 +442,28 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
                     if constexpr (HILO) zl[j][nt] = *(const f16x8 *)(a.zlo + (long)row * a.ldz + kt * 32 + (lane >> 4) * 8);
                 }
 #pragma unroll
-                for (int d = 0; d < 4; ++d)
-                    if (d < DS) wt[j][d] = w1[((long)(c * DS + d) * KT1 + kt) * 64 + lane];
+                for (int d = 0; d < DS; ++d) wt[j][d] = w1[((long)(c * DS + d) * KT1 + kt) * 64 + lane];
             }
         }
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             if (k0 + j < kst) {
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    if (d < DS) {
-                        const f16x8 af = __builtin_bit_cast(f16x8, wt[j][d]);
+                for (int d = 0; d < DS; ++d) {
+                    const f16x8 af = __builtin_bit_cast(f16x8, wt[j][d]);
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            acc[d][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, zb[j][nt], acc[d][nt], 0, 0, 0);
-                            if constexpr (HILO) acc[d][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, zl[j][nt], acc[d][nt], 0, 0, 0);
-                        }
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[d][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, zb[j][nt], acc[d][nt], 0, 0, 0);
+                        if constexpr (HILO) acc[d][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, zl[j][nt], acc[d][nt], 0, 0, 0);
                     }
                 }
             }
         }
     }
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < DS; ++d)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            if (d < DS) red[((wave * 4 + d) * NT + nt) * 64 + lane] = acc[d][nt];
+        for (int nt = 0; nt < NT; ++nt) red[((wave * 4 + d) * NT + nt) * 64 + lane] = acc[d][nt];
     __syncthreads();
     // reduce the 8 K-partials, tanh, park m_c[t][d] as f16 hi/lo
     for (int item = wave; item < DS * NT; item += 8) {
@@ -524,8 +520,11 @@ void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
     const int NT = a.T <= 16 ? 1 : 2;
     const size_t lds = (size_t)8 * 4 * NT * 64 * 16 + (size_t)2 * NT * 16 * (a.Dm + 8) * 2;
     dim3 grid((a.C / 16 + 7) / 8, 5), block(512);
-    if (hilo) { if (NT == 1) hipLaunchKernelGGL((v6_mix_kernel<1, true>), grid, block, lds, s, a); else hipLaunchKernelGGL((v6_mix_kernel<2, true>), grid, block, lds, s, a); }
-    else { if (NT == 1) hipLaunchKernelGGL((v6_mix_kernel<1, false>), grid, block, lds, s, a); else hipLaunchKernelGGL((v6_mix_kernel<2, false>), grid, block, lds, s, a); }
+#define V6L(nt, h, ds) hipLaunchKernelGGL((v6_mix_kernel<nt, h, ds>), grid, block, lds, s, a)
+    const int DS = a.Dm >> 4;
+    if (hilo) { if (NT == 1) { if (DS == 2) V6L(1, true, 2); else V6L(1, true, 4); } else { if (DS == 2) V6L(2, true, 2); else V6L(2, true, 4); } }
+    else      { if (NT == 1) { if (DS == 2) V6L(1, false, 2); else V6L(1, false, 4); } else { if (DS == 2) V6L(2, false, 2); else V6L(2, false, 4); } }
+#undef V6L
 }
 
 // =====================================================================================
