@@ -92,7 +92,7 @@ static rwkv_model_info detect_info(const SafeTensors &st) {
 // ------------------------------------------------------------------------------------------------
 // engine
 // ------------------------------------------------------------------------------------------------
-struct Opd {                        // f16 hi/lo activation operand [Tmax][ld]
+struct Opd {                        // f16 hi/lo activation operand, B-tiled (rwkv_kernels.hip opd_off): ceil16(Tmax) x ld
     _Float16 *hi = nullptr, *lo = nullptr;
     int ld = 0;
 };
@@ -100,7 +100,7 @@ struct Opd {                        // f16 hi/lo activation operand [Tmax][ld]
 struct ProbSpec {
     const DMat *W = nullptr;
     Opd x;
-    int xoff = 0;                   // column offset into x
+    int xoff = 0;                   // column offset into x (multiple of 32)
     int act = ACT_NONE, post = POST_NONE;
     const float *bias = nullptr, *m0 = nullptr, *m1 = nullptr;
     int ldm = 0;
@@ -207,9 +207,13 @@ struct rwkv_engine {
     }
     Opd alloc_opd(int ld) {
         Opd o;
+        ld = (ld + 31) / 32 * 32;                                      // whole k-tiles
         o.ld = ld;
-        o.hi = dalloc<_Float16>((size_t)chunk * ld);
-        o.lo = hilo ? dalloc<_Float16>((size_t)chunk * ld) : nullptr;
+        const size_t cap = (size_t)((chunk + 15) / 16 * 16) * ld;      // whole (16 token x 32 k) tiles
+        o.hi = dalloc<_Float16>(cap);
+        o.lo = hilo ? dalloc<_Float16>(cap) : nullptr;
+        HIP_CHECK(hipMemset(o.hi, 0, cap * 2));                        // lanes of a partly filled token tile are read (never used)
+        if (o.lo) HIP_CHECK(hipMemset(o.lo, 0, cap * 2));
         return o;
     }
     ~rwkv_engine() {
@@ -585,7 +589,7 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
         if (force_spb) spb = force_spb; else if (f_spb) spb = f_spb;
         spb = std::min(spb, std::max(1, 150 / (nw * NT)));                     // LDS: spb*nw*NT KiB <= 150 KiB
         g.W = s.W->data; g.S = s.W->scales; g.fmt = s.W->fmt; g.rows = s.W->rows; g.K = K;
-        g.xhi = s.x.hi + s.xoff; g.xlo = s.x.lo ? s.x.lo + s.xoff : nullptr; g.ldx = s.x.ld;
+        g.xhi = s.x.hi + (s.xoff >> 5) * 512; g.xlo = s.x.lo ? s.x.lo + (s.xoff >> 5) * 512 : nullptr; g.ldx = s.x.ld;   // column offset = whole k-tiles
         g.spb = spb; g.nw = nw; g.ksb = ksb;
         g.nblk_strip = (strips + spb - 1) / spb;
         g.block_begin = blocks;
@@ -629,7 +633,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam) {
             const ProbSpec &s = ps[i];
             GemmProb &g = Lh.p[i];
             g.W = s.W->data; g.S = s.W->scales; g.fmt = s.W->fmt; g.rows = s.W->rows; g.K = s.W->K;
-            g.xhi = s.x.hi + s.xoff; g.xlo = s.x.lo ? s.x.lo + s.xoff : nullptr; g.ldx = s.x.ld;
+            g.xhi = s.x.hi + (s.xoff >> 5) * 512; g.xlo = s.x.lo ? s.x.lo + (s.xoff >> 5) * 512 : nullptr; g.ldx = s.x.ld;   // column offset = whole k-tiles
             g.spb = 16; g.nw = 8; g.ksb = 1; g.nblk_strip = 0;
             g.block_begin = blocks;
             blocks += gemm_tile_blocks(shape, s.W->rows, T);
@@ -1317,8 +1321,9 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
             mats[i].fmt = fmt; mats[i].rows = rows; mats[i].K = K;
         }
         Opd x; x.ld = K;
-        x.hi = (_Float16 *)dal((size_t)T * K * 2); x.lo = (_Float16 *)dal((size_t)T * K * 2);
-        HIP_CHECK(hipMemset(x.hi, 0, (size_t)T * K * 2)); HIP_CHECK(hipMemset(x.lo, 0, (size_t)T * K * 2));
+        const size_t xcap = (size_t)((T + 15) / 16 * 16) * x.ld * 2;
+        x.hi = (_Float16 *)dal(xcap); x.lo = (_Float16 *)dal(xcap);
+        HIP_CHECK(hipMemset(x.hi, 0, xcap)); HIP_CHECK(hipMemset(x.lo, 0, xcap));
         float *out = (float *)dal((size_t)T * rows * 4);
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));

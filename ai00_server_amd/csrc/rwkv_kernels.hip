@@ -45,6 +45,15 @@ __device__ __forceinline__ void split_hilo(float v, _Float16 &hi, _Float16 &lo) 
     lo = (_Float16)(c - (float)hi);
 }
 
+// Activation operands (the f16 hi/lo X of every GEMM) live in HBM in MFMA B-FRAGMENT order, not row-major:
+// 1 KiB tiles of (16 tokens x 32 k); inside a tile lane l = ((k>>3)&3)*16 + (t&15) owns 8 consecutive k (16 B), i.e.
+// exactly the register image of `v_mfma_f32_16x16x32_f16`'s B operand.  A wave's fragment load is then ONE contiguous
+// 1 KiB read (8 full cache lines) instead of 16 scattered 64 B segments — measured 2.5-3 us per GEMM at T = 32
+// (scripts/trace_gemm.py).  `ld` (k per token row) is a multiple of 32; token capacity is a multiple of 16.
+__device__ __forceinline__ long opd_off(int t, int k, int ld) {
+    return ((long)(t >> 4) * (ld >> 5) + (k >> 5)) * 512 + ((((k >> 3) & 3) << 4) + (t & 15)) * 8 + (k & 7);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -75,6 +84,26 @@ template <int FMT> struct Fmt;
 template <> struct Fmt<W_F16> { static constexpr int TK = 32, KS = 1, SH = 5; };
 template <> struct Fmt<W_INT8> { static constexpr int TK = 64, KS = 2, SH = 6; };
 template <> struct Fmt<W_NF4> { static constexpr int TK = 128, KS = 4, SH = 7; };
+
+#ifdef RWKV_TRACE      // dev-only timeline probes (scripts/trace_gemm.py); never defined in the product build
+__device__ unsigned long long g_trace[4096 * 8];
+#define TRACE_PT(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) g_trace[((blockIdx.x * 16 + (threadIdx.x >> 6)) << 3) + (i)] = wall_clock64(); } while (0)
+extern "C" int rwkv_debug_trace(unsigned long long *out, int n) {
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+    static unsigned long long zeros[4096 * 8];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice);
+    return rc;
+}
+__device__ unsigned long long g_trace2[4 * 2048 * 8];   // [kernel id][linear block][probe], wave 0 only
+#define TRACE_K(kid, i) do { const unsigned lb_ = blockIdx.x + gridDim.x * blockIdx.y; if (threadIdx.x == 0 && lb_ < 2048) g_trace2[(((kid) * 2048 + lb_) << 3) + (i)] = wall_clock64(); } while (0)
+extern "C" int rwkv_debug_trace2(unsigned long long *out) {
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace2), sizeof(g_trace2), 0, hipMemcpyDeviceToHost);
+    return rc;
+}
+#else
+#define TRACE_PT(i) do { } while (0)
+#define TRACE_K(kid, i) do { } while (0)
+#endif
 
 constexpr int RS = 8;                                   // k-steps (of 32) per register round = 256 k
 template <int FMT> struct WRound {                      // one strip's tiles for 256 k of this wave's K slice
@@ -219,21 +248,25 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
         }
     };
 
+    TRACE_PT(0);
     for (int t0 = 0; t0 < L.T; t0 += NT * 16) {
         for (int sl = wave; sl < nslice && wave < nw; sl += nw) {
             const int k0 = kbeg + sl * KW;
             // rounds of this slice that lie inside the K range (the last slice may be short)
             const int nsub = TAIL ? SUB : min(SUB, (kend - k0) / RK);
             const int nround = nstrip * nsub;
-            WRound<FMT> cur, nxt;
-            // X slice of this wave -> B fragments (lane: token = lane&15, k = ks*32 + (lane>>4)*8 .. +8)
+            TRACE_PT(6);
+            // X slice of this wave -> B fragments: one contiguous 1 KiB tile per (n-tile, k-step), see opd_off
             f16x8 xb[NT][KSW], xl[HILO ? NT : 1][HILO ? KSW : 1];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                int row = t0 + nt * 16 + (lane & 15);
-                row = row < L.T ? row : L.T - 1;
-                const _Float16 *ph = P.xhi + (long)row * P.ldx + k0 + (lane >> 4) * 8;
-                const _Float16 *pl = HILO ? P.xlo + (long)row * P.ldx + k0 + (lane >> 4) * 8 : nullptr;
+                // token tile of this n-tile (clamped: results of tiles / lanes beyond T are never stored); lanes beyond the
+                // step's last token re-read its 16 B so a T = 1 step still moves 64 B per k-step, not 1 KiB
+                const int tile = min((t0 >> 4) + nt, (L.T - 1) >> 4);
+                const int tl = min(lane & 15, L.T - 1 - tile * 16);
+                const long xo = ((long)tile * (P.ldx >> 5) + (k0 >> 5)) * 512 + ((lane >> 4) * 16 + tl) * 8;
+                const _Float16 *ph = P.xhi + xo;
+                const _Float16 *pl = HILO ? P.xlo + xo : nullptr;
 #pragma unroll
                 for (int sub = 0; sub < SUB; ++sub) {
                     if (TAIL || sub < nsub) {                      // one uniform branch per 256-k round
@@ -241,8 +274,8 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                         for (int k8 = 0; k8 < RS; ++k8) {
                             const int ks = sub * RS + k8;
                             const bool in = !TAIL || (k0 + ks * 32 < kend);
-                            xb[nt][ks] = in ? *(const f16x8 *)(ph + ks * 32) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                            if constexpr (HILO) xl[nt][ks] = in ? *(const f16x8 *)(pl + ks * 32) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                            xb[nt][ks] = in ? *(const f16x8 *)(ph + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                            if constexpr (HILO) xl[nt][ks] = in ? *(const f16x8 *)(pl + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                         }
                     } else {
 #pragma unroll
@@ -253,9 +286,28 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                     }
                 }
             }
-            // weights after X: the X fragments are L2 hits and complete first, so (in-order vmcnt) the MFMAs of round r
-            // only wait for rounds <= r while later rounds are still streaming in from HBM
-            load_round<FMT, TAIL>(cur, P, strip0, k0, kend, true, lane);
+            // X first, weights after: the X fragments are L2 hits and complete first, so (in-order vmcnt) the MFMAs of round
+            // r only wait for rounds <= r while later rounds are still streaming in from HBM.  (Weights-first was measured
+            // and is slower: issuing is throttled by the CU's memory pipeline either way, and X then lands last.)
+            constexpr int MAXR = FMT == W_F16 ? 2 : 4;            // rounds a wave holds in registers at once (gemm_max_rounds)
+            WRound<FMT> cur, nxt, w[SHOT ? MAXR : 1];
+            if constexpr (SHOT) {
+                // single shot: every weight tile of this wave is in flight before the first MFMA (host: spb * SUB <= MAXR)
+#pragma unroll
+                for (int r = 0; r < MAXR; ++r) {
+                    const int s = r / SUB, sub = r % SUB;
+                    if (s < nstrip && sub < nsub) load_round<FMT, TAIL>(w[r], P, strip0 + s, k0 + sub * RK, kend, true, lane);
+                }
+            } else {
+                load_round<FMT, TAIL>(cur, P, strip0, k0, kend, true, lane);
+            }
+#ifdef RWKV_TRACE
+            TRACE_PT(1);
+#if RWKV_TRACE >= 2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TRACE_PT(5);
+#endif
+#endif
             f32x4 acc[NT], acc2[NT];
             auto park = [&](int s) {                               // partial sums of strip s -> LDS slot of this wave
                 f32x4 *slot = red + ((s * nw + wave) * NT) * 64 + lane;
@@ -266,16 +318,6 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                 }
             };
             if constexpr (SHOT) {
-                // ---- single shot: every weight tile of this wave is in flight before the first MFMA.
-                // (host guarantees spb * SUB <= MAXR)
-                constexpr int MAXR = FMT == W_F16 ? 2 : 4;        // rounds a wave holds in registers at once (gemm_max_rounds)
-                WRound<FMT> w[MAXR];
-                w[0] = cur;
-#pragma unroll
-                for (int r = 1; r < MAXR; ++r) {
-                    const int s = r / SUB, sub = r % SUB;
-                    if (s < nstrip && sub < nsub) load_round<FMT, TAIL>(w[r], P, strip0 + s, k0 + sub * RK, kend, true, lane);
-                }
 #pragma unroll
                 for (int r = 0; r < MAXR; ++r) {
                     const int s = r / SUB, sub = r % SUB;          // compile-time after unrolling
@@ -309,7 +351,9 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
             }
             (void)nround;
         }
+        TRACE_PT(2);
         __syncthreads();
+        TRACE_PT(3);
         // ---- reduce + epilogue: (strip, n-tile) items round-robin over the block's waves
         const int nwaves = blockDim.x >> 6;
         for (int item = wave; item < nstrip * NT; item += nwaves) {
@@ -338,13 +382,15 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                     f16x4 h, l;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { _Float16 a, b; split_hilo(v[r], a, b); h[r] = a; l[r] = b; }
-                    *(f16x4 *)(P.out_hi + (long)t * P.ldh + row0) = h;
-                    if (P.out_lo) *(f16x4 *)(P.out_lo + (long)t * P.ldh + row0) = l;
+                    const long oo = opd_off(t, row0, P.ldh);
+                    *(f16x4 *)(P.out_hi + oo) = h;
+                    if (P.out_lo) *(f16x4 *)(P.out_lo + oo) = l;
                 }
             }
         }
         if (t0 + NT * 16 < L.T) __syncthreads();
     }
+    TRACE_PT(4);
 }
 
 template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL>
@@ -419,6 +465,24 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     _Float16 *m_hi = (_Float16 *)(smem + (size_t)8 * 4 * NT * 64 * 16);
     _Float16 *m_lo = m_hi + NT * 16 * mstride;
 
+    TRACE_K(0, 0);
+    // phase-2 operands of this wave (W2 strip, mu, xx, dx): independent of phase 1, so fetched first — their L2/MALL
+    // latency hides behind phase 1 instead of following its barrier
+    const int strip = sg * 8 + wave;                              // >= C/16: idle in phase 2
+    const int strip_c = min(strip, (C >> 4) - 1);
+    const int row0 = strip_c * 16 + (lane >> 4) * 4;
+    u32x4 w2t[DS / 2];
+    float4 xxv[NT], dxv[NT];
+#pragma unroll
+    for (int ks = 0; ks < DS / 2; ++ks) w2t[ks] = ((const u32x4 *)a.W2[c])[((long)strip_c * (DS / 2) + ks) * 64 + lane];
+    const float4 mu = *(const float4 *)(a.mu[c] + row0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        int t = nt * 16 + (lane & 15);
+        t = t < T ? t : T - 1;
+        xxv[nt] = *(const float4 *)(a.xx + (long)t * C + row0);
+        dxv[nt] = *(const float4 *)(a.dx + (long)t * C + row0);
+    }
     // ---- phase 1: partial m_c over this wave's K slice
     f32x4 acc[DS][NT];
 #pragma unroll
@@ -436,10 +500,11 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
                 const int kt = wave * kst + k0 + j;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    int row = nt * 16 + (lane & 15);
-                    row = row < T ? row : T - 1;
-                    zb[j][nt] = *(const f16x8 *)(a.zhi + (long)row * a.ldz + kt * 32 + (lane >> 4) * 8);
-                    if constexpr (HILO) zl[j][nt] = *(const f16x8 *)(a.zlo + (long)row * a.ldz + kt * 32 + (lane >> 4) * 8);
+                    const int tile = min(nt, (T - 1) >> 4);
+                    const int tl = min(lane & 15, T - 1 - tile * 16);
+                    const long zo = ((long)tile * (a.ldz >> 5) + kt) * 512 + ((lane >> 4) * 16 + tl) * 8;
+                    zb[j][nt] = *(const f16x8 *)(a.zhi + zo);
+                    if constexpr (HILO) zl[j][nt] = *(const f16x8 *)(a.zlo + zo);
                 }
 #pragma unroll
                 for (int d = 0; d < DS; ++d) wt[j][d] = w1[((long)(c * DS + d) * KT1 + kt) * 64 + lane];
@@ -464,7 +529,9 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     for (int d = 0; d < DS; ++d)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) red[((wave * 4 + d) * NT + nt) * 64 + lane] = acc[d][nt];
+    TRACE_K(0, 1);
     __syncthreads();
+    TRACE_K(0, 2);
     // reduce the 8 K-partials, tanh, park m_c[t][d] as f16 hi/lo
     for (int item = wave; item < DS * NT; item += 8) {
         const int d = item / NT, nt = item - d * NT;
@@ -478,16 +545,15 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
         if constexpr (HILO) *(f16x4 *)(m_lo + t * mstride + d * 16 + (lane >> 4) * 4) = ll;
     }
     __syncthreads();
-    // ---- phase 2: strip (sg*8 + wave) of W2_c times m_c, lerp epilogue
-    const int strip = sg * 8 + wave;
+    TRACE_K(0, 3);
+    // ---- phase 2: strip (sg*8 + wave) of W2_c times m_c, lerp epilogue (operands prefetched before phase 1)
     if (strip < (C >> 4)) {
-        const int KT2 = Dm >> 5;
-        const u32x4 *w2p = (const u32x4 *)a.W2[c];
         f32x4 o[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < KT2; ++ks) {
-            const f16x8 af = __builtin_bit_cast(f16x8, w2p[((long)strip * KT2 + ks) * 64 + lane]);
+#pragma unroll
+        for (int ks = 0; ks < DS / 2; ++ks) {
+            const f16x8 af = __builtin_bit_cast(f16x8, w2t[ks]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int off = (nt * 16 + (lane & 15)) * mstride + ks * 32 + (lane >> 4) * 8;
@@ -495,23 +561,21 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
                 if constexpr (HILO) o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, *(const f16x8 *)(m_lo + off), o[nt], 0, 0, 0);
             }
         }
-        const int row0 = strip * 16 + (lane >> 4) * 4;
-        const float4 mu = *(const float4 *)(a.mu[c] + row0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int t = nt * 16 + (lane & 15);
             if (t < T) {
-                const float4 xx = *(const float4 *)(a.xx + (long)t * C + row0);
-                const float4 dx = *(const float4 *)(a.dx + (long)t * C + row0);
+                const float4 xx = xxv[nt], dx = dxv[nt];
                 float4 r;
                 r.x = xx.x + dx.x * (mu.x + o[nt][0]);
                 r.y = xx.y + dx.y * (mu.y + o[nt][1]);
                 r.z = xx.z + dx.z * (mu.z + o[nt][2]);
                 r.w = xx.w + dx.w * (mu.w + o[nt][3]);
-                store_operand4(a.ohi[c], a.olo[c], (long)t * a.ldh + row0, r);
+                store_operand4(a.ohi[c], a.olo[c], opd_off(t, row0, a.ldh), r);
             }
         }
     }
+    TRACE_K(0, 4);
 }
 
 bool v6_mix_supported(int T, int C, int Dm) { return T <= 32 && C % 256 == 0 && (Dm == 32 || Dm == 64); }
@@ -603,7 +667,7 @@ __device__ __forceinline__ f16x8 tg_frag(const TRound<FMT, SPW, KC> &w, int h, i
 // Tile shape: WAVES waves x SPW strips per wave (rows = WAVES*SPW*16) x NTL n-tiles (tokens = NTL*16)
 template <bool HILO, int WAVES, int SPW, int NTL, int KC, int FMT>
 __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
-    constexpr int BT = NTL * 16, THREADS = WAVES * 64, STRIPS = WAVES * SPW, TG_KC = KC, TG_STRIDE = KC + 8, PPR = KC / 8;
+    constexpr int BT = NTL * 16, THREADS = WAVES * 64, STRIPS = WAVES * SPW, TG_KC = KC, TG_STRIDE = KC + 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lb = (int)blockIdx.x - P.block_begin;
@@ -612,7 +676,6 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
     const int nstrips = P.rows >> 4;
     const int strip = rb * STRIPS + wave * SPW;
     const int t0 = tt * BT;
-    const int rows_valid = min(BT, L.T - t0);
     const int K = P.K;
     const int nchunk = (K + TG_KC - 1) / TG_KC;
     constexpr int PART = BT * TG_STRIDE;                          // halfs per (buffer, hi|lo)
@@ -627,20 +690,26 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) acc[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // X staging registers (one chunk ahead of the LDS buffer being multiplied).  Rows beyond the step are clamped
-    // to its last row (never stored); FULL chunks carry no predicates at all.
+    // X staging registers (one chunk ahead of the LDS buffer being multiplied).  The operand is B-tiled in HBM
+    // (opd_off): piece p of a chunk = (tile p/64, lane p%64), so a wave reads one contiguous 1 KiB tile per step and
+    // scatters it into the row-major LDS image (row stride KC+8 halfs: conflict-free).  Token tiles beyond the step
+    // are clamped to its last tile (their results are never stored); FULL chunks carry no predicates at all.
     struct XRegs { uint4 h[XP], l[HILO ? XP : 1]; };
+    constexpr int KTC = TG_KC / 32;                               // k-tiles per chunk
+    const int last_tile = (L.T - 1) >> 4;
     auto stage_load = [&](XRegs &x, int c, auto full) {
         constexpr bool FULL = decltype(full)::value;
         const int k0 = c * TG_KC;
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int p = tid + i * THREADS;
-            const int r = min(p / PPR, rows_valid - 1), c8 = p % PPR;  // PPR 16-byte pieces per row of the chunk
-            const int k = k0 + c8 * 8;
+            const int tile = p >> 6, j = p & 63;
+            const int ttile = min((t0 >> 4) + tile / KTC, last_tile), kt = tile % KTC;
+            const int k = k0 + kt * 32;
             if (FULL || k < K) {
-                x.h[i] = *(const uint4 *)(P.xhi + (long)(t0 + r) * P.ldx + k);
-                if constexpr (HILO) x.l[i] = *(const uint4 *)(P.xlo + (long)(t0 + r) * P.ldx + k);
+                const long xo = ((long)ttile * (P.ldx >> 5) + (k >> 5)) * 512 + j * 8;
+                x.h[i] = *(const uint4 *)(P.xhi + xo);
+                if constexpr (HILO) x.l[i] = *(const uint4 *)(P.xlo + xo);
             } else {
                 x.h[i] = make_uint4(0, 0, 0, 0);
                 if constexpr (HILO) x.l[i] = make_uint4(0, 0, 0, 0);
@@ -652,7 +721,8 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int p = tid + i * THREADS;
-            const int r = p / PPR, c8 = p % PPR;
+            const int tile = p >> 6, j = p & 63;
+            const int r = (tile / KTC) * 16 + (j & 15), c8 = (tile % KTC) * 4 + (j >> 4);
             *(uint4 *)(bh + r * TG_STRIDE + c8 * 8) = x.h[i];
             if constexpr (HILO) *(uint4 *)(bh + PART + r * TG_STRIDE + c8 * 8) = x.l[i];
         }
@@ -745,8 +815,9 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
                         f16x4 hh, ll;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { _Float16 a, b; split_hilo(v[r], a, b); hh[r] = a; ll[r] = b; }
-                        *(f16x4 *)(P.out_hi + (long)t * P.ldh + row0) = hh;
-                        if (P.out_lo) *(f16x4 *)(P.out_lo + (long)t * P.ldh + row0) = ll;
+                        const long oo = opd_off(t, row0, P.ldh);
+                        *(f16x4 *)(P.out_hi + oo) = hh;
+                        if (P.out_lo) *(f16x4 *)(P.out_lo + oo) = ll;
                     }
                 }
             }
@@ -857,14 +928,17 @@ template <int PT>
 __global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
     __shared__ float red[4];
     const int t = blockIdx.x, C = a.C;
+    TRACE_K(2, 0);
     const int slot = a.rm.slot[t], prev = a.rm.prev[t], last = a.rm.last[t];
     float *__restrict__ sx = a.sx + (long)slot * a.sx_slot_stride;
     float4 xv[PT], pv[PT];
     row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, t, C, xv);
+    TRACE_K(2, 1);
     if (prev >= 0) row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, prev, C, pv);
     else { ROW_FOR(i, c) pv[i] = ld4(sx + c); }
     if (a.x_out) { ROW_FOR(i, c) *(float4 *)(a.x_out + (long)t * C + c) = xv[i]; }
     row_layernorm<PT>(xv, C, a.lnw, a.lnb, red);
+    TRACE_K(2, 2);
     if (prev >= 0) row_layernorm<PT>(pv, C, a.lnw, a.lnb, red);
     if (last >= 0) {            // this block owns the slot's token-shift state write (after its own read above)
         if (last == t) {
@@ -901,10 +975,11 @@ __global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
                     o.z = xv[i].z + dxv[i].z * muv[i].z;
                     o.w = xv[i].w + dxv[i].w * muv[i].w;
                 }
-                store_operand4(oh, ol, (long)t * a.ldh + c, o);
+                store_operand4(oh, ol, opd_off(t, c, a.ldh), o);
             }
         }
     }
+    TRACE_K(2, 3);
 }
 #define ROW_DISPATCH(KERN, C_, GRID, ...)                                                          \
     do {                                                                                           \
@@ -940,7 +1015,7 @@ __global__ __launch_bounds__(256) void ln_out_kernel(const LnOutArgs a) {
     float4 v[PT];
     row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, t, C, v);
     row_layernorm<PT>(v, C, a.lnw, a.lnb, red);
-    ROW_FOR(i, c) store_operand4(a.ohi, a.olo, (long)o * a.ldh + c, v[i]);
+    ROW_FOR(i, c) store_operand4(a.ohi, a.olo, opd_off(o, c, a.ldh), v[i]);
 }
 void launch_ln_out(const LnOutArgs &a, int n_out, hipStream_t s) { ROW_DISPATCH(ln_out_kernel, a.C, n_out, a); }
 
@@ -966,6 +1041,7 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {   // <= 
     __shared__ float sh_out[64];
     const int seq = blockIdx.x, h = blockIdx.y;
     const int tid = threadIdx.x, ig = tid >> 4, jg = tid & 15;
+    TRACE_K(1, 0);
     const int slot = a.seq_slot[seq], row0 = a.seq_begin[seq], nrow = a.seq_len[seq];
     const int C = a.C, cb = h * 64;
     float *st = a.state + (long)slot * a.slot_stride + (long)h * 4096;
@@ -1012,7 +1088,9 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {   // <= 
             dsum += __shfl_xor(dsum, 1, 64);
             dsum += __shfl_xor(dsum, 2, 64);
         }
+        TRACE_K(1, 1);
         __syncthreads();                                   // previous iteration's LDS readers done
+        TRACE_K(1, 2);
         if (tid < 64) {
             if (a.version == 7) {
                 float kk = k * kk_p;
@@ -1068,6 +1146,7 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {   // <= 
 #pragma unroll
             for (int aa = 0; aa < 4; ++aa) sh_out[aa * 16 + ig] = outp[aa];
         }
+        TRACE_K(1, 3);
         __syncthreads();
         if (tid < 64) {                                    // wave 0: GroupNorm over the head + gate
             const float o = sh_out[tid];
@@ -1082,12 +1161,15 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {   // <= 
             y *= gt;
             _Float16 hh, ll;
             split_hilo(y, hh, ll);
-            a.yhi[(long)t * a.ldh + cb + tid] = hh;
-            if (a.ylo) a.ylo[(long)t * a.ldh + cb + tid] = ll;
+            const long yo = opd_off(t, cb + tid, a.ldh);
+            a.yhi[yo] = hh;
+            if (a.ylo) a.ylo[yo] = ll;
         }
     }
+    TRACE_K(1, 4);
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa) *(float4 *)(st + (aa * 16 + ig) * 64 + jg * 4) = T[aa];
+    TRACE_K(1, 5);
 }
 void launch_wkv(const WkvArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(wkv_kernel, dim3(a.n_seq, a.H), dim3(256), 0, s, a);

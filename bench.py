@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--quant", default="int8", choices=["none", "int8", "nf4"])
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode-only", action="store_true", help="skip the embeddings / PCIe / sampling / CPU legs (profiling)")
     ap.add_argument("--sweep", default="", help="extra batch sizes reported under 'sweep', e.g. 1,8")
     args = ap.parse_args()
 
@@ -146,7 +147,7 @@ def main():
 
     # PCIe-inclusive rate through rwkv_infer (logits D2H every token, as run.rs:809-832 does) — never `value`
     pcie = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.decode_only:
         nst = max(5, min(30, args.steps))
         inp_tok = [int(x) for x in first]
         t = time.perf_counter()
@@ -158,7 +159,7 @@ def main():
 
     # serving path with the on-device sampling front-end (rwkv_infer_sample: nucleus defaults, 8 bytes/slot over PCIe)
     sampled = None
-    if rank == 0 and world == 1 and V <= 65536:
+    if rank == 0 and world == 1 and V <= 65536 and not args.decode_only:
         from ai00_server_amd.harness import NucleusSampler
         smp = [NucleusSampler() for _ in range(eng.max_batch)]
         rng = np.random.default_rng(0)
@@ -177,7 +178,7 @@ def main():
     # second half of BASELINE's metric: embeddings/s = documents prefilled (256 tokens each, one per slot) and read
     # back as one layer's WKV rows (rwkv_state_back_layer) per second, same engine, rank 0 only
     emb = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.decode_only:
         doc_len, layer = 256, info.num_layer - 1
         docs = [[t % V for t in R.synth_prompt(100 + b, doc_len)] for b in range(B)]
         zero = eng.state.init()
@@ -198,7 +199,7 @@ def main():
                "embedding": f"layer {layer} WKV rows [64 x {info.num_emb}] via rwkv_state_back_layer"}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.decode_only:
         # the oracle ("port") on the host cores, B=1, bounded sample (fp32 weights, no quantisation on the CPU side)
         t0 = time.time()
         ref = R.RwkvRef(tensors)
