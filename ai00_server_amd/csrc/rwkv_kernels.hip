@@ -890,20 +890,28 @@ __device__ __forceinline__ void row_load_sum(const float *__restrict__ x_in, con
         if (j < np) { ROW_FOR(i, c) v[i] = v[i] + pp[j][i]; }
     }
 }
-// two-pass LayerNorm (mean, then centred variance), eps 1e-5 — same order as the oracle's _ln
+// block-wide sum without the leading barrier: `buf` (4 floats of LDS) must not have been read since the last barrier
+// by anything still in flight — callers alternate two buffers.
+__device__ __forceinline__ float block_sum256_nb(float v, float *buf) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return buf[0] + buf[1] + buf[2] + buf[3];
+}
+// two-pass LayerNorm (mean, then centred variance), eps 1e-5 — same order as the oracle's _ln.
+// `red` = 8 floats of LDS (mean uses [0..3], variance [4..7]); wv/bv = the row's weight and bias, loaded by the caller
+// together with everything else the kernel needs so that no load waits behind a reduction.
 template <int PT>
-__device__ __forceinline__ void row_layernorm(float4 (&v)[PT], int C, const float *__restrict__ w, const float *__restrict__ b, float *red) {
-    float4 wv[PT], bv[PT];
-    ROW_FOR(i, c) { wv[i] = ld4(w + c); bv[i] = ld4(b + c); }
+__device__ __forceinline__ void row_layernorm(float4 (&v)[PT], int C, const float4 (&wv)[PT], const float4 (&bv)[PT], float *red) {
     float s = 0.f;
     ROW_FOR(i, c) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    const float mean = block_sum256(s, red) / (float)C;
+    const float mean = block_sum256_nb(s, red) / (float)C;
     float q = 0.f;
     ROW_FOR(i, c) {
         const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
         q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
     }
-    const float var = block_sum256(q, red) / (float)C;
+    const float var = block_sum256_nb(q, red + 4) / (float)C;
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     ROW_FOR(i, c) {
         v[i].x = (v[i].x - mean) * rstd * wv[i].x + bv[i].x;
@@ -926,27 +934,33 @@ __device__ __forceinline__ void store_operand4(_Float16 *__restrict__ hi, _Float
 
 template <int PT>
 __global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
-    __shared__ float red[4];
+    __shared__ float red[8];
     const int t = blockIdx.x, C = a.C;
     TRACE_K(2, 0);
+    // every load that does not depend on another load is issued here, parameters first: the kernel is one latency
+    // chain (it moves ~100 KB), so each load left behind a reduction costs a full L2/MALL round trip
+    float4 wv[PT], bv[PT], mu0[PT], mu1[PT];
+    ROW_FOR(i, c) { wv[i] = ld4(a.lnw + c); bv[i] = ld4(a.lnb + c); }
+    if (a.nmix > 0) { ROW_FOR(i, c) mu0[i] = ld4(a.mu[0] + c); }
+    if (a.nmix > 1) { ROW_FOR(i, c) mu1[i] = ld4(a.mu[1] + c); }
     const int slot = a.rm.slot[t], prev = a.rm.prev[t], last = a.rm.last[t];
     float *__restrict__ sx = a.sx + (long)slot * a.sx_slot_stride;
     float4 xv[PT], pv[PT];
     row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, t, C, xv);
-    TRACE_K(2, 1);
     if (prev >= 0) row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, prev, C, pv);
     else { ROW_FOR(i, c) pv[i] = ld4(sx + c); }
+    TRACE_K(2, 1);
     if (a.x_out) { ROW_FOR(i, c) *(float4 *)(a.x_out + (long)t * C + c) = xv[i]; }
-    row_layernorm<PT>(xv, C, a.lnw, a.lnb, red);
+    row_layernorm<PT>(xv, C, wv, bv, red);
     TRACE_K(2, 2);
-    if (prev >= 0) row_layernorm<PT>(pv, C, a.lnw, a.lnb, red);
+    if (prev >= 0) row_layernorm<PT>(pv, C, wv, bv, red);
     if (last >= 0) {            // this block owns the slot's token-shift state write (after its own read above)
         if (last == t) {
             ROW_FOR(i, c) *(float4 *)(sx + c) = xv[i];
         } else {
             float4 lv[PT];
             row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, last, C, lv);
-            row_layernorm<PT>(lv, C, a.lnw, a.lnb, red);
+            row_layernorm<PT>(lv, C, wv, bv, red);
             ROW_FOR(i, c) *(float4 *)(sx + c) = lv[i];
         }
     }
@@ -957,11 +971,12 @@ __global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
         if (m < a.nmix) {
-            const float *__restrict__ mu = a.mu[m];
             _Float16 *__restrict__ oh = a.ohi[m];
             _Float16 *__restrict__ ol = a.olo[m];
             float4 muv[PT];
-            ROW_FOR(i, c) muv[i] = ld4(mu + c);
+            if (m == 0) { ROW_FOR(i, c) muv[i] = mu0[i]; }
+            else if (m == 1) { ROW_FOR(i, c) muv[i] = mu1[i]; }
+            else { const float *__restrict__ mu = a.mu[m]; ROW_FOR(i, c) muv[i] = ld4(mu + c); }
             ROW_FOR(i, c) {
                 float4 o;
                 if (a.mode == 0) {
@@ -993,8 +1008,10 @@ void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s) { ROW_DISPATCH(
 
 template <int PT>
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
-    __shared__ float red[4];
+    __shared__ float red[8];
     const int t = blockIdx.x, C = a.C;
+    float4 wv[PT], bv[PT];
+    ROW_FOR(i, c) { wv[i] = ld4(a.lnw + c); bv[i] = ld4(a.lnb + c); }
     int tok = a.token[t];
     tok = tok < 0 ? 0 : (tok >= a.V ? a.V - 1 : tok);
     float4 v[PT];
@@ -1002,19 +1019,21 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
         const f16x4 e = *(const f16x4 *)(a.emb + (long)tok * C + c);
         v[i] = make_float4((float)e[0], (float)e[1], (float)e[2], (float)e[3]);
     }
-    row_layernorm<PT>(v, C, a.lnw, a.lnb, red);
+    row_layernorm<PT>(v, C, wv, bv, red);
     ROW_FOR(i, c) *(float4 *)(a.x + (long)t * C + c) = v[i];
 }
 void launch_embed(const EmbedArgs &a, int T, hipStream_t s) { ROW_DISPATCH(embed_kernel, a.C, T, a); }
 
 template <int PT>
 __global__ __launch_bounds__(256) void ln_out_kernel(const LnOutArgs a) {
-    __shared__ float red[4];
+    __shared__ float red[8];
     const int o = blockIdx.x, C = a.C;
+    float4 wv[PT], bv[PT];
+    ROW_FOR(i, c) { wv[i] = ld4(a.lnw + c); bv[i] = ld4(a.lnb + c); }
     const int t = a.out_rows[o];
     float4 v[PT];
     row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, t, C, v);
-    row_layernorm<PT>(v, C, a.lnw, a.lnb, red);
+    row_layernorm<PT>(v, C, wv, bv, red);
     ROW_FOR(i, c) store_operand4(a.ohi, a.olo, opd_off(o, c, a.ldh), v[i]);
 }
 void launch_ln_out(const LnOutArgs &a, int n_out, hipStream_t s) { ROW_DISPATCH(ln_out_kernel, a.C, n_out, a); }
