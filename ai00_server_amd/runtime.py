@@ -23,7 +23,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librwkv_hip.so")
+LIB_PATH = os.environ.get("RWKV_HIP_LIB") or os.path.join(_HERE, "librwkv_hip.so")   # override: A/B builds (scripts/build_variant.py)
 
 
 class RwkvError(RuntimeError):
