@@ -12,7 +12,9 @@ enum Post : int { POST_NONE = 0, POST_MUL = 1, POST_MIX = 2 };
 
 constexpr int TILE_ROWS = 16;        // output rows per strip (MFMA 16x16x32 M)
 constexpr int KSTEP = 32;            // K per MFMA
-constexpr int GEMM_MAX_WAVES = 10;    // 640-thread blocks: <= 168 VGPRs per lane
+constexpr int GEMM_MAX_WAVES = 10;    // 640-thread blocks: <= 168 VGPRs per lane (KSW = 8 variants)
+constexpr int GEMM_MAX_WAVES_K16 = 8; // KSW = 16 variants: 512-thread blocks, 2 waves per SIMD -> 256 VGPRs per lane
+int gemm_variant_max_waves(int KSW);
 constexpr int GEMM_MAXP = 8;
 constexpr int INT8_BLOCK = 128;
 constexpr int NF4_BLOCK = 64;

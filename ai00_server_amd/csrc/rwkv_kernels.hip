@@ -291,6 +291,12 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
             // and is slower: issuing is throttled by the CU's memory pipeline either way, and X then lands last.)
             constexpr int MAXR = FMT == W_F16 ? 2 : 4;            // rounds a wave holds in registers at once (gemm_max_rounds)
             WRound<FMT> cur, nxt, w[SHOT ? MAXR : 1];
+            // streamed (not single-shot) quantised weights: a ring of RD rounds in flight per wave.  With only cur/nxt
+            // (one round ahead) a wave's K slice is a serial chain of memory latencies — 6 rounds x ~0.9 us at T = 1
+            // (scripts/trace_gemm.py); fp16 rounds are twice the registers and stay at one round ahead.
+            constexpr int RD = (!SHOT && FMT != W_F16) ? 4 : 1;
+            WRound<FMT> ring[RD];
+            const bool ringed = RD > 1 && nsub == SUB;
             if constexpr (SHOT) {
                 // single shot: every weight tile of this wave is in flight before the first MFMA (host: spb * SUB <= MAXR)
 #pragma unroll
@@ -298,6 +304,10 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                     const int s = r / SUB, sub = r % SUB;
                     if (s < nstrip && sub < nsub) load_round<FMT, TAIL>(w[r], P, strip0 + s, k0 + sub * RK, kend, true, lane);
                 }
+            } else if (ringed) {
+#pragma unroll
+                for (int j = 0; j < RD; ++j)
+                    if (j < nround) load_round<FMT, TAIL>(ring[j], P, strip0 + j / SUB, k0 + (j % SUB) * RK, kend, true, lane);
             } else {
                 load_round<FMT, TAIL>(cur, P, strip0, k0, kend, true, lane);
             }
@@ -328,6 +338,25 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                         }
                         if (sub < nsub) mma_round(w[r], acc, acc2, xb, xl, sub, k0);
                         if (sub == SUB - 1) park(s);
+                    }
+                }
+            } else if (ringed) {
+                for (int r0 = 0; r0 < nround; r0 += RD) {
+#pragma unroll
+                    for (int j = 0; j < RD; ++j) {                 // RD % SUB == 0: sub is compile-time, xb indices stay static
+                        const int r = r0 + j, s = r / SUB;
+                        constexpr int SUBM = SUB - 1;
+                        const int sub = j & SUBM;
+                        if (r < nround) {
+                            if (sub == 0) {
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) acc[nt] = acc2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            }
+                            mma_round(ring[j], acc, acc2, xb, xl, sub, k0);
+                            if (r + RD < nround)
+                                load_round<FMT, TAIL>(ring[j], P, strip0 + (r + RD) / SUB, k0 + sub * RK, kend, true, lane);
+                            if (sub == SUB - 1) park(s);
+                        }
                     }
                 }
             } else {
@@ -394,7 +423,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
 }
 
 template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL>
-__global__ __launch_bounds__(GEMM_MAX_WAVES * 64) void gemm_kernel(const GemmLaunch L) {
+__global__ __launch_bounds__((KSW == 16 ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES) * 64) void gemm_kernel(const GemmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int pi = 0;
     for (int i = 1; i < L.nprob; ++i)
@@ -404,6 +433,8 @@ __global__ __launch_bounds__(GEMM_MAX_WAVES * 64) void gemm_kernel(const GemmLau
     else if (P.fmt == W_INT8) gemm_body<NT, KSW, HILO, SHOT, false, W_INT8>(L, P, smem);   // quantised K is a multiple of 256
     else gemm_body<NT, KSW, HILO, SHOT, false, W_NF4>(L, P, smem);
 }
+
+int gemm_variant_max_waves(int KSW) { return KSW == 16 ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES; }
 
 void gemm_variant(int T, bool hilo, int &NT, int &KSW) {
     static const int ksw8 = std::getenv("RWKV_KSW8") ? std::atoi(std::getenv("RWKV_KSW8")) : 0;
