@@ -581,7 +581,7 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
         // strips per block: the whole grid should be resident at once (~164 VGPRs -> 12 waves per CU), and a wave's
         // rounds should fit in registers so that every load is issued up-front (single shot); the head matrix is too
         // big for that and runs 8 strips per block, software-pipelined.
-        const int sub = KSW / 8, maxr = gemm_max_rounds(s.W->fmt);
+        const int sub = KSW / 8, maxr = gemm_max_rounds(s.W->fmt, NT, hilo);
         const long cap = 256L * std::max(1, 8 / nw);           // measured: 5-wave blocks are resident one per CU
         int spb = (int)((total_strips * ksb + cap - 1) / cap);
         if ((total_strips * ksb + spb - 1) / spb > 1024) spb = 8;            // huge matrices (head): long pipelined blocks

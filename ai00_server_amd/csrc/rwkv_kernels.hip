@@ -240,7 +240,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                 const f16x8 a = frag<FMT>(w, ks, lut);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    f32x4 &d = (ks & 1) ? acc2[nt] : acc[nt];
+                    f32x4 &d = (NT == 1 && (ks & 1)) ? acc2[nt] : acc[nt];   // NT = 2 already has two independent chains
                     d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[nt][sub * RS + ks], d, 0, 0, 0);
                     if constexpr (HILO) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xl[nt][sub * RS + ks], d, 0, 0, 0);
                 }
@@ -289,12 +289,12 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
             // X first, weights after: the X fragments are L2 hits and complete first, so (in-order vmcnt) the MFMAs of round
             // r only wait for rounds <= r while later rounds are still streaming in from HBM.  (Weights-first was measured
             // and is slower: issuing is throttled by the CU's memory pipeline either way, and X then lands last.)
-            constexpr int MAXR = FMT == W_F16 ? 2 : 4;            // rounds a wave holds in registers at once (gemm_max_rounds)
+            constexpr int MAXR = FMT == W_F16 ? 2 : ((NT == 2 || HILO) ? 3 : 4);   // rounds a wave holds in registers at once (gemm_max_rounds)
             WRound<FMT> cur, nxt, w[SHOT ? MAXR : 1];
             // streamed (not single-shot) quantised weights: a ring of RD rounds in flight per wave.  With only cur/nxt
             // (one round ahead) a wave's K slice is a serial chain of memory latencies — 6 rounds x ~0.9 us at T = 1
             // (scripts/trace_gemm.py); fp16 rounds are twice the registers and stay at one round ahead.
-            constexpr int RD = (!SHOT && FMT != W_F16) ? 4 : 1;
+            constexpr int RD = (!SHOT && FMT != W_F16) ? ((NT == 2 || HILO) ? 2 : 4) : 1;
             WRound<FMT> ring[RD];
             const bool ringed = RD > 1 && nsub == SUB;
             if constexpr (SHOT) {
@@ -468,7 +468,7 @@ void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
 #undef GEMM_V3
 }
 
-int gemm_max_rounds(int fmt) { return fmt == W_F16 ? 2 : 4; }
+int gemm_max_rounds(int fmt, int NT, bool hilo) { return fmt == W_F16 ? 2 : ((NT == 2 || hilo) ? 3 : 4); }   // 64 X registers in a 168-VGPR budget: 3
 
 __device__ __forceinline__ void store_operand4(_Float16 *__restrict__ hi, _Float16 *__restrict__ lo, long off, float4 o);
 
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[d][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const u32x4 *w1 = (const u32x4 *)a.W1;
-    constexpr int KB = DS == 2 ? 10 : 4;                                          // k-steps per batch: all loads of a batch in flight at once
+    constexpr int KB = DS == 2 ? ((HILO && NT == 2) ? 5 : 10) : 4;                                          // k-steps per batch: all loads of a batch in flight at once
     for (int k0 = 0; k0 < kst; k0 += KB) {
         f16x8 zb[KB][NT], zl[HILO ? KB : 1][HILO ? NT : 1];
         u32x4 wt[KB][DS];
