@@ -126,8 +126,21 @@ def main():
         vec_bytes = sum(int(np.prod(s)) * 2 for k, s in shapes.items() if len([d for d in s if d > 1]) <= 1)
         layer_gemm_bytes = eng.weight_bytes - head_bytes - vec_bytes          # weights the layer GEMM launches stream
         achieved = layer_gemm_bytes / (g_ms / nprof * 1e-3)
+        # HBM traffic per launch from the PMC passes (scripts/collect_pmc.py on the same workload; committed under
+        # profiles/).  Not collectable inside this process: counters need rocprofv3 around the run.
+        traffic, traffic_src = None, None
+        import glob
+        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                               f"*_pmc_traffic_{args.workload}_{args.quant}_b{B}.json"))):
+            try:
+                traffic = json.load(open(f))["layer_gemm"]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/" + os.path.basename(f)
+            except Exception:
+                pass
         roof = {"bound": "hbm", "kernel": "gemm_kernel (layer projections)", "achieved": achieved / 1e9,
-                "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": layer_gemm_bytes / max(1, g_n // nprof),
                 "launches_per_step": g_n // nprof, "avg_launch_us": g_ms / g_n * 1e3,
                 "bytes_per_step": layer_gemm_bytes,
                 "head_gemm_GBps": head_bytes / (h_ms / nprof * 1e-3) / 1e9,
