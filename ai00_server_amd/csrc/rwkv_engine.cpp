@@ -108,6 +108,7 @@ struct ProbSpec {
     int ldo = 0;
     bool partial = false;           // out = partial-sum buffer, K may be split across blocks
     Opd oh;                         // optional operand output
+    const float *lnp_mu = nullptr;  // LN-prologue launches: the token-shift mix vector of this problem (x unused)
 };
 
 enum Family { FAM_GEMM = 0, FAM_HEAD = 1, FAM_ROW = 2, FAM_WKV = 3, FAM_SAMPLE = 4, FAM_COPY = 5 };
@@ -270,7 +271,9 @@ struct rwkv_engine {
     }
 
     void load(const rwkv_load_desc &d);
-    int gemm(std::vector<ProbSpec> &ps, int T, int fam);
+    int gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs *lnp = nullptr, const ShiftCommit *commit = nullptr);
+    bool ln_fusable(std::vector<ProbSpec> &ps, int T, int np);
+    float *lnp_xx_att = nullptr, *lnp_xx_ffn = nullptr;   // normalised rows published by an LN-prologue launch (for the commit)
     void plan_step(const rwkv_slot_input *in, StepPlan &pl);
     void upload_plan(const StepPlan &pl);
     void run_layers(int T, int n_seq, int n_out, const int *d_token);
@@ -498,6 +501,7 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
     pstride = (long)TC;
     xA = dalloc<float>(TC); xB = dalloc<float>(TC); P = dalloc<float>(TC * 8);
     xx = dalloc<float>(TC); dx = dalloc<float>(TC);
+    lnp_xx_att = dalloc<float>((size_t)LNP_MAX_T * C); lnp_xx_ffn = dalloc<float>((size_t)LNP_MAX_T * C);
     fr = dalloc<float>(TC); fk = dalloc<float>(TC); fv = dalloc<float>(TC); fg = dalloc<float>(TC); frr = dalloc<float>(TC);
     ftd = dalloc<float>((size_t)chunk * 128);
     if (info.version == 7) {
@@ -598,6 +602,7 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
         g.act = s.act; g.post = s.post; g.bias = s.bias; g.m0 = s.m0; g.m1 = s.m1; g.ldm = s.ldm;
         g.out_f32 = s.out; g.ldo = s.ldo; g.partial_stride = pstride;
         g.out_hi = s.oh.hi; g.out_lo = s.oh.lo; g.ldh = s.oh.ld;
+        g.lnp_mu = s.lnp_mu;
         max_nw = std::max(max_nw, nw);
         if (spb * sub > maxr) shot = false;
         if (Kb % 256) tail = true;
@@ -612,7 +617,28 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
     return np;
 }
 
-int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam) {
+// Can this launch carry the LayerNorm + token-shift prologue (rwkv_kernels.h LnProArgs)?  Single-token steps in
+// Fp16 mode whose every problem walks K = C with one slice per wave and the same wave count (the prologue is a
+// block-wide cooperative pass), with room in LDS for the rows.
+bool rwkv_engine::ln_fusable(std::vector<ProbSpec> &ps, int T, int np) {
+    static const int off = env_int("RWKV_NO_LN_FUSE");
+    if (off || hilo || T > LNP_MAX_T || np > LNP_MAX_NP) return false;
+    int NT, KSW;
+    gemm_variant(T, hilo, NT, KSW);
+    if (NT != 1 || KSW != 16) return false;
+    const int C = info.num_emb;
+    for (auto &s : ps) if (s.W->K != C || s.partial) return false;
+    GemmLaunch Lh;
+    plan_gemm(Lh, ps, T, hilo, pstride);
+    for (int i = 0; i < Lh.nprob; ++i) {
+        const GemmProb &g = Lh.p[i];
+        if (g.ksb != 1 || g.nw * 64 != Lh.threads || (C + KSW * 32 - 1) / (KSW * 32) > g.nw) return false;
+    }
+    if (C > 8 * Lh.threads || C % 32) return false;
+    return (size_t)Lh.lds_items * NT * 1024 + lnp_lds_bytes(T, C, hilo) <= 150 * 1024;
+}
+
+int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs *lnp, const ShiftCommit *commit) {
     GemmLaunch Lh;
     static const int no_tile = env_int("RWKV_NO_TILE");
     if (T >= GEMM_TILE_MIN_T && !no_tile) {
@@ -647,6 +673,8 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam) {
         return 1;
     }
     const int np = plan_gemm(Lh, ps, T, hilo, pstride);
+    if (lnp) Lh.lnp = *lnp;
+    if (commit) Lh.commit = *commit;
     launch(fam, [&] { launch_gemm(Lh, hilo, s_main); });
     return np;
 }
@@ -758,18 +786,40 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token) {
         auto prob = [&](const DMat *W, const Opd &x, int act, float *out, int ldo) {
             ProbSpec s; s.W = W; s.x = x; s.act = act; s.out = out; s.ldo = ldo; return s;
         };
+        // single-token steps: the LayerNorm + token shift rides as a prologue of the GEMM that consumes it, and the launch
+        // after that commits the shift state (LnProArgs / ShiftCommit in rwkv_kernels.h)
+        auto ln_pro = [&](const LnShiftArgs &r, float *xx_pub) {
+            LnProArgs lp{};
+            lp.x_in = r.x_in; lp.x_out = r.x_out; lp.P = r.P; lp.np = r.np; lp.pstride = r.pstride;
+            lp.lnw = r.lnw; lp.lnb = r.lnb; lp.sx = r.sx; lp.sx_slot_stride = r.sx_slot_stride; lp.rm = r.rm;
+            lp.mode = r.mode; lp.xx_out = xx_pub; lp.C = C;
+            return lp;
+        };
+        auto commit_of = [&](const LnShiftArgs &r, const float *xx_pub) {
+            ShiftCommit cm{};
+            cm.src = xx_pub; cm.sx = r.sx; cm.sx_slot_stride = r.sx_slot_stride; cm.rm = r.rm; cm.T = T; cm.C = C;
+            return cm;
+        };
+        bool att_fused = false;                                    // a commit of the time-mix shift state is pending
         if (info.version == 5) {
             a.mode = 0; a.nmix = 4;
             for (int i = 0; i < 4; ++i) { a.mu[i] = w.mu[i]; a.ohi[i] = opA[i].hi; a.olo[i] = opA[i].lo; }
-            launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
             ps = {prob(w.Wk, opA[0], ACT_NONE, fk, C), prob(w.Wv, opA[1], ACT_NONE, fv, C),
                   prob(w.Wr, opA[2], ACT_NONE, fr, C), prob(w.Wg, opA[3], ACT_SILU, fg, C)};
-            gemm(ps, T, FAM_GEMM);
+            for (int i = 0; i < 4; ++i) ps[i].lnp_mu = w.mu[i];
+            if ((att_fused = ln_fusable(ps, T, np))) {
+                LnProArgs lp = ln_pro(a, lnp_xx_att);
+                gemm(ps, T, FAM_GEMM, &lp);
+            } else {
+                launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
+                gemm(ps, T, FAM_GEMM);
+            }
         } else if (info.version == 6) {
             a.mode = 1; a.nmix = 1; a.mu[0] = w.mu[0]; a.ohi[0] = opA[0].hi; a.olo[0] = opA[0].lo;
             a.xx_out = xx; a.dx_out = dx;
-            launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
-            static const int no_fuse = env_int("RWKV_NO_V6_FUSE");
+            static const int no_fuse = env_int("RWKV_NO_V6_FUSE"), no_ln_fuse = env_int("RWKV_NO_LN_FUSE");
+            att_fused = !no_fuse && !no_ln_fuse && v6_mix_ln_supported(T, C, Dm, hilo, np);
+            if (!att_fused) launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
             if (v6_mix_supported(T, C, Dm) && !no_fuse) {
                 // fused: x_c = xx + dx * (mu_c + W2_c tanh(W1_c z)) in one launch
                 V6MixArgs m{};
@@ -777,6 +827,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token) {
                 for (int c = 0; c < 5; ++c) { m.W2[c] = w.W2[c]->data; m.mu[c] = w.mu[1 + c]; m.ohi[c] = opA[1 + c].hi; m.olo[c] = opA[1 + c].lo; }
                 m.zhi = opA[0].hi; m.zlo = opA[0].lo; m.ldz = C;
                 m.xx = xx; m.dx = dx; m.ldh = C; m.T = T; m.C = C; m.Dm = Dm;
+                if (att_fused) { m.lnp = ln_pro(a, lnp_xx_att); m.mu_x = w.mu[0]; }
                 launch(FAM_GEMM, [&] { launch_v6_mix(m, hilo, s_main); });
             } else {
                 {   // m = tanh(W1 z)  ->  operand [T][5*Dm]
@@ -798,24 +849,32 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token) {
             ps = {prob(w.Wk, opA[2], ACT_NONE, fk, C), prob(w.Wv, opA[3], ACT_NONE, fv, C),
                   prob(w.Wr, opA[4], ACT_NONE, fr, C), prob(w.Wg, opA[5], ACT_SILU, fg, C),
                   prob(w.D1, opA[1], ACT_TANH, ftd, Dd)};
-            gemm(ps, T, FAM_GEMM);
+            if (att_fused) { ShiftCommit cm = commit_of(a, lnp_xx_att); gemm(ps, T, FAM_GEMM, nullptr, &cm); att_fused = false; }
+            else gemm(ps, T, FAM_GEMM);
         } else {
             a.mode = 1; a.nmix = 6;
             for (int i = 0; i < 6; ++i) { a.mu[i] = w.mu[i]; a.ohi[i] = opA[i].hi; a.olo[i] = opA[i].lo; }
-            launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
             // opA: 0=r 1=w 2=k 3=v 4=a 5=g
             ps = {prob(w.Wr, opA[0], ACT_NONE, fr, C), prob(w.Wk, opA[2], ACT_NONE, fk, C), prob(w.Wv, opA[3], ACT_NONE, fv, C)};
-            { ProbSpec s = prob(w.w1, opA[1], ACT_TANH, nullptr, 0); s.oh = opL[0]; ps.push_back(s); }
-            { ProbSpec s = prob(w.a1, opA[4], ACT_NONE, nullptr, 0); s.oh = opL[1]; ps.push_back(s); }
-            { ProbSpec s = prob(w.g1, opA[5], ACT_SIGMOID, nullptr, 0); s.oh = opL[2]; ps.push_back(s); }
-            if (l > 0) { ProbSpec s = prob(w.v1, opA[3], ACT_NONE, nullptr, 0); s.oh = opL[3]; ps.push_back(s); }
-            gemm(ps, T, FAM_GEMM);
+            ps[0].lnp_mu = w.mu[0]; ps[1].lnp_mu = w.mu[2]; ps[2].lnp_mu = w.mu[3];
+            { ProbSpec s = prob(w.w1, opA[1], ACT_TANH, nullptr, 0); s.oh = opL[0]; s.lnp_mu = w.mu[1]; ps.push_back(s); }
+            { ProbSpec s = prob(w.a1, opA[4], ACT_NONE, nullptr, 0); s.oh = opL[1]; s.lnp_mu = w.mu[4]; ps.push_back(s); }
+            { ProbSpec s = prob(w.g1, opA[5], ACT_SIGMOID, nullptr, 0); s.oh = opL[2]; s.lnp_mu = w.mu[5]; ps.push_back(s); }
+            if (l > 0) { ProbSpec s = prob(w.v1, opA[3], ACT_NONE, nullptr, 0); s.oh = opL[3]; s.lnp_mu = w.mu[3]; ps.push_back(s); }
+            if ((att_fused = ln_fusable(ps, T, np))) {
+                LnProArgs lp = ln_pro(a, lnp_xx_att);
+                gemm(ps, T, FAM_GEMM, &lp);
+            } else {
+                launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
+                gemm(ps, T, FAM_GEMM);
+            }
             ps.clear();
             { ProbSpec s = prob(w.w2, opL[0], ACT_DECAY7, fw7, C); s.bias = w.w0; ps.push_back(s); }
             { ProbSpec s = prob(w.a2, opL[1], ACT_SIGMOID, fa7, C); s.bias = w.a0; ps.push_back(s); }
             { ProbSpec s = prob(w.g2, opL[2], ACT_NONE, fg, C); ps.push_back(s); }
             if (l > 0) { ProbSpec s = prob(w.v2, opL[3], ACT_SIGMOID, fvg7, C); s.bias = w.v0; ps.push_back(s); }
-            gemm(ps, T, FAM_GEMM);
+            if (att_fused) { ShiftCommit cm = commit_of(a, lnp_xx_att); gemm(ps, T, FAM_GEMM, nullptr, &cm); att_fused = false; }
+            else gemm(ps, T, FAM_GEMM);
         }
         std::swap(cur, oth);
         {
@@ -835,7 +894,8 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token) {
             ProbSpec s = prob(w.Wo, opY, ACT_NONE, P, C);
             s.partial = true;
             ps = {s};
-            np = gemm(ps, T, FAM_GEMM);
+            if (att_fused) { ShiftCommit cm = commit_of(a, lnp_xx_att); np = gemm(ps, T, FAM_GEMM, nullptr, &cm); }
+            else np = gemm(ps, T, FAM_GEMM);
         }
         // ---- channel mix
         LnShiftArgs f{};
@@ -846,21 +906,28 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token) {
         f.mode = info.version == 5 ? 0 : 1;
         f.nmix = info.version == 7 ? 1 : 2;
         for (int i = 0; i < f.nmix; ++i) { f.mu[i] = w.fmu[i]; f.ohi[i] = opA[i].hi; f.olo[i] = opA[i].lo; }
-        launch(FAM_ROW, [&] { launch_ln_shift(f, T, s_main); });
-        std::swap(cur, oth);
+        bool ffn_fused = false;
         {
             ProbSpec s = prob(w.Fk, opA[0], ACT_RELU2, nullptr, 0);
-            s.oh = opK;
+            s.oh = opK; s.lnp_mu = w.fmu[0];
             ps = {s};
-            if (info.version != 7) ps.push_back(prob(w.Fr, opA[1], ACT_SIGMOID, frr, C));
-            gemm(ps, T, FAM_GEMM);
+            if (info.version != 7) { ProbSpec r = prob(w.Fr, opA[1], ACT_SIGMOID, frr, C); r.lnp_mu = w.fmu[1]; ps.push_back(r); }
+            if ((ffn_fused = ln_fusable(ps, T, np))) {
+                LnProArgs lp = ln_pro(f, lnp_xx_ffn);
+                gemm(ps, T, FAM_GEMM, &lp);
+            } else {
+                launch(FAM_ROW, [&] { launch_ln_shift(f, T, s_main); });
+                gemm(ps, T, FAM_GEMM);
+            }
+            std::swap(cur, oth);
         }
         {
             ProbSpec s = prob(w.Fv, opK, ACT_NONE, P, C);
             s.partial = true;
             if (info.version != 7) { s.post = POST_MUL; s.m0 = frr; s.ldm = C; }
             ps = {s};
-            np = gemm(ps, T, FAM_GEMM);
+            if (ffn_fused) { ShiftCommit cm = commit_of(f, lnp_xx_ffn); np = gemm(ps, T, FAM_GEMM, nullptr, &cm); }
+            else np = gemm(ps, T, FAM_GEMM);
         }
     }
     if (n_out > 0) {

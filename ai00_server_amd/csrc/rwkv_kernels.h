@@ -33,6 +33,42 @@ struct DMat {
     uint64_t bytes = 0;             // payload + scales, for roofline accounting
 };
 
+struct RowMeta {                    // device arrays, one entry per row of this step
+    const int *token;               // token id
+    const int *slot;                // state slot
+    const int *prev;                // previous row of the same slot in this step, or -1 (-> state)
+    const int *last;                // for first rows: last row of the slot in this step; else -1
+};
+
+// LayerNorm + token-shift PROLOGUE of a GEMM-like kernel (tiny decode steps, T <= LNP_MAX_T): every block redoes the
+// row work of `ln_shift_kernel` for all T rows in LDS and builds its MFMA B fragments from there, which removes one
+// launch (~5 us of pure latency) per LayerNorm.  Block 0 also publishes x_out (the residual stream) and xx_out (the
+// normalised rows); the token-shift STATE is committed by the launch that follows (ShiftCommit), because other
+// blocks of this launch still read the old state.
+constexpr int LNP_MAX_T = 1;        // single-token decode steps (two rows at once do not fit the register file beside the weights)
+constexpr int LNP_MAX_NP = 5;       // partial-sum slabs of the producing GEMM
+struct LnProArgs {
+    const float *x_in;              // null: no prologue in this launch
+    float *x_out;
+    const float *P;
+    int np;
+    long pstride;
+    const float *lnw, *lnb;
+    const float *sx;                // token-shift state of this layer (read only here)
+    long sx_slot_stride;
+    RowMeta rm;
+    int mode;                       // 0: V5  op = xx*mu + prev*(1-mu);  1: V6/V7  op = xx + (prev-xx)*mu
+    float *xx_out;                  // [T][C]
+    int C;
+};
+struct ShiftCommit {                // sx[slot[t]] = src[last[t]] for rows with last[t] >= 0; run by one extra block
+    const float *src;               // null: nothing to commit
+    float *sx;
+    long sx_slot_stride;
+    RowMeta rm;
+    int T, C;
+};
+
 struct GemmProb {
     const void *W;
     const void *S;
@@ -54,6 +90,7 @@ struct GemmProb {
     long partial_stride;
     _Float16 *out_hi, *out_lo;      // operand output [T][ldh]
     int ldh;
+    const float *lnp_mu;            // LN-prologue launches: this problem's token-shift mix vector (xhi/xlo unused)
 };
 
 struct GemmLaunch {
@@ -65,9 +102,12 @@ struct GemmLaunch {
     int single_shot;                // every problem's rounds per wave fit in registers: issue all loads up-front
     int tail;                       // some fp16 problem has a K range that is not a multiple of 256: predicated variant
     int total_blocks;
+    LnProArgs lnp;
+    ShiftCommit commit;             // grid = total_blocks + 1 when commit.src is set
 };
 
 void gemm_variant(int T, bool hilo, int &NT, int &KSW);   // tile variant used for T rows
+size_t lnp_lds_bytes(int T, int C, bool hilo);                       // extra dynamic LDS of an LN-prologue launch
 void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s);
 int gemm_max_rounds(int fmt, int NT, bool hilo);
 // prefill path (T >= GEMM_TILE_MIN_T): LDS-tiled MFMA GEMM, no K split; uses p[].block_begin and total_blocks only
@@ -86,16 +126,13 @@ struct V6MixArgs {
     const float *mu[5];
     _Float16 *ohi[5], *olo[5];      // outputs: the five GEMM operands [T][ldh]
     int ldh, T, C, Dm;
+    LnProArgs lnp;                  // lnp.x_in set: LayerNorm + shift computed in the kernel (z, xx, dx unused)
+    const float *mu_x;              // with lnp: z = xx + dx * mu_x
 };
 bool v6_mix_supported(int T, int C, int Dm);
+bool v6_mix_ln_supported(int T, int C, int Dm, bool hilo, int np);   // the LayerNorm-prologue form (lnp set)
 void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s);
 
-struct RowMeta {                    // device arrays, one entry per row of this step
-    const int *token;               // token id
-    const int *slot;                // state slot
-    const int *prev;                // previous row of the same slot in this step, or -1 (-> state)
-    const int *last;                // for first rows: last row of the slot in this step; else -1
-};
 
 struct LnShiftArgs {
     const float *x_in;

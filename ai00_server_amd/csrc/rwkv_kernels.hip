@@ -213,7 +213,177 @@ __device__ __forceinline__ f16x8 frag(const WRound<FMT> &w, int ks, const Nf4Lut
     }
 }
 
-template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, int FMT>
+// =====================================================================================
+// LayerNorm + token-shift prologue (LnProArgs): the row work of ln_shift_kernel redone by EVERY block of a GEMM-like
+// launch for all T <= LNP_MAX_T rows.  Leaves in LDS (row stride C + LNP_PAD floats):
+//   xx_l[t][c]  normalised rows,  pv_l[t][c]  the slots' shift states,
+//   op_l        the calling block's GEMM operand mix(xx, prev, mu) as f16 (hi[, lo]) in MFMA B-fragment order.
+// Same arithmetic as ln_shift_kernel (slab sum in slab order, two-pass LayerNorm); the cross-wave sums run over
+// blockDim/64 waves instead of 4, so results may differ from the unfused path in the last bit.
+// Host guarantees C <= 8 * blockDim.x, np <= LNP_MAX_NP, T <= LNP_MAX_T.  All threads of the block must call it.
+// =====================================================================================
+constexpr int LNP_PAD = 4;
+__device__ __forceinline__ float4 lnp_ld4(const float *p) { return *(const float4 *)p; }
+__device__ __forceinline__ float lnp_mix1(int mode, float x, float p, float m) {
+    return mode == 0 ? x * m + p * (1.0f - m) : x + (p - x) * m;
+}
+constexpr int LNP_PTN = 2;
+struct LnCarry { int prev[LNP_MAX_T]; };
+// part 1: every global load of the prologue; residual sums and shift states land in LDS, per-wave partial sums in `red`
+__device__ __forceinline__ void ln_prologue_load(const LnProArgs &a, int T, float *xx_l, float *pv_l, float *red,
+                                                 bool publish, LnCarry &k) {
+    constexpr int PTN = LNP_PTN;
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.C, ldl = C + LNP_PAD;
+    int (&prev)[LNP_MAX_T] = k.prev;
+    // ---- pass 1, row by row (registers: one row's slabs in flight): residual sum -> LDS, state -> LDS, partial sums
+#pragma unroll
+    for (int t = 0; t < LNP_MAX_T; ++t) {
+        if (t < T) {
+            const int slot = a.rm.slot[t];
+            prev[t] = a.rm.prev[t];
+            float4 v[PTN], sxv[PTN], pp[LNP_MAX_NP][PTN];
+#pragma unroll
+            for (int i = 0; i < PTN; ++i) {
+                const int c = (tid + i * nth) * 4;
+                if (c < C) {
+                    v[i] = lnp_ld4(a.x_in + (long)t * C + c);
+#pragma unroll
+                    for (int j = 0; j < LNP_MAX_NP; ++j)       // branch-free: slabs beyond np re-read slab 0 and are dropped below
+                        pp[j][i] = lnp_ld4(a.P + (j < a.np ? j : 0) * a.pstride + (long)t * C + c);
+                    sxv[i] = lnp_ld4(a.sx + (long)slot * a.sx_slot_stride + c);
+                }
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < PTN; ++i) {
+                const int c = (tid + i * nth) * 4;
+                if (c < C) {
+#pragma unroll
+                    for (int j = 0; j < LNP_MAX_NP; ++j) {
+                        const bool on = j < a.np;              // select, not multiply: an unused slab may hold anything
+                        v[i].x += on ? pp[j][i].x : 0.f; v[i].y += on ? pp[j][i].y : 0.f;
+                        v[i].z += on ? pp[j][i].z : 0.f; v[i].w += on ? pp[j][i].w : 0.f;
+                    }
+                    if (publish) *(float4 *)(a.x_out + (long)t * C + c) = v[i];
+                    *(float4 *)(xx_l + t * ldl + c) = v[i];
+                    *(float4 *)(pv_l + t * ldl + c) = sxv[i];
+                    sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+                }
+            }
+            sum = wave_sum(sum);
+            if (lane == 0) red[t * 16 + wave] = sum;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+// part 2: reductions, normalisation, operand emit (LDS only, four barriers)
+template <bool HILO>
+__device__ __forceinline__ void ln_prologue_finish(const LnProArgs &a, int T, const float *mu, float *xx_l, float *pv_l, _Float16 *op_l,
+                                                   float *red, bool publish, const LnCarry &k) {
+    constexpr int PTN = LNP_PTN;
+    const int tid = threadIdx.x, nth = blockDim.x, nwv = nth >> 6, lane = tid & 63, wave = tid >> 6;
+    const int C = a.C, ldl = C + LNP_PAD;
+    const int (&prev)[LNP_MAX_T] = k.prev;
+    float4 wv[PTN], bv[PTN], muv[PTN];                           // L2-hot parameters: in flight across the first barrier
+#pragma unroll
+    for (int i = 0; i < PTN; ++i) {
+        const int c = (tid + i * nth) * 4;
+        if (c < C) { wv[i] = lnp_ld4(a.lnw + c); bv[i] = lnp_ld4(a.lnb + c); muv[i] = lnp_ld4(mu + c); }
+    }
+    __syncthreads();
+    // ---- pass 2: centred variance (each thread re-reads its own elements from LDS)
+    float mean[LNP_MAX_T];
+#pragma unroll
+    for (int t = 0; t < LNP_MAX_T; ++t) {
+        mean[t] = 0.f;
+        if (t < T) {
+            float m = 0.f, q = 0.f;
+            for (int w2 = 0; w2 < nwv; ++w2) m += red[t * 16 + w2];
+            mean[t] = m / (float)C;
+#pragma unroll
+            for (int i = 0; i < PTN; ++i) {
+                const int c = (tid + i * nth) * 4;
+                if (c < C) {
+                    const float4 v = *(const float4 *)(xx_l + t * ldl + c);
+                    const float d0 = v.x - mean[t], d1 = v.y - mean[t], d2 = v.z - mean[t], d3 = v.w - mean[t];
+                    q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+            }
+            q = wave_sum(q);
+            if (lane == 0) red[32 + t * 16 + wave] = q;
+        }
+    }
+    __syncthreads();
+    // ---- pass 3: normalise in place
+#pragma unroll
+    for (int t = 0; t < LNP_MAX_T; ++t) {
+        if (t < T) {
+            float m = 0.f;
+            for (int w2 = 0; w2 < nwv; ++w2) m += red[32 + t * 16 + w2];
+            const float rstd = 1.0f / sqrtf(m / (float)C + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < PTN; ++i) {
+                const int c = (tid + i * nth) * 4;
+                if (c < C) {
+                    const float4 v = *(const float4 *)(xx_l + t * ldl + c);
+                    float4 o;
+                    o.x = (v.x - mean[t]) * rstd * wv[i].x + bv[i].x;
+                    o.y = (v.y - mean[t]) * rstd * wv[i].y + bv[i].y;
+                    o.z = (v.z - mean[t]) * rstd * wv[i].z + bv[i].z;
+                    o.w = (v.w - mean[t]) * rstd * wv[i].w + bv[i].w;
+                    *(float4 *)(xx_l + t * ldl + c) = o;
+                    if (publish) *(float4 *)(a.xx_out + (long)t * C + c) = o;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pass 4: this block's GEMM operand  op = mix(xx, prev, mu)  as f16 in MFMA B-fragment order, T rows per tile:
+    //      halfs [(k>>5)*4 + ((k>>3)&3)][t][k&7]  (+ the lo parts behind them).  A row that follows another row of its slot
+    //      inside this step shifts from that row, otherwise from the state.
+    _Float16 *op_lo = op_l + (size_t)T * C;
+#pragma unroll
+    for (int t = 0; t < LNP_MAX_T; ++t) {
+        if (t < T) {
+#pragma unroll
+            for (int i = 0; i < PTN; ++i) {
+                const int c = (tid + i * nth) * 4;
+                if (c < C) {
+                    const float4 x = *(const float4 *)(xx_l + t * ldl + c);
+                    const float4 pvv = prev[t] >= 0 ? *(const float4 *)(xx_l + prev[t] * ldl + c) : *(const float4 *)(pv_l + t * ldl + c);
+                    const float o0 = lnp_mix1(a.mode, x.x, pvv.x, muv[i].x), o1 = lnp_mix1(a.mode, x.y, pvv.y, muv[i].y);
+                    const float o2 = lnp_mix1(a.mode, x.z, pvv.z, muv[i].z), o3 = lnp_mix1(a.mode, x.w, pvv.w, muv[i].w);
+                    f16x4 hh, ll;
+                    _Float16 h, l;
+                    split_hilo(o0, h, l); hh[0] = h; ll[0] = l;
+                    split_hilo(o1, h, l); hh[1] = h; ll[1] = l;
+                    split_hilo(o2, h, l); hh[2] = h; ll[2] = l;
+                    split_hilo(o3, h, l); hh[3] = h; ll[3] = l;
+                    const int off = ((((c >> 5) << 2) + ((c >> 3) & 3)) * T + t) * 8 + (c & 7);
+                    *(f16x4 *)(op_l + off) = hh;
+                    if constexpr (HILO) *(f16x4 *)(op_lo + off) = ll;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ size_t lnp_op_off(int T, int k, int tl) { return (size_t)((k >> 3) * T + tl) * 8; }   // k multiple of 8
+size_t lnp_lds_bytes(int T, int C, bool hilo) { return (size_t)(2 * T * (C + LNP_PAD) + 64) * 4 + (size_t)T * C * 2 * (hilo ? 2 : 1); }
+
+// token-shift state commit of the previous launch's prologue (one extra block)
+__device__ __forceinline__ void shift_commit(const ShiftCommit &c) {
+    for (int t = 0; t < c.T; ++t) {
+        const int last = c.rm.last[t];
+        if (last < 0) continue;
+        const float *src = c.src + (long)last * c.C;
+        float *dst = c.sx + (long)c.rm.slot[t] * c.sx_slot_stride;
+        for (int i = threadIdx.x * 4; i < c.C; i += blockDim.x * 4) *(float4 *)(dst + i) = *(const float4 *)(src + i);
+    }
+}
+
+template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, int FMT, bool LNP>
 __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
     constexpr int KW = KSW * 32, SUB = KSW / RS, RK = RS * 32;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -258,34 +428,6 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
             TRACE_PT(6);
             // X slice of this wave -> B fragments: one contiguous 1 KiB tile per (n-tile, k-step), see opd_off
             f16x8 xb[NT][KSW], xl[HILO ? NT : 1][HILO ? KSW : 1];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                // token tile of this n-tile (clamped: results of tiles / lanes beyond T are never stored); lanes beyond the
-                // step's last token re-read its 16 B so a T = 1 step still moves 64 B per k-step, not 1 KiB
-                const int tile = min((t0 >> 4) + nt, (L.T - 1) >> 4);
-                const int tl = min(lane & 15, L.T - 1 - tile * 16);
-                const long xo = ((long)tile * (P.ldx >> 5) + (k0 >> 5)) * 512 + ((lane >> 4) * 16 + tl) * 8;
-                const _Float16 *ph = P.xhi + xo;
-                const _Float16 *pl = HILO ? P.xlo + xo : nullptr;
-#pragma unroll
-                for (int sub = 0; sub < SUB; ++sub) {
-                    if (TAIL || sub < nsub) {                      // one uniform branch per 256-k round
-#pragma unroll
-                        for (int k8 = 0; k8 < RS; ++k8) {
-                            const int ks = sub * RS + k8;
-                            const bool in = !TAIL || (k0 + ks * 32 < kend);
-                            xb[nt][ks] = in ? *(const f16x8 *)(ph + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                            if constexpr (HILO) xl[nt][ks] = in ? *(const f16x8 *)(pl + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                        }
-                    } else {
-#pragma unroll
-                        for (int k8 = 0; k8 < RS; ++k8) {
-                            xb[nt][sub * RS + k8] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                            if constexpr (HILO) xl[nt][sub * RS + k8] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                        }
-                    }
-                }
-            }
             // X first, weights after: the X fragments are L2 hits and complete first, so (in-order vmcnt) the MFMAs of round
             // r only wait for rounds <= r while later rounds are still streaming in from HBM.  (Weights-first was measured
             // and is slower: issuing is throttled by the CU's memory pipeline either way, and X then lands last.)
@@ -294,22 +436,78 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
             // streamed (not single-shot) quantised weights: a ring of RD rounds in flight per wave.  With only cur/nxt
             // (one round ahead) a wave's K slice is a serial chain of memory latencies — 6 rounds x ~0.9 us at T = 1
             // (scripts/trace_gemm.py); fp16 rounds are twice the registers and stay at one round ahead.
-            constexpr int RD = (!SHOT && FMT != W_F16) ? ((NT == 2 || HILO) ? 2 : 4) : 1;
+            constexpr int RD = (!SHOT && FMT != W_F16) ? ((NT == 2 || HILO || LNP) ? 2 : 4) : 1;
             WRound<FMT> ring[RD];
             const bool ringed = RD > 1 && nsub == SUB;
-            if constexpr (SHOT) {
-                // single shot: every weight tile of this wave is in flight before the first MFMA (host: spb * SUB <= MAXR)
+            auto load_x = [&]() {
 #pragma unroll
-                for (int r = 0; r < MAXR; ++r) {
-                    const int s = r / SUB, sub = r % SUB;
-                    if (s < nstrip && sub < nsub) load_round<FMT, TAIL>(w[r], P, strip0 + s, k0 + sub * RK, kend, true, lane);
+                for (int nt = 0; nt < NT; ++nt) {
+                    // token tile of this n-tile (clamped: results of tiles / lanes beyond T are never stored); lanes beyond the
+                    // step's last token re-read its 16 B so a T = 1 step still moves 64 B per k-step, not 1 KiB
+                    const int tile = min((t0 >> 4) + nt, (L.T - 1) >> 4);
+                    const int tl = min(lane & 15, L.T - 1 - tile * 16);
+                    const long xo = ((long)tile * (P.ldx >> 5) + (k0 >> 5)) * 512 + ((lane >> 4) * 16 + tl) * 8;
+                    const _Float16 *ph = P.xhi + xo;
+                    const _Float16 *pl = HILO ? P.xlo + xo : nullptr;
+#pragma unroll
+                    for (int sub = 0; sub < SUB; ++sub) {
+                        if (TAIL || sub < nsub) {                      // one uniform branch per 256-k round
+#pragma unroll
+                            for (int k8 = 0; k8 < RS; ++k8) {
+                                const int ks = sub * RS + k8;
+                                const bool in = !TAIL || (k0 + ks * 32 < kend);
+                                xb[nt][ks] = in ? *(const f16x8 *)(ph + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                                if constexpr (HILO) xl[nt][ks] = in ? *(const f16x8 *)(pl + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                            }
+                        } else {
+#pragma unroll
+                            for (int k8 = 0; k8 < RS; ++k8) {
+                                xb[nt][sub * RS + k8] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                                if constexpr (HILO) xl[nt][sub * RS + k8] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                            }
+                        }
+                    }
                 }
-            } else if (ringed) {
+            };
+            auto issue_w = [&]() {
+                if constexpr (SHOT) {
+                    // single shot: every weight tile of this wave is in flight before the first MFMA (host: spb * SUB <= MAXR)
 #pragma unroll
-                for (int j = 0; j < RD; ++j)
-                    if (j < nround) load_round<FMT, TAIL>(ring[j], P, strip0 + j / SUB, k0 + (j % SUB) * RK, kend, true, lane);
+                    for (int r = 0; r < MAXR; ++r) {
+                        const int s = r / SUB, sub = r % SUB;
+                        if (s < nstrip && sub < nsub) load_round<FMT, TAIL>(w[r], P, strip0 + s, k0 + sub * RK, kend, true, lane);
+                    }
+                } else if (ringed) {
+#pragma unroll
+                    for (int j = 0; j < RD; ++j)
+                        if (j < nround) load_round<FMT, TAIL>(ring[j], P, strip0 + j / SUB, k0 + (j % SUB) * RK, kend, true, lane);
+                } else {
+                    load_round<FMT, TAIL>(cur, P, strip0, k0, kend, true, lane);
+                }
+            };
+            if constexpr (LNP) {
+                // LayerNorm prologue launch: row loads, then this wave's weights (holding both in flight at once does not
+                // fit the register file), then the reductions; the B fragments come from the prologue's LDS image.
+                // One slice per wave, one 16-token tile (host checks).
+                float *xx_l = (float *)(smem + (size_t)L.lds_items * NT * 64 * 16);
+                const int ldl = L.lnp.C + LNP_PAD;
+                float *pv_l = xx_l + L.T * ldl, *lred = pv_l + L.T * ldl;
+                _Float16 *op_l = (_Float16 *)(lred + 64);
+                LnCarry carry;
+                ln_prologue_load(L.lnp, L.T, xx_l, pv_l, lred, blockIdx.x == 0, carry);
+                issue_w();                                     // the weights fly while the rows are reduced and normalised
+                ln_prologue_finish<HILO>(L.lnp, L.T, P.lnp_mu, xx_l, pv_l, op_l, lred, blockIdx.x == 0, carry);
+                const int tl = min(lane & 15, L.T - 1);
+                const _Float16 *oph = op_l + lnp_op_off(L.T, k0 + (lane >> 4) * 8, tl);
+#pragma unroll
+                for (int ks = 0; ks < KSW; ++ks) {
+                    const bool in = !TAIL || (k0 + ks * 32 < kend);
+                    xb[0][ks] = in ? *(const f16x8 *)(oph + (size_t)ks * 4 * L.T * 8) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if constexpr (HILO) xl[0][ks] = in ? *(const f16x8 *)(oph + (size_t)L.T * L.lnp.C + (size_t)ks * 4 * L.T * 8) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                }
             } else {
-                load_round<FMT, TAIL>(cur, P, strip0, k0, kend, true, lane);
+                load_x();
+                issue_w();
             }
 #ifdef RWKV_TRACE
             TRACE_PT(1);
@@ -422,16 +620,20 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
     TRACE_PT(4);
 }
 
-template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL>
+template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, bool LNP>
 __global__ __launch_bounds__((KSW == 16 ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES) * 64) void gemm_kernel(const GemmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((int)blockIdx.x >= L.total_blocks) {                      // the extra block of a launch that carries a commit
+        shift_commit(L.commit);
+        return;
+    }
     int pi = 0;
     for (int i = 1; i < L.nprob; ++i)
         if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
     const GemmProb &P = L.p[pi];
-    if (P.fmt == W_F16) gemm_body<NT, KSW, HILO, SHOT, TAIL, W_F16>(L, P, smem);
-    else if (P.fmt == W_INT8) gemm_body<NT, KSW, HILO, SHOT, false, W_INT8>(L, P, smem);   // quantised K is a multiple of 256
-    else gemm_body<NT, KSW, HILO, SHOT, false, W_NF4>(L, P, smem);
+    if (P.fmt == W_F16) gemm_body<NT, KSW, HILO, SHOT, TAIL, W_F16, LNP>(L, P, smem);
+    else if (P.fmt == W_INT8) gemm_body<NT, KSW, HILO, SHOT, false, W_INT8, LNP>(L, P, smem);   // quantised K is a multiple of 256
+    else gemm_body<NT, KSW, HILO, SHOT, false, W_NF4, LNP>(L, P, smem);
 }
 
 int gemm_variant_max_waves(int KSW) { return KSW == 16 ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES; }
@@ -446,22 +648,23 @@ void gemm_variant(int T, bool hilo, int &NT, int &KSW) {
 void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
     int NT, KSW;
     gemm_variant(L.T, hilo, NT, KSW);
-    const size_t lds = (size_t)L.lds_items * NT * 64 * 16;
-    dim3 grid(L.total_blocks), block(L.threads);
+    const bool lnp = L.lnp.x_in != nullptr;                   // host: only for the (NT 1, KSW 16, !hilo) variant, see plan_gemm
+    const size_t lds = (size_t)L.lds_items * NT * 64 * 16 + (lnp ? lnp_lds_bytes(L.T, L.lnp.C, hilo) : 0);
+    dim3 grid(L.total_blocks + (L.commit.src ? 1 : 0)), block(L.threads);
     static bool attr_done[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
-#define GEMM_V3(X, sh, tl) X(1, 8, true, sh, tl) X(1, 16, false, sh, tl) X(2, 8, false, sh, tl) X(1, 8, false, sh, tl)
+#define GEMM_V3(X, sh, tl) X(1, 8, true, sh, tl, false) X(1, 16, false, sh, tl, false) X(2, 8, false, sh, tl, false) X(1, 8, false, sh, tl, false) X(1, 16, false, sh, tl, true)
 #define GEMM_VARIANTS(X) GEMM_V3(X, true, true) GEMM_V3(X, true, false) GEMM_V3(X, false, true) GEMM_V3(X, false, false)
     if (!attr_done[dev & 15]) {                               // allow > 64 KiB dynamic LDS (gfx950: 160 KiB / CU)
         const int cap = 160 * 1024;
-#define SET_ATTR(a, b, c, d, e) (void)hipFuncSetAttribute((const void *)gemm_kernel<a, b, c, d, e>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+#define SET_ATTR(a, b, c, d, e, f) (void)hipFuncSetAttribute((const void *)gemm_kernel<a, b, c, d, e, f>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         GEMM_VARIANTS(SET_ATTR)
 #undef SET_ATTR
         attr_done[dev & 15] = true;
     }
     const bool shot = L.single_shot != 0, tail = L.tail != 0;
-#define LAUNCH(a, b, c, d, e) if (NT == a && KSW == b && hilo == c && shot == d && tail == e) hipLaunchKernelGGL((gemm_kernel<a, b, c, d, e>), grid, block, lds, s, L);
+#define LAUNCH(a, b, c, d, e, f) if (NT == a && KSW == b && hilo == c && shot == d && tail == e && lnp == f) hipLaunchKernelGGL((gemm_kernel<a, b, c, d, e, f>), grid, block, lds, s, L);
     GEMM_VARIANTS(LAUNCH)
 #undef LAUNCH
 #undef GEMM_VARIANTS
@@ -480,7 +683,7 @@ __device__ __forceinline__ void store_operand4(_Float16 *__restrict__ hi, _Float
 // apply tanh and keep m_c in LDS as the f16 (hi, lo) operand; then wave w multiplies strip w of W2_c (K = Dm)
 // with it and applies the lerp epilogue, emitting the five GEMM operands.
 // =====================================================================================
-template <int NT, bool HILO, int DS>
+template <int NT, bool HILO, int DS, bool LNP>
 __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -507,12 +710,34 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
 #pragma unroll
     for (int ks = 0; ks < DS / 2; ++ks) w2t[ks] = ((const u32x4 *)a.W2[c])[((long)strip_c * (DS / 2) + ks) * 64 + lane];
     const float4 mu = *(const float4 *)(a.mu[c] + row0);
+    // LNP (single-token steps): LayerNorm + token shift are redone here by every block (ln_prologue_*): z arrives in LDS in
+    // fragment order, xx and dx for the epilogue come from the prologue's LDS rows
+    float *xx_l = (float *)(m_lo + NT * 16 * mstride);
+    const int ldl = C + LNP_PAD;
+    float *pv_l = xx_l + LNP_MAX_T * ldl, *lred = pv_l + LNP_MAX_T * ldl;
+    _Float16 *z_l = (_Float16 *)(lred + 64);
+    if constexpr (LNP) {
+        LnCarry carry;
+        const bool pub = blockIdx.x == 0 && blockIdx.y == 0;
+        ln_prologue_load(a.lnp, T, xx_l, pv_l, lred, pub, carry);
+        ln_prologue_finish<HILO>(a.lnp, T, a.mu_x, xx_l, pv_l, z_l, lred, pub, carry);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        int t = nt * 16 + (lane & 15);
-        t = t < T ? t : T - 1;
-        xxv[nt] = *(const float4 *)(a.xx + (long)t * C + row0);
-        dxv[nt] = *(const float4 *)(a.dx + (long)t * C + row0);
+        for (int nt = 0; nt < NT; ++nt) {
+            const int t = min(nt * 16 + (lane & 15), T - 1);
+            const float4 x = *(const float4 *)(xx_l + t * ldl + row0);
+            const float4 pr = carry.prev[t < LNP_MAX_T ? t : 0] >= 0 ? *(const float4 *)(xx_l + carry.prev[t < LNP_MAX_T ? t : 0] * ldl + row0)
+                                                                      : *(const float4 *)(pv_l + t * ldl + row0);
+            xxv[nt] = x;
+            dxv[nt] = make_float4(pr.x - x.x, pr.y - x.y, pr.z - x.z, pr.w - x.w);
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            int t = nt * 16 + (lane & 15);
+            t = t < T ? t : T - 1;
+            xxv[nt] = *(const float4 *)(a.xx + (long)t * C + row0);
+            dxv[nt] = *(const float4 *)(a.dx + (long)t * C + row0);
+        }
     }
     // ---- phase 1: partial m_c over this wave's K slice
     f32x4 acc[DS][NT];
@@ -533,9 +758,14 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
                 for (int nt = 0; nt < NT; ++nt) {
                     const int tile = min(nt, (T - 1) >> 4);
                     const int tl = min(lane & 15, T - 1 - tile * 16);
-                    const long zo = ((long)tile * (a.ldz >> 5) + kt) * 512 + ((lane >> 4) * 16 + tl) * 8;
-                    zb[j][nt] = *(const f16x8 *)(a.zhi + zo);
-                    if constexpr (HILO) zl[j][nt] = *(const f16x8 *)(a.zlo + zo);
+                    if constexpr (LNP) {
+                        zb[j][nt] = *(const f16x8 *)(z_l + lnp_op_off(T, kt * 32 + (lane >> 4) * 8, tl));
+                        if constexpr (HILO) zl[j][nt] = *(const f16x8 *)(z_l + (size_t)T * C + lnp_op_off(T, kt * 32 + (lane >> 4) * 8, tl));
+                    } else {
+                        const long zo = ((long)tile * (a.ldz >> 5) + kt) * 512 + ((lane >> 4) * 16 + tl) * 8;
+                        zb[j][nt] = *(const f16x8 *)(a.zhi + zo);
+                        if constexpr (HILO) zl[j][nt] = *(const f16x8 *)(a.zlo + zo);
+                    }
                 }
 #pragma unroll
                 for (int d = 0; d < DS; ++d) wt[j][d] = w1[((long)(c * DS + d) * KT1 + kt) * 64 + lane];
@@ -613,13 +843,26 @@ bool v6_mix_supported(int T, int C, int Dm) { return T <= 32 && C % 256 == 0 && 
 
 void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
     const int NT = a.T <= 16 ? 1 : 2;
-    const size_t lds = (size_t)8 * 4 * NT * 64 * 16 + (size_t)2 * NT * 16 * (a.Dm + 8) * 2;
+    const bool lnp = a.lnp.x_in != nullptr;                    // host: T <= LNP_MAX_T, !hilo, C <= 4096 (v6_mix_ln_supported)
+    const size_t lds = (size_t)8 * 4 * NT * 64 * 16 + (size_t)2 * NT * 16 * (a.Dm + 8) * 2 + (lnp ? lnp_lds_bytes(LNP_MAX_T, a.C, hilo) : 0);
     dim3 grid((a.C / 16 + 7) / 8, 5), block(512);
-#define V6L(nt, h, ds) hipLaunchKernelGGL((v6_mix_kernel<nt, h, ds>), grid, block, lds, s, a)
+    static bool attr_done[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_done[dev & 15]) {
+        (void)hipFuncSetAttribute((const void *)v6_mix_kernel<1, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)v6_mix_kernel<1, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done[dev & 15] = true;
+    }
+#define V6L(nt, h, ds, ln) hipLaunchKernelGGL((v6_mix_kernel<nt, h, ds, ln>), grid, block, lds, s, a)
     const int DS = a.Dm >> 4;
-    if (hilo) { if (NT == 1) { if (DS == 2) V6L(1, true, 2); else V6L(1, true, 4); } else { if (DS == 2) V6L(2, true, 2); else V6L(2, true, 4); } }
-    else      { if (NT == 1) { if (DS == 2) V6L(1, false, 2); else V6L(1, false, 4); } else { if (DS == 2) V6L(2, false, 2); else V6L(2, false, 4); } }
+    if (lnp) { if (DS == 2) V6L(1, false, 2, true); else V6L(1, false, 4, true); }
+    else if (hilo) { if (NT == 1) { if (DS == 2) V6L(1, true, 2, false); else V6L(1, true, 4, false); } else { if (DS == 2) V6L(2, true, 2, false); else V6L(2, true, 4, false); } }
+    else      { if (NT == 1) { if (DS == 2) V6L(1, false, 2, false); else V6L(1, false, 4, false); } else { if (DS == 2) V6L(2, false, 2, false); else V6L(2, false, 4, false); } }
 #undef V6L
+}
+bool v6_mix_ln_supported(int T, int C, int Dm, bool hilo, int np) {
+    return v6_mix_supported(T, C, Dm) && T <= LNP_MAX_T && !hilo && np <= LNP_MAX_NP && C <= 8 * 512;
 }
 
 // =====================================================================================
