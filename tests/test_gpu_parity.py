@@ -427,3 +427,27 @@ def test_on_device_nucleus_sampling_matches_reference_sampler():
     _, sm = eng.infer_sample(inp, [g, None, None], [0.99, 0.0, 0.0])
     assert sm[0][0] == int(np.argmax(outs[0][-1])) and sm[1] is None
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["v5-small", "v6-small", "v7-small"])
+def test_single_token_steps_with_ln_prologue_interleave_with_chunks(name):
+    """T = 1 steps run LayerNorm + token shift as a prologue of the consuming kernel and commit the shift state in
+    the following launch; multi-token steps use the row kernel.  Alternating the two on a non-zero slot must give the
+    oracle's logits at every step and its state at the end (Fp16 mode: the fused path is only taken there)."""
+    t, eng = build(name, rt.Precision.Fp16, B=3, chunk=8)
+    ref = R.RwkvRef(t)
+    p = prompt(ref, 11, 9)
+    sw = ref.init_state()
+    want = ref.forward(p, sw, full=True)
+    cuts = [1, 3, 1, 1, 2, 1]                                   # 9 tokens
+    pos, slot = 0, 2
+    for n in cuts:
+        inp = rt.RnnInput([rt.RnnInputBatch(p[pos:pos + n] if b == slot else [], rt.RnnOption.Last) for b in range(3)])
+        inp, outs = eng.infer(inp)
+        assert inp.num_token() == 0
+        pos += n
+        got = outs[slot][-1]
+        assert np.abs(got - want[pos - 1]).max() <= tol(rt.Precision.Fp16, want[pos - 1])
+    st = eng.state.back(slot)
+    assert np.abs(st - sw).max() <= tol(rt.Precision.Fp16, sw)
+    eng.close()
