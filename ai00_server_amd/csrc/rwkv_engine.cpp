@@ -888,7 +888,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token) {
             k.v_first = vfirst; k.layer = l;
             k.lnx_w = w.lnxw; k.lnx_b = w.lnxb;
             k.yhi = opY.hi; k.ylo = opY.lo; k.ldh = C;
-            launch(FAM_WKV, [&] { launch_wkv(k, s_main); });
+            launch(FAM_WKV, [&] { launch_wkv(k, T > n_seq, s_main); });
         }
         {
             ProbSpec s = prob(w.Wo, opY, ACT_NONE, P, C);

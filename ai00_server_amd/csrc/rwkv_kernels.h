@@ -202,7 +202,7 @@ struct WkvArgs {
     _Float16 *yhi, *ylo;
     int ldh;
 };
-void launch_wkv(const WkvArgs &a, hipStream_t s);
+void launch_wkv(const WkvArgs &a, bool multi_row, hipStream_t s);   // multi_row: some sequence has > 1 row in this step
 
 // ---- state slab <-> internal layout ---------------------------------------------------
 struct StatePackArgs {

@@ -54,10 +54,33 @@ __device__ __forceinline__ long opd_off(int t, int k, int ld) {
     return ((long)(t >> 4) * (ld >> 5) + (k >> 5)) * 512 + ((((k >> 3) & 3) << 4) + (t & 15)) * 8 + (k & 7);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+// Cross-lane sums on the DPP path (v_add_f32 with a dpp source modifier, a few cycles each) instead of `__shfl_xor`,
+// which hipcc lowers to ds_bpermute_b32 — an LDS-crossbar round trip per step, and these reductions sit on the
+// per-token critical path of the WKV recurrence and of every LayerNorm.  All lanes of the wave must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15); every lane of the row gets the result
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_f32<0xB1>(v);                                   // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);                                   // quad_perm [2,3,0,1]
+    v += dpp_f32<0x124>(v);                                  // row_ror:4
+    v += dpp_f32<0x128>(v);                                  // row_ror:8
     return v;
+}
+// sum over the 4 lanes of a quad; every lane of the quad gets the result
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row_sum16(v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48)));
 }
 
 // block-wide sum over 256 threads; `red` is >= 4 floats of LDS.  All threads get the result.
@@ -1321,15 +1344,13 @@ void launch_ln_out(const LnOutArgs &a, int n_out, hipStream_t s) { ROW_DISPATCH(
 //   v7   : sa_p = sum_q T_pq (-kk_q) ; T_pq <- T_pq w_q + sa_p (kk_q a_q) + v_p k_q ; out_p = sum_q T_pq r_q
 // followed by GroupNorm over the head (eps 64e-5), gate, and (v7) the r.k.r_k bonus.
 // =====================================================================================
-__device__ __forceinline__ float sum16(float v) {       // reduce across the 16 lanes sharing (tid>>4)
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    return v;
-}
+__device__ __forceinline__ float sum16(float v) { return row_sum16(v); }   // the 16 lanes sharing (tid>>4) are one DPP row
 
-__global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {   // <= 102 VGPRs: 5 blocks per CU = 1280 (B=32 x 40 heads) in one generation
+// PIPE = false (decode, one row per sequence): <= 102 VGPRs, 5 blocks per CU = 1280 (B=32 x 40 heads) in one generation.
+// PIPE = true (a sequence has several rows): the next row's inputs are fetched while the current row is computed — the
+// per-token chain was one L2/MALL round trip (~1 us) per token — and V6's D2 rows (loop-invariant) stay in registers.
+template <bool PIPE>
+__global__ __launch_bounds__(256, PIPE ? 2 : 5) void wkv_kernel(const WkvArgs a) {
     __shared__ __attribute__((aligned(16))) float sh_r[64], sh_k[64], sh_v[64], sh_w[64], sh_u[64], sh_kk[64], sh_ka[64];
     __shared__ float sh_out[64];
     const int seq = blockIdx.x, h = blockIdx.y;
@@ -1358,11 +1379,58 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {   // <= 
     const int per = a.Dd >> 2;
     const float decay0 = a.version == 6 ? a.wdec_or_decay[cb + ch] : 0.f;
 
+    struct Row { float r, k, v, gt, av, vg, w7, vf; float4 td[8]; };
+    auto issue_row = [&](int t, Row &x) {                    // loads only (PIPE): consumed one iteration later
+        const long rb = (long)t * C + cb;
+        x.r = x.k = x.v = x.gt = x.av = x.vg = x.w7 = x.vf = 0.f;
+        if (tid < 64) {
+            x.r = a.r[rb + tid]; x.k = a.k[rb + tid]; x.v = a.v[rb + tid]; x.gt = a.g[rb + tid];
+            if (a.version == 7) {
+                x.av = a.a7[rb + tid]; x.w7 = a.w7[rb + tid];
+                if (a.layer != 0) { x.vg = a.vg7[rb + tid]; x.vf = a.v_first[rb + tid]; }
+            }
+        }
+        if (a.version == 6) {
+            const float *tdp = a.td + (long)t * a.Dd + part * per;
+#pragma unroll
+            for (int d4 = 0; d4 < 8; ++d4)
+                if (d4 * 4 < per) x.td[d4] = *(const float4 *)(tdp + d4 * 4);
+        }
+    };
+    f16x8 d2r[4];
+    Row cur, nxt;
+    const bool pipe_ok = PIPE && per <= 32;                  // Dd <= 128: D2 slice and td slice fit the register budget
+    if (PIPE) {
+        if (a.version == 6 && pipe_ok) {
+            const _Float16 *d2 = a.D2 + (long)(cb + ch) * a.Dd + part * per;
+#pragma unroll
+            for (int d8 = 0; d8 < 4; ++d8)
+                if (d8 * 8 < per) d2r[d8] = *(const f16x8 *)(d2 + d8 * 8);
+        }
+        if (pipe_ok && nrow > 0) issue_row(row0, cur);
+    }
+
     for (int it = 0; it < nrow; ++it) {
         const int t = row0 + it;
         const long rb = (long)t * C + cb;
-        // ---- issue every global load of this token before the first barrier
         float r = 0.f, k = 0.f, v = 0.f, gt = 0.f, av = 0.f, vg = 0.f, w7 = 0.f, vf = 0.f;
+        float dsum = 0.f;
+        if (PIPE && pipe_ok) {
+            if (it + 1 < nrow) issue_row(t + 1, nxt);
+            r = cur.r; k = cur.k; v = cur.v; gt = cur.gt; av = cur.av; vg = cur.vg; w7 = cur.w7; vf = cur.vf;
+            if (a.version == 6) {
+#pragma unroll
+                for (int d8 = 0; d8 < 4; ++d8)
+                    if (d8 * 8 < per) {
+                        const f16x8 wv = d2r[d8];
+                        const float4 t0v = cur.td[2 * d8], t1v = cur.td[2 * d8 + 1];
+                        dsum += (float)wv[0] * t0v.x + (float)wv[1] * t0v.y + (float)wv[2] * t0v.z + (float)wv[3] * t0v.w +
+                                (float)wv[4] * t1v.x + (float)wv[5] * t1v.y + (float)wv[6] * t1v.z + (float)wv[7] * t1v.w;
+                    }
+                dsum = quad_sum(dsum);
+            }
+        } else {
+        // ---- issue every global load of this token before the first barrier
         if (tid < 64) {
             r = a.r[rb + tid]; k = a.k[rb + tid]; v = a.v[rb + tid]; gt = a.g[rb + tid];
             if (a.version == 7) {
@@ -1370,7 +1438,6 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {   // <= 
                 if (a.layer != 0) { vg = a.vg7[rb + tid]; vf = a.v_first[rb + tid]; }
             }
         }
-        float dsum = 0.f;
         if (a.version == 6) {
             // decay LoRA stage 2: d_c = time_decay_c + sum_d D2[c][d] td[d];  w = exp(-exp(d))
             const _Float16 *d2 = a.D2 + (long)(cb + ch) * a.Dd + part * per;
@@ -1381,8 +1448,8 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {   // <= 
                 dsum += (float)wv[0] * t0v.x + (float)wv[1] * t0v.y + (float)wv[2] * t0v.z + (float)wv[3] * t0v.w +
                         (float)wv[4] * t1v.x + (float)wv[5] * t1v.y + (float)wv[6] * t1v.z + (float)wv[7] * t1v.w;
             }
-            dsum += __shfl_xor(dsum, 1, 64);
-            dsum += __shfl_xor(dsum, 2, 64);
+            dsum = quad_sum(dsum);
+        }
         }
         TRACE_K(1, 1);
         __syncthreads();                                   // previous iteration's LDS readers done
@@ -1461,14 +1528,16 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {   // <= 
             a.yhi[yo] = hh;
             if (a.ylo) a.ylo[yo] = ll;
         }
+        if (PIPE) cur = nxt;
     }
     TRACE_K(1, 4);
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, T[aa]), (f32x4 *)(st + (aa * 16 + ig) * 64 + jg * 4));
     TRACE_K(1, 5);
 }
-void launch_wkv(const WkvArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(wkv_kernel, dim3(a.n_seq, a.H), dim3(256), 0, s, a);
+void launch_wkv(const WkvArgs &a, bool multi_row, hipStream_t s) {
+    if (multi_row) hipLaunchKernelGGL(wkv_kernel<true>, dim3(a.n_seq, a.H), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(wkv_kernel<false>, dim3(a.n_seq, a.H), dim3(256), 0, s, a);
 }
 
 // =====================================================================================
