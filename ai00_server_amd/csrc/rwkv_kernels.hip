@@ -1346,11 +1346,9 @@ void launch_ln_out(const LnOutArgs &a, int n_out, hipStream_t s) { ROW_DISPATCH(
 // =====================================================================================
 __device__ __forceinline__ float sum16(float v) { return row_sum16(v); }   // the 16 lanes sharing (tid>>4) are one DPP row
 
-// PIPE = false (decode, one row per sequence): <= 102 VGPRs, 5 blocks per CU = 1280 (B=32 x 40 heads) in one generation.
-// PIPE = true (a sequence has several rows): the next row's inputs are fetched while the current row is computed — the
-// per-token chain was one L2/MALL round trip (~1 us) per token — and V6's D2 rows (loop-invariant) stay in registers.
-template <bool PIPE>
-__global__ __launch_bounds__(256, PIPE ? 2 : 5) void wkv_kernel(const WkvArgs a) {
+// Decode form (one row per sequence; also correct for several): <= 102 VGPRs, 5 blocks per CU = 1280 (B=32 x 40 heads)
+// in one generation.  Steps in which a sequence has several rows use wkv_chunk_kernel below.
+__global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
     __shared__ __attribute__((aligned(16))) float sh_r[64], sh_k[64], sh_v[64], sh_w[64], sh_u[64], sh_kk[64], sh_ka[64];
     __shared__ float sh_out[64];
     const int seq = blockIdx.x, h = blockIdx.y;
@@ -1379,57 +1377,11 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 5) void wkv_kernel(const WkvArgs a)
     const int per = a.Dd >> 2;
     const float decay0 = a.version == 6 ? a.wdec_or_decay[cb + ch] : 0.f;
 
-    struct Row { float r, k, v, gt, av, vg, w7, vf; float4 td[8]; };
-    auto issue_row = [&](int t, Row &x) {                    // loads only (PIPE): consumed one iteration later
-        const long rb = (long)t * C + cb;
-        x.r = x.k = x.v = x.gt = x.av = x.vg = x.w7 = x.vf = 0.f;
-        if (tid < 64) {
-            x.r = a.r[rb + tid]; x.k = a.k[rb + tid]; x.v = a.v[rb + tid]; x.gt = a.g[rb + tid];
-            if (a.version == 7) {
-                x.av = a.a7[rb + tid]; x.w7 = a.w7[rb + tid];
-                if (a.layer != 0) { x.vg = a.vg7[rb + tid]; x.vf = a.v_first[rb + tid]; }
-            }
-        }
-        if (a.version == 6) {
-            const float *tdp = a.td + (long)t * a.Dd + part * per;
-#pragma unroll
-            for (int d4 = 0; d4 < 8; ++d4)
-                if (d4 * 4 < per) x.td[d4] = *(const float4 *)(tdp + d4 * 4);
-        }
-    };
-    f16x8 d2r[4];
-    Row cur, nxt;
-    const bool pipe_ok = PIPE && per <= 32;                  // Dd <= 128: D2 slice and td slice fit the register budget
-    if (PIPE) {
-        if (a.version == 6 && pipe_ok) {
-            const _Float16 *d2 = a.D2 + (long)(cb + ch) * a.Dd + part * per;
-#pragma unroll
-            for (int d8 = 0; d8 < 4; ++d8)
-                if (d8 * 8 < per) d2r[d8] = *(const f16x8 *)(d2 + d8 * 8);
-        }
-        if (pipe_ok && nrow > 0) issue_row(row0, cur);
-    }
-
     for (int it = 0; it < nrow; ++it) {
         const int t = row0 + it;
         const long rb = (long)t * C + cb;
         float r = 0.f, k = 0.f, v = 0.f, gt = 0.f, av = 0.f, vg = 0.f, w7 = 0.f, vf = 0.f;
         float dsum = 0.f;
-        if (PIPE && pipe_ok) {
-            if (it + 1 < nrow) issue_row(t + 1, nxt);
-            r = cur.r; k = cur.k; v = cur.v; gt = cur.gt; av = cur.av; vg = cur.vg; w7 = cur.w7; vf = cur.vf;
-            if (a.version == 6) {
-#pragma unroll
-                for (int d8 = 0; d8 < 4; ++d8)
-                    if (d8 * 8 < per) {
-                        const f16x8 wv = d2r[d8];
-                        const float4 t0v = cur.td[2 * d8], t1v = cur.td[2 * d8 + 1];
-                        dsum += (float)wv[0] * t0v.x + (float)wv[1] * t0v.y + (float)wv[2] * t0v.z + (float)wv[3] * t0v.w +
-                                (float)wv[4] * t1v.x + (float)wv[5] * t1v.y + (float)wv[6] * t1v.z + (float)wv[7] * t1v.w;
-                    }
-                dsum = quad_sum(dsum);
-            }
-        } else {
         // ---- issue every global load of this token before the first barrier
         if (tid < 64) {
             r = a.r[rb + tid]; k = a.k[rb + tid]; v = a.v[rb + tid]; gt = a.g[rb + tid];
@@ -1449,7 +1401,6 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 5) void wkv_kernel(const WkvArgs a)
                         (float)wv[4] * t1v.x + (float)wv[5] * t1v.y + (float)wv[6] * t1v.z + (float)wv[7] * t1v.w;
             }
             dsum = quad_sum(dsum);
-        }
         }
         TRACE_K(1, 1);
         __syncthreads();                                   // previous iteration's LDS readers done
@@ -1528,16 +1479,194 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 5) void wkv_kernel(const WkvArgs a)
             a.yhi[yo] = hh;
             if (a.ylo) a.ylo[yo] = ll;
         }
-        if (PIPE) cur = nxt;
     }
     TRACE_K(1, 4);
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, T[aa]), (f32x4 *)(st + (aa * 16 + ig) * 64 + jg * 4));
     TRACE_K(1, 5);
 }
+
+// =====================================================================================
+// WKV for steps in which a sequence has several rows (prefill chunks).  Same arithmetic as wkv_kernel, re-ordered so
+// that nothing but the recurrence itself is sequential.  Per chunk of WKV_CH tokens of the block's (slot, head):
+//   A (parallel over tokens, one wave per token): r/k/v loads, the decay  w = exp(-exp(decay + D2 td))  (V6), V7's
+//     kappa normalisation / k, v transforms  ->  LDS rows;
+//   B (sequential over tokens, NO barrier, NO global access): state update and output from LDS rows, 16-lane DPP sums,
+//     raw head outputs -> LDS;
+//   C (parallel over tokens): GroupNorm over the head, bonus (V7), gate, operand emit.
+// The per-token chain of the decode kernel (3 barriers, an L2 round trip, two exp, three wave reductions: ~1.5 us) shrinks
+// to ~20 LDS reads + 48 FMAs + 16 DPP adds.
+// =====================================================================================
+constexpr int WKV_CH = 32;                               // tokens per chunk: 8 per wave in the parallel phases
+constexpr int WKV_MAX_DD = 128;                          // V6 decay LoRA width held in registers (all released models: 64 / 128)
+template <int DD>
+__device__ __forceinline__ float wkv_decay_dot(const f16x8 (&d2r)[WKV_MAX_DD / 8], const float *tdl) {
+    constexpr int PER8 = DD / 32;
+    float ps[4];
+#pragma unroll
+    for (int part = 0; part < 4; ++part) {
+        float dsum = 0.f;
+#pragma unroll
+        for (int g8 = 0; g8 < PER8; ++g8) {
+            const int d8 = part * PER8 + g8;
+            const f16x8 wv = d2r[d8];
+            const float4 t0v = *(const float4 *)(tdl + d8 * 8), t1v = *(const float4 *)(tdl + d8 * 8 + 4);
+            dsum += (float)wv[0] * t0v.x + (float)wv[1] * t0v.y + (float)wv[2] * t0v.z + (float)wv[3] * t0v.w +
+                    (float)wv[4] * t1v.x + (float)wv[5] * t1v.y + (float)wv[6] * t1v.z + (float)wv[7] * t1v.w;
+        }
+        ps[part] = dsum;
+    }
+    return (ps[0] + ps[1]) + (ps[2] + ps[3]);
+}
+__global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_r[WKV_CH][64], s_k[WKV_CH][64], s_v[WKV_CH][64], s_w[WKV_CH][64];
+    __shared__ __attribute__((aligned(16))) float s_kk[WKV_CH][64], s_ka[WKV_CH][64], s_o[WKV_CH][64];
+    __shared__ __attribute__((aligned(16))) float s_u[64];
+    float *s_td = &s_kk[0][0];                           // V6: td rows of the chunk [WKV_CH][Dd] (s_kk + s_ka are V7-only)
+    const int seq = blockIdx.x, h = blockIdx.y;
+    const int tid = threadIdx.x, ig = tid >> 4, jg = tid & 15, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = a.seq_slot[seq], row0 = a.seq_begin[seq], nrow = a.seq_len[seq];
+    const int C = a.C, cb = h * 64, Dd = a.Dd;
+    float *st = a.state + (long)slot * a.slot_stride + (long)h * 4096;
+    float4 T[4];
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) T[aa] = __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4 *)(st + (aa * 16 + ig) * 64 + jg * 4)));
+    if (a.version != 7 && tid < 64) s_u[tid] = a.u[cb + tid];
+    // per-channel parameters (channel = lane in phases A and C)
+    const float lnw = a.lnx_w[cb + lane], lnb = a.lnx_b[cb + lane];
+    float kk_p = 0.f, ka_p = 0.f, rk_p = 0.f, wconst = 0.f, decay0 = 0.f;
+    if (a.version == 7) { kk_p = a.k_k[cb + lane]; ka_p = a.k_a[cb + lane]; rk_p = a.r_k[cb + lane]; }
+    if (a.version == 5) wconst = a.wdec_or_decay[cb + lane];
+    f16x8 d2r[WKV_MAX_DD / 8];                           // V6: this channel's row of D2 (loop-invariant)
+    if (a.version == 6) {
+        decay0 = a.wdec_or_decay[cb + lane];
+        const _Float16 *d2 = a.D2 + (long)(cb + lane) * Dd;
+#pragma unroll
+        for (int d8 = 0; d8 < WKV_MAX_DD / 8; ++d8)
+            if (d8 * 8 < Dd) d2r[d8] = *(const f16x8 *)(d2 + d8 * 8);
+    }
+
+    for (int c0 = 0; c0 < nrow; c0 += WKV_CH) {
+        const int n = min(WKV_CH, nrow - c0);
+        // ---- phase A: wave w prepares tokens w, w+4, ... (lane = channel).  A1: every global load of the chunk is issued
+        //      back to back and parked RAW in the LDS rows (a lane only touches its own elements: no barrier);
+        //      A2: a rolled loop transforms the rows in place.
+#pragma unroll
+        for (int i = 0; i < WKV_CH / 4; ++i) {
+            const int tt = wave + 4 * i;
+            if (tt < n) {
+                const long rb = (long)(row0 + c0 + tt) * C + cb + lane;
+                s_r[tt][lane] = a.r[rb]; s_k[tt][lane] = a.k[rb]; s_v[tt][lane] = a.v[rb];
+                if (a.version == 7) {
+                    s_ka[tt][lane] = a.a7[rb]; s_w[tt][lane] = a.w7[rb];
+                    if (a.layer != 0) { s_o[tt][lane] = a.v_first[rb]; s_kk[tt][lane] = a.vg7[rb]; }
+                }
+            }
+        }
+        if (a.version == 6) {                            // td rows of the chunk -> LDS (coalesced), read back as broadcasts
+            const float *tdp = a.td + (long)(row0 + c0) * Dd;
+            for (int i = tid * 4; i < n * Dd; i += 256 * 4) *(float4 *)(s_td + i) = *(const float4 *)(tdp + i);
+            __syncthreads();
+        }
+        for (int tt = wave; tt < n; tt += 4) {
+            if (a.version == 5) {
+                s_w[tt][lane] = wconst;
+            } else if (a.version == 6) {
+                // decay LoRA stage 2 in the decode kernel's order: four partial sums over Dd/4, combined (p0+p1)+(p2+p3)
+                const float *tdl = s_td + tt * Dd;
+                const float dd = Dd == 64 ? wkv_decay_dot<64>(d2r, tdl) : wkv_decay_dot<128>(d2r, tdl);
+                s_w[tt][lane] = expf(-expf(decay0 + dd));
+            } else {
+                const float av = s_ka[tt][lane];
+                float k = s_k[tt][lane], v = s_v[tt][lane];
+                float kk = k * kk_p;
+                const float ss = wave_sum(kk * kk);
+                kk = kk / fmaxf(sqrtf(ss), 1e-12f);
+                k = k * (1.0f + (av - 1.0f) * ka_p);
+                if (a.layer == 0) a.v_first[(long)(row0 + c0 + tt) * C + cb + lane] = v;
+                else v = v + (s_o[tt][lane] - v) * s_kk[tt][lane];
+                s_kk[tt][lane] = -kk;
+                s_ka[tt][lane] = kk * av;
+                s_k[tt][lane] = k; s_v[tt][lane] = v;
+            }
+        }
+        __syncthreads();
+        // ---- phase B: the recurrence; thread (ig, jg) owns T[p = aa*16+ig][q = jg*4 .. +4]
+        float4 uq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.version != 7) uq = *(const float4 *)(s_u + jg * 4);
+        for (int tt = 0; tt < n; ++tt) {
+            const float4 rq = *(const float4 *)(&s_r[tt][jg * 4]);
+            const float4 kq = *(const float4 *)(&s_k[tt][jg * 4]);
+            const float4 wq = *(const float4 *)(&s_w[tt][jg * 4]);
+            float outp[4];
+            if (a.version != 7) {
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa) {
+                    const float vp = s_v[tt][aa * 16 + ig];
+                    float4 &S = T[aa];
+                    float o, kv;
+                    kv = kq.x * vp; o = rq.x * (uq.x * kv + S.x); S.x = kv + wq.x * S.x;
+                    kv = kq.y * vp; o += rq.y * (uq.y * kv + S.y); S.y = kv + wq.y * S.y;
+                    kv = kq.z * vp; o += rq.z * (uq.z * kv + S.z); S.z = kv + wq.z * S.z;
+                    kv = kq.w * vp; o += rq.w * (uq.w * kv + S.w); S.w = kv + wq.w * S.w;
+                    outp[aa] = sum16(o);
+                }
+            } else {
+                const float4 nk = *(const float4 *)(&s_kk[tt][jg * 4]);
+                const float4 ka = *(const float4 *)(&s_ka[tt][jg * 4]);
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa) {
+                    const float vp = s_v[tt][aa * 16 + ig];
+                    float4 &S = T[aa];
+                    float sa = S.x * nk.x + S.y * nk.y + S.z * nk.z + S.w * nk.w;
+                    sa = sum16(sa);
+                    S.x = S.x * wq.x + sa * ka.x + vp * kq.x;
+                    S.y = S.y * wq.y + sa * ka.y + vp * kq.y;
+                    S.z = S.z * wq.z + sa * ka.z + vp * kq.z;
+                    S.w = S.w * wq.w + sa * ka.w + vp * kq.w;
+                    const float o = S.x * rq.x + S.y * rq.y + S.z * rq.z + S.w * rq.w;
+                    outp[aa] = sum16(o);
+                }
+            }
+            if (jg == 0) {
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa) s_o[tt][aa * 16 + ig] = outp[aa];
+            }
+        }
+        __syncthreads();
+        // ---- phase C: GroupNorm over the head (eps 64e-5), bonus (V7), gate, operand emit; wave w takes tokens w, w+4, ...
+#pragma unroll
+        for (int i = 0; i < WKV_CH / 4; ++i) {               // gates of the chunk: loads back to back, parked in s_w (free after B)
+            const int tt = wave + 4 * i;
+            if (tt < n) s_w[tt][lane] = a.g[(long)(row0 + c0 + tt) * C + cb + lane];
+        }
+        for (int tt = wave; tt < n; tt += 4) {
+            const int t = row0 + c0 + tt;
+            const float o = s_o[tt][lane];
+            const float mean = wave_sum(o) * (1.0f / 64.0f);
+            const float d = o - mean;
+            const float var = wave_sum(d * d) * (1.0f / 64.0f);
+            float y = d / sqrtf(var + 64e-5f) * lnw + lnb;
+            if (a.version == 7) {
+                const float bonus = wave_sum(s_r[tt][lane] * s_k[tt][lane] * rk_p);
+                y += bonus * s_v[tt][lane];
+            }
+            y *= s_w[tt][lane];
+            _Float16 hh, ll;
+            split_hilo(y, hh, ll);
+            const long yo = opd_off(t, cb + lane, a.ldh);
+            a.yhi[yo] = hh;
+            if (a.ylo) a.ylo[yo] = ll;
+        }
+        __syncthreads();                                   // the next chunk overwrites the LDS rows
+    }
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, T[aa]), (f32x4 *)(st + (aa * 16 + ig) * 64 + jg * 4));
+}
 void launch_wkv(const WkvArgs &a, bool multi_row, hipStream_t s) {
-    if (multi_row) hipLaunchKernelGGL(wkv_kernel<true>, dim3(a.n_seq, a.H), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(wkv_kernel<false>, dim3(a.n_seq, a.H), dim3(256), 0, s, a);
+    if (multi_row && (a.version != 6 || a.Dd == 64 || a.Dd == 128)) hipLaunchKernelGGL(wkv_chunk_kernel, dim3(a.n_seq, a.H), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(wkv_kernel, dim3(a.n_seq, a.H), dim3(256), 0, s, a);
 }
 
 // =====================================================================================
