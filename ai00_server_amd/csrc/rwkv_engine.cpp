@@ -61,6 +61,57 @@ static rwkv_status guard(F &&f) {
 // ------------------------------------------------------------------------------------------------
 // model info (Loader::info, lib.rs:587)
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Prefab: the loaded (re-tiled / quantised / converted) model as one binary image, so that a later load skips the
+// safetensors parse, the LoRA blend and the GPU re-tile / quantise passes.  Counterpart of `ModelSerialize::serialize`
+// (lib.rs:131-154) and `LoadType::Prefab` (lib.rs:517-553, sniffed at lib.rs:585-588); the reference's CBOR image of
+// web-rwkv's internal tensors is not reproducible here, this is our own versioned format:
+//   header  { char magic[8] "RWKVHIP\0"; u32 version; u32 n_entries; rwkv_model_info info; i32 quant_layers, quant_type; }
+//   entries { u32 kind (0 f32 vector, 1 raw f16, 2 tiled matrix); i32 fmt, rows, K; u32 counted; u32 name_len;
+//             u64 n_elems, data_bytes, scale_bytes; name[name_len]; pad to 16; data; pad to 16; scales; pad to 16 }
+// ------------------------------------------------------------------------------------------------
+static const char kPrefabMagic[8] = {'R', 'W', 'K', 'V', 'H', 'I', 'P', 0};
+constexpr uint32_t kPrefabVersion = 1;
+struct PfEntryHead { uint32_t kind; int32_t fmt, rows, K; uint32_t counted, name_len; uint64_t n_elems, data_bytes, scale_bytes; };
+struct PfHeader { char magic[8]; uint32_t version, n_entries; rwkv_model_info info; int32_t quant_layers, quant_type; };
+struct PfEntry { PfEntryHead h; const uint8_t *data = nullptr, *scales = nullptr; };
+static bool prefab_sniff(const uint8_t *b, size_t n) { return b && n >= sizeof(PfHeader) && std::memcmp(b, kPrefabMagic, 8) == 0; }
+struct Prefab {
+    PfHeader hdr{};
+    std::map<std::string, PfEntry> entries;
+    static Prefab parse(const uint8_t *b, size_t n) {
+        Prefab p;
+        if (!prefab_sniff(b, n)) throw RwkvError(RWKV_ERR_FORMAT, "not a prefab image");
+        std::memcpy(&p.hdr, b, sizeof(PfHeader));
+        if (p.hdr.version != kPrefabVersion) throw RwkvError(RWKV_ERR_UNSUPPORTED, "prefab version mismatch");
+        size_t off = sizeof(PfHeader);
+        auto pad16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+        for (uint32_t i = 0; i < p.hdr.n_entries; ++i) {
+            PfEntry e;
+            if (off + sizeof(PfEntryHead) > n) throw RwkvError(RWKV_ERR_FORMAT, "prefab truncated");
+            std::memcpy(&e.h, b + off, sizeof(PfEntryHead));
+            off += sizeof(PfEntryHead);
+            if (off + e.h.name_len > n) throw RwkvError(RWKV_ERR_FORMAT, "prefab truncated");
+            std::string name((const char *)b + off, e.h.name_len);
+            off = pad16(off + e.h.name_len);
+            if (off + e.h.data_bytes > n) throw RwkvError(RWKV_ERR_FORMAT, "prefab truncated");
+            e.data = b + off;
+            off = pad16(off + e.h.data_bytes);
+            if (off + e.h.scale_bytes > n) throw RwkvError(RWKV_ERR_FORMAT, "prefab truncated");
+            e.scales = e.h.scale_bytes ? b + off : nullptr;
+            off = pad16(off + e.h.scale_bytes);
+            p.entries.emplace(std::move(name), e);
+        }
+        return p;
+    }
+    const PfEntry &get(const std::string &name, uint32_t kind) const {
+        auto it = entries.find(name);
+        if (it == entries.end() || it->second.h.kind != kind) throw RwkvError(RWKV_ERR_FORMAT, "prefab: missing entry " + name);
+        return it->second;
+    }
+    bool has(const std::string &name) const { return entries.count(name) != 0; }
+};
+
 static rwkv_model_info detect_info(const SafeTensors &st) {
     rwkv_model_info i{};
     if (st.find("blocks.0.att.x_r")) i.version = 7;
@@ -153,6 +204,8 @@ struct rwkv_engine {
     std::map<std::string, DMat> mats;
     std::map<std::string, float *> vecs;
     std::map<std::string, _Float16 *> raws;
+    std::map<std::string, std::pair<size_t, bool>> vec_meta, raw_meta;   // element count, counted-in-weight_bytes (prefab save)
+    void save_prefab(const char *path);
     std::vector<LayerW> layers;
     const float *ln0w, *ln0b, *lnow, *lnob;
     const _Float16 *emb = nullptr;
@@ -303,15 +356,71 @@ static bool is_quant_target(int version, const std::string &suffix) {
     return false;
 }
 
+void rwkv_engine::save_prefab(const char *path) {
+    FILE *f = std::fopen(path, "wb");
+    if (!f) throw RwkvError(RWKV_ERR_INVALID, std::string("cannot open ") + path);
+    struct Closer { FILE *f; ~Closer() { std::fclose(f); } } closer{f};
+    auto put = [&](const void *p, size_t n) { if (n && std::fwrite(p, 1, n, f) != n) throw RwkvError(RWKV_ERR_INVALID, "short write"); };
+    size_t pos = 0;
+    auto putp = [&](const void *p, size_t n) {                 // payload + pad to 16
+        static const char zeros[16] = {0};
+        put(p, n);
+        pos += n;
+        const size_t padn = ((pos + 15) & ~(size_t)15) - pos;
+        put(zeros, padn);
+        pos += padn;
+    };
+    PfHeader h{};
+    std::memcpy(h.magic, kPrefabMagic, 8);
+    h.version = kPrefabVersion;
+    h.n_entries = (uint32_t)(vecs.size() + raws.size() + mats.size());
+    h.info = info; h.quant_layers = quant_layers; h.quant_type = quant_type;
+    put(&h, sizeof(h));
+    pos = sizeof(h);
+    std::vector<uint8_t> host;
+    auto entry = [&](const std::string &name, uint32_t kind, int fmt, int rows, int K, bool counted, uint64_t n_elems,
+                     const void *dev_data, size_t data_bytes, const void *dev_scales, size_t scale_bytes) {
+        PfEntryHead e{};
+        e.kind = kind; e.fmt = fmt; e.rows = rows; e.K = K; e.counted = counted ? 1 : 0; e.name_len = (uint32_t)name.size();
+        e.n_elems = n_elems; e.data_bytes = data_bytes; e.scale_bytes = scale_bytes;
+        put(&e, sizeof(e));
+        pos += sizeof(e);
+        putp(name.data(), name.size());
+        host.resize(std::max(data_bytes, scale_bytes));
+        HIP_CHECK(hipMemcpy(host.data(), dev_data, data_bytes, hipMemcpyDeviceToHost));
+        putp(host.data(), data_bytes);
+        if (scale_bytes) {
+            HIP_CHECK(hipMemcpy(host.data(), dev_scales, scale_bytes, hipMemcpyDeviceToHost));
+            putp(host.data(), scale_bytes);
+        }
+    };
+    HIP_CHECK(hipSetDevice(device));
+    for (auto &kv : vecs) entry(kv.first, 0, 0, 0, 0, true, vec_meta.at(kv.first).first, kv.second, vec_meta.at(kv.first).first * 4, nullptr, 0);
+    for (auto &kv : raws) entry(kv.first, 1, 0, 0, 0, raw_meta.at(kv.first).second, raw_meta.at(kv.first).first, kv.second, raw_meta.at(kv.first).first * 2, nullptr, 0);
+    for (auto &kv : mats) {
+        const DMat &m = kv.second;
+        const size_t db = m.fmt == W_F16 ? (size_t)m.rows * m.K * 2 : m.fmt == W_INT8 ? (size_t)m.rows * m.K : (size_t)m.rows * m.K / 2;
+        const size_t sb = m.fmt == W_F16 ? 0 : m.fmt == W_INT8 ? (size_t)m.rows * (m.K / 128) * 4 : (size_t)m.rows * (m.K / 64) * 2;
+        entry(kv.first, 2, m.fmt, m.rows, m.K, true, m.bytes, m.data, db, m.scales, sb);
+    }
+}
+
 void rwkv_engine::load(const rwkv_load_desc &d) {
-    SafeTensors st = SafeTensors::parse(d.st_bytes, d.st_len);
-    info = detect_info(st);
+    const bool pf = prefab_sniff(d.st_bytes, d.st_len);      // lib.rs:585-588: the file is sniffed, not named
+    Prefab prefab;
+    SafeTensors st;
+    if (pf) { prefab = Prefab::parse(d.st_bytes, d.st_len); info = prefab.hdr.info; }
+    else { st = SafeTensors::parse(d.st_bytes, d.st_len); info = detect_info(st); }
     const int L = info.num_layer, C = info.num_emb, F = info.num_hidden, V = info.num_vocab, H = info.num_head;
     max_batch = d.max_batch > 0 ? d.max_batch : 8;
     chunk = d.token_chunk_size > 0 ? d.token_chunk_size : 128;
     hilo = d.precision == RWKV_PRECISION_FP32;
     quant_layers = std::max(0, std::min(d.quant_layers, L));
     quant_type = d.quant_type;
+    if (pf) {                                                // a prefab is already quantised / blended: its settings win
+        quant_layers = prefab.hdr.quant_layers; quant_type = prefab.hdr.quant_type;
+        if (d.n_lora) throw RwkvError(RWKV_ERR_UNSUPPORTED, "LoRA adapters cannot be applied to a prefab image");
+    }
     if (quant_type != RWKV_QUANT_NONE && quant_type != RWKV_QUANT_INT8 && quant_type != RWKV_QUANT_NF4)
         throw RwkvError(RWKV_ERR_UNSUPPORTED, "quant_type must be None, Int8 or NF4 (SF4 is not supported)");
     if (quant_type != RWKV_QUANT_NONE && quant_layers > 0 && (C % 256 || F % 256))
@@ -329,7 +438,7 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
         loras.emplace_back(SafeTensors::parse(d.lora[i].st_bytes, d.lora[i].st_len), d.lora[i].alpha);
 
     size_t raw_cap = 0;
-    for (auto &kv : st.tensors) raw_cap = std::max(raw_cap, kv.second.nbytes);
+    if (!pf) for (auto &kv : st.tensors) raw_cap = std::max(raw_cap, kv.second.nbytes);
     _Float16 *raw = nullptr;                                   // temp upload buffer
     HIP_CHECK(hipMalloc((void **)&raw, std::max<size_t>(raw_cap, 16)));
     struct RawGuard { void *p; ~RawGuard() { (void)hipFree(p); } } rg{raw};
@@ -342,26 +451,58 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
         HIP_CHECK(hipMemcpyAsync(raw, t.data, t.nbytes, hipMemcpyHostToDevice, s_main));
     };
     auto load_vec = [&](const std::string &name, int op = 0) -> const float * {
+        if (pf) {
+            const PfEntry &e = prefab.get(name, 0);
+            float *v = dalloc<float>((size_t)e.h.n_elems);
+            HIP_CHECK(hipMemcpy(v, e.data, e.h.n_elems * 4, hipMemcpyHostToDevice));
+            vecs[name] = v; vec_meta[name] = {(size_t)e.h.n_elems, true};
+            weight_bytes += (uint64_t)e.h.n_elems * 2;
+            return v;
+        }
         const StTensor &t = st.get(name);
         upload_raw(t);
         float *v = dalloc<float>((size_t)t.numel());
         launch_f16_to_f32(raw, v, t.numel(), op, s_main);
         HIP_CHECK(hipStreamSynchronize(s_main));
-        vecs[name] = v;
+        vecs[name] = v; vec_meta[name] = {(size_t)t.numel(), true};
         weight_bytes += (uint64_t)t.numel() * 2;
         return v;
     };
     auto load_raw16 = [&](const std::string &name, bool count) -> const _Float16 * {
+        if (pf) {
+            const PfEntry &e = prefab.get(name, 1);
+            _Float16 *v = dalloc<_Float16>((size_t)e.h.n_elems);
+            HIP_CHECK(hipMemcpy(v, e.data, e.h.n_elems * 2, hipMemcpyHostToDevice));
+            raws[name] = v; raw_meta[name] = {(size_t)e.h.n_elems, count};
+            if (count) weight_bytes += (uint64_t)e.h.n_elems * 2;
+            return v;
+        }
         const StTensor &t = st.get(name);
         if (t.dtype != "F16") throw RwkvError(RWKV_ERR_UNSUPPORTED, "tensor dtype must be F16");
         _Float16 *v = dalloc<_Float16>((size_t)t.numel());
         HIP_CHECK(hipMemcpy(v, t.data, t.nbytes, hipMemcpyHostToDevice));
-        raws[name] = v;
+        raws[name] = v; raw_meta[name] = {(size_t)t.numel(), count};
         if (count) weight_bytes += (uint64_t)t.nbytes;
         return v;
     };
     // matrix [.., rows, K] (leading dims folded into `index`)
     auto load_mat = [&](const std::string &name, int fmt, int index = -1, const std::string &key = "") -> const DMat * {
+        if (pf) {
+            const std::string &k = key.empty() ? name : key;
+            const PfEntry &e = prefab.get(k, 2);
+            DMat m;
+            m.fmt = e.h.fmt; m.rows = e.h.rows; m.K = e.h.K; m.bytes = e.h.n_elems;
+            void *p = dalloc<uint8_t>((size_t)e.h.data_bytes);
+            HIP_CHECK(hipMemcpy(p, e.data, e.h.data_bytes, hipMemcpyHostToDevice));
+            m.data = p;
+            if (e.h.scale_bytes) {
+                void *sc = dalloc<uint8_t>((size_t)e.h.scale_bytes);
+                HIP_CHECK(hipMemcpy(sc, e.scales, e.h.scale_bytes, hipMemcpyHostToDevice));
+                m.scales = sc;
+            }
+            weight_bytes += m.bytes;
+            return &mats.emplace(k, m).first->second;
+        }
         const StTensor &t = st.get(name);
         if (t.shape.size() < 2) throw RwkvError(RWKV_ERR_FORMAT, name + ": expected a matrix");
         const int K = (int)t.shape.back(), rows = (int)t.shape[t.shape.size() - 2];
@@ -459,9 +600,13 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
             for (int i = 0; i < 6; ++i) w.mu[i] = load_vec(p + "att.time_mix_" + n6[i]);
             w.wdec = load_vec(p + "att.time_decay");
             w.W1 = load_mat(p + "att.time_mix_w1", W_F16);
-            const StTensor &w2 = st.get(p + "att.time_mix_w2");
-            if (w2.shape.size() != 3 || w2.shape[0] != 5) throw RwkvError(RWKV_ERR_FORMAT, "time_mix_w2 must be [5,C,Dm]");
-            Dm = (int)w2.shape[2];
+            if (!pf) {
+                const StTensor &w2 = st.get(p + "att.time_mix_w2");
+                if (w2.shape.size() != 3 || w2.shape[0] != 5) throw RwkvError(RWKV_ERR_FORMAT, "time_mix_w2 must be [5,C,Dm]");
+                Dm = (int)w2.shape[2];
+            } else {
+                Dm = prefab.get(p + "att.time_mix_w2#0", 2).h.K;
+            }
             for (int c = 0; c < 5; ++c) w.W2[c] = load_mat(p + "att.time_mix_w2", W_F16, c, p + "att.time_mix_w2#" + std::to_string(c));
             w.D1 = load_mat(p + "att.time_decay_w1", W_F16);
             Dd = w.D1->rows;
@@ -476,7 +621,7 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
             w.w1 = load_mat(p + "att.w1", W_F16); w.w2 = load_mat(p + "att.w2", W_F16);
             w.a1 = load_mat(p + "att.a1", W_F16); w.a2 = load_mat(p + "att.a2", W_F16);
             w.g1 = load_mat(p + "att.g1", W_F16); w.g2 = load_mat(p + "att.g2", W_F16);
-            if (l > 0 || st.find(p + "att.v0")) {
+            if (l > 0 || (pf ? prefab.has(p + "att.v0") : st.find(p + "att.v0") != nullptr)) {
                 w.v0 = load_vec(p + "att.v0");
                 w.v1 = load_mat(p + "att.v1", W_F16); w.v2 = load_mat(p + "att.v2", W_F16);
             }
@@ -1086,8 +1231,22 @@ rwkv_status rwkv_device_name(int32_t index, char *buf, size_t buf_len) {
 rwkv_status rwkv_model_info_from_st(const uint8_t *st_bytes, size_t st_len, rwkv_model_info *out) {
     return guard([&] {
         if (!out) throw RwkvError(RWKV_ERR_INVALID, "null out");
+        if (prefab_sniff(st_bytes, st_len)) {                   // lib.rs:585-588: safetensors or prefab, by content
+            PfHeader h;
+            std::memcpy(&h, st_bytes, sizeof(h));
+            if (h.version != kPrefabVersion) throw RwkvError(RWKV_ERR_UNSUPPORTED, "prefab version mismatch");
+            *out = h.info;
+            return;
+        }
         SafeTensors st = SafeTensors::parse(st_bytes, st_len);
         *out = detect_info(st);
+    });
+}
+
+rwkv_status rwkv_engine_save_prefab(rwkv_engine *e, const char *path) {
+    return guard([&] {
+        if (!e || !path) throw RwkvError(RWKV_ERR_INVALID, "null argument");
+        e->save_prefab(path);
     });
 }
 

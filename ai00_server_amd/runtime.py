@@ -71,6 +71,7 @@ ABI_SYMBOLS = {
     "rwkv_model_info_from_st": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(_ModelInfoC)]),
     "rwkv_engine_create": (C.c_int32, [C.POINTER(_LoadDescC), C.POINTER(C.c_void_p)]),
     "rwkv_engine_destroy": (None, [C.c_void_p]),
+    "rwkv_engine_save_prefab": (C.c_int32, [C.c_void_p, C.c_char_p]),
     "rwkv_engine_info": (C.c_int32, [C.c_void_p, C.POINTER(_ModelInfoC)]),
     "rwkv_engine_device": (C.c_int32, [C.c_void_p]),
     "rwkv_engine_max_batch": (C.c_int32, [C.c_void_p]),
@@ -359,6 +360,11 @@ class Runtime:
     @property
     def weight_bytes(self) -> int:
         return int(lib().rwkv_engine_weight_bytes(self._h))
+
+    def save_prefab(self, path: str):
+        """`ModelSerialize::serialize(file)` (lib.rs:131-154): the loaded (tiled / quantised / blended) model as one image;
+        hand its bytes to `ModelBuilder` like a safetensors file (sniffed by content, lib.rs:585-588)."""
+        _check(lib().rwkv_engine_save_prefab(self._h, os.fsencode(path)))
 
     def _prepare(self, inp: RnnInput):
         if len(inp.batches) != self.max_batch:

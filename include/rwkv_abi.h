@@ -58,6 +58,10 @@ typedef struct rwkv_model_info {
     int32_t reserved;
 } rwkv_model_info;
 rwkv_status rwkv_model_info_from_st(const uint8_t *st_bytes, size_t st_len, rwkv_model_info *out);
+/* `st_bytes` here and in rwkv_load_desc may also be a PREFAB image written by rwkv_engine_save_prefab: the content is
+ * sniffed exactly as lib.rs:585-588 does (safetensors, else prefab).  A prefab carries the re-tiled / quantised /
+ * LoRA-blended weights, so loading it skips those passes; its quantisation settings override the descriptor's and
+ * LoRA adapters are rejected (RWKV_ERR_UNSUPPORTED).  The format is this library's own (versioned), not web-rwkv's CBOR. */
 
 /* ---- `create_context` lib.rs:351-368 + `load_runtime` lib.rs:391-516 ---------------------- */
 enum { RWKV_QUANT_NONE = 0, RWKV_QUANT_INT8 = 1, RWKV_QUANT_NF4 = 2 };   /* `Quant` lib.rs:689-704 */
@@ -87,6 +91,8 @@ typedef struct rwkv_engine rwkv_engine;   /* = Context + Model + vN::Bundle + To
 
 rwkv_status rwkv_engine_create(const rwkv_load_desc *desc, rwkv_engine **out);
 void rwkv_engine_destroy(rwkv_engine *e);                       /* Unload/drop lib.rs:652-656 */
+/* `ModelSerialize::serialize(file)` lib.rs:131-154 (the "save model" admin call): write the loaded model as a prefab image. */
+rwkv_status rwkv_engine_save_prefab(rwkv_engine *e, const char *path);
 rwkv_status rwkv_engine_info(const rwkv_engine *e, rwkv_model_info *out);
 int32_t rwkv_engine_device(const rwkv_engine *e);               /* HIP device ordinal in use */
 int32_t rwkv_engine_max_batch(const rwkv_engine *e);

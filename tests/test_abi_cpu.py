@@ -127,3 +127,19 @@ def test_chunk_policy_water_filling(built_lib):
         pending = [p - t for p, t in zip(pending, take)]
         calls += 1
     assert calls == -(-1072 // 128)
+
+
+def test_prefab_images_are_sniffed_and_bad_ones_rejected(built_lib):
+    """`rwkv_model_info_from_st` takes safetensors or a prefab image by content (lib.rs:585-588); a truncated or
+    wrong-version image is an error code, never an abort.  (Writing/reading a real image needs a GPU: test_gpu_parity.)"""
+    import struct
+    info = (6, 2, 128, 448, 256, 2, 64, 0)
+    good = b"RWKVHIP\0" + struct.pack("<II", 1, 0) + struct.pack("<8i", *info) + struct.pack("<ii", 0, 0)
+    got = rt.Loader.info(good)
+    assert (got.version, got.num_layer, got.num_emb, got.num_hidden, got.num_vocab, got.num_head) == info[:6]
+    bad_version = b"RWKVHIP\0" + struct.pack("<II", 99, 0) + good[16:]
+    with pytest.raises(rt.RwkvError) as e:
+        rt.Loader.info(bad_version)
+    assert e.value.code == -3
+    with pytest.raises(rt.RwkvError):
+        rt.Loader.info(b"RWKVHIP\0" + b"\x01\x00")             # shorter than a header: falls through to the safetensors parser

@@ -451,3 +451,38 @@ def test_single_token_steps_with_ln_prologue_interleave_with_chunks(name):
     st = eng.state.back(slot)
     assert np.abs(st - sw).max() <= tol(rt.Precision.Fp16, sw)
     eng.close()
+
+
+@pytest.mark.parametrize("name,quant", [("v6-small", (3, 1)), ("v7-small", (2, 2)), ("v5-small", (0, 0))])
+def test_prefab_round_trip_is_bit_exact(name, quant, tmp_path):
+    """Prefab save/load (`ModelSerialize::serialize` lib.rs:131-154, `LoadType::Prefab` lib.rs:517-553): a model saved after
+    quantisation + LoRA blend and loaded back from the image gives bit-identical logits and state, and reports the
+    same info and weight bytes; a LoRA on top of a prefab is refused."""
+    t = R.synth_named(name)
+    st = R.st_serialize(t)
+    rng = np.random.default_rng(5)
+    C = R.model_info(t).num_emb
+    lora = R.st_serialize({"blocks.0.att.output.lora.0": (rng.standard_normal((C, 4)) * 0.05).astype(np.float16),
+                           "blocks.0.att.output.lora.1": (rng.standard_normal((C, 4)) * 0.05).astype(np.float16)})
+    eng = rt.ModelBuilder(st).quant(quant[0], rt.Quant(quant[1])).lora(lora, 0.5).build(max_batch=2, token_chunk_size=16)
+    ref = R.RwkvRef(t)
+    ps = [prompt(ref, 3, 13), prompt(ref, 4, 7)]
+    a = run_prompts(eng, ps)
+    sa = [eng.state.back(b) for b in range(2)]
+    path = str(tmp_path / "model.prefab")
+    eng.save_prefab(path)
+    info, wb = eng.info, eng.weight_bytes
+    eng.close()
+    image = open(path, "rb").read()
+    assert image[:7] == b"RWKVHIP" and rt.Loader.info(image) == info
+    eng2 = rt.ModelBuilder(image).build(max_batch=2, token_chunk_size=16)          # quant settings come from the image
+    assert eng2.info == info and eng2.weight_bytes == wb
+    b = run_prompts(eng2, ps)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    for bi in range(2):
+        np.testing.assert_array_equal(sa[bi], eng2.state.back(bi))
+    eng2.close()
+    with pytest.raises(rt.RwkvError) as e:
+        rt.ModelBuilder(image).lora(lora, 0.5).build(max_batch=1)
+    assert e.value.code == -3
