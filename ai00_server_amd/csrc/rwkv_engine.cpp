@@ -794,11 +794,15 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         Lh.T = T;
         // 64x64 tiles measured best everywhere (tile_bench): with 256-k chunks while the launch is latency-bound
         // (few blocks: one L2 round trip per chunk dominates), with 128-k chunks (more blocks per CU) once it is
-        // throughput-bound.  RWKV_TILE_SHAPE overrides (0..5) for experiments.
-        static const int f_shape = std::getenv("RWKV_TILE_SHAPE") ? env_int("RWKV_TILE_SHAPE") : -1;
+        // throughput-bound.  RWKV_TILE_SHAPE overrides (0..9) for experiments.
+        static const int f_shape = (std::getenv("RWKV_TILE_SHAPE") && *std::getenv("RWKV_TILE_SHAPE")) ? env_int("RWKV_TILE_SHAPE") : -1;
         long tot64 = 0;
         for (auto &s : ps) tot64 += gemm_tile_blocks(3, s.W->rows, T);
         int shape = tot64 <= 1536 ? 4 : 3;
+        // the direct-to-LDS 128x64 shape (7: two strips per wave, X tiles by global_load_lds) pays only for very large
+        // grids: 7B fp16 prefill at chunk 1024 25.9 -> 27.5 k tok/s, but 21.3 -> 17.8 k at chunk 512; the 256x128
+        // GLDS shape (9) wins isolated large fp16 GEMMs (404 -> 536 TFLOP/s) and loses the model (small matrices starve)
+        if (T >= 1024 && tot64 >= 2500) shape = 7;
         if (f_shape >= 0 && f_shape < GEMM_TILE_SHAPES) shape = f_shape;
         int blocks = 0;
         for (size_t i = 0; i < ps.size(); ++i) {

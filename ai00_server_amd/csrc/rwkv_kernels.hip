@@ -962,7 +962,14 @@ __device__ __forceinline__ f16x8 tg_frag(const TRound<FMT, SPW, KC> &w, int h, i
 }
 
 // Tile shape: WAVES waves x SPW strips per wave (rows = WAVES*SPW*16) x NTL n-tiles (tokens = NTL*16)
-template <bool HILO, int WAVES, int SPW, int NTL, int KC, int FMT>
+// 16 bytes per lane straight from global memory into LDS (no VGPR, no ds_write): lane l lands at lds + 16*l, so a
+// B-fragment tile of the tiled operand (opd_off) arrives in LDS already in fragment order.  `lds` is wave-uniform.
+__device__ __forceinline__ void glds16(const _Float16 *g, _Float16 *lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)g,
+                                     (__attribute__((address_space(3))) void *)(uintptr_t)(uint32_t)(uintptr_t)lds, 16, 0, 0);
+}
+
+template <bool HILO, int WAVES, int SPW, int NTL, int KC, int FMT, bool GLDS>
 __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
     constexpr int BT = NTL * 16, THREADS = WAVES * 64, STRIPS = WAVES * SPW, TG_KC = KC, TG_STRIDE = KC + 8;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -975,7 +982,7 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
     const int t0 = tt * BT;
     const int K = P.K;
     const int nchunk = (K + TG_KC - 1) / TG_KC;
-    constexpr int PART = BT * TG_STRIDE;                          // halfs per (buffer, hi|lo)
+    constexpr int PART = GLDS ? NTL * (KC / 32) * 512 : BT * TG_STRIDE;   // halfs per (buffer, hi|lo)
     _Float16 *xs = (_Float16 *)smem;                              // [buf][hi|lo][BT][TG_STRIDE]
     constexpr int XP = BT * TG_KC / 8 / THREADS;                  // 16-byte pieces per thread per part
     Nf4Lut lut;
@@ -1024,6 +1031,27 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
             if constexpr (HILO) *(uint4 *)(bh + PART + r * TG_STRIDE + c8 * 8) = x.l[i];
         }
     };
+    // GLDS staging: tile i = (token tile i / KTC, k-tile i % KTC) of the chunk is one 1 KiB direct-to-LDS load, issued by
+    // wave i % WAVES; the LDS image [tile][lane][8] IS the B-fragment order, so the MFMA loop reads it with conflict-free
+    // contiguous ds_read_b128 and no staging registers or ds_write pass exist.
+    auto glds_issue = [&](int c, int buf, auto full) {
+        constexpr bool FULL = decltype(full)::value;
+        const int k0 = c * TG_KC;
+        _Float16 *bh = xs + (HILO ? buf * 2 : buf) * PART;
+#pragma unroll
+        for (int j = 0; j < (NTL * KTC + WAVES - 1) / WAVES; ++j) {
+            const int i = wave + j * WAVES;
+            if (i < NTL * KTC) {
+                const int tt = i / KTC, kt = i % KTC, k = k0 + kt * 32;
+                if (FULL || k < K) {
+                    const int ttile = min((t0 >> 4) + tt, last_tile);
+                    const long xo = ((long)ttile * (P.ldx >> 5) + (k >> 5)) * 512 + lane * 8;
+                    glds16(P.xhi + xo, bh + i * 512);
+                    if constexpr (HILO) glds16(P.xlo + xo, bh + PART + i * 512);
+                }
+            }
+        }
+    };
     auto mma_chunk = [&](const TRound<FMT, SPW, KC> &w, int c, auto full) {
         constexpr bool FULL = decltype(full)::value;
         const int k0 = c * TG_KC;
@@ -1034,7 +1062,7 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
                 f16x8 xv[NTL], xc[HILO ? NTL : 1];                  // all B fragments of the k-step in flight at once
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt) {
-                    const int off = (nt * 16 + (lane & 15)) * TG_STRIDE + ks * 32 + (lane >> 4) * 8;
+                    const int off = GLDS ? ((nt * KTC + ks) * 64 + lane) * 8 : (nt * 16 + (lane & 15)) * TG_STRIDE + ks * 32 + (lane >> 4) * 8;
                     xv[nt] = *(const f16x8 *)(bh + off);
                     if constexpr (HILO) xc[nt] = *(const f16x8 *)(bh + PART + off);
                 }
@@ -1061,6 +1089,33 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
     // forces the waits anyway and the extra sets spill.)
     const int nfull = K / TG_KC;                                   // chunks entirely inside K
     TRound<FMT, SPW, KC> cur, nxt;
+    if constexpr (GLDS) {
+        // chunk c+1's X tiles are issued into the other buffer at the top of iteration c (every wave passed the barrier
+        // that ended iteration c-1, so nobody still reads it); the barrier at the bottom (with the vmcnt(0) the compiler
+        // puts in front of it) publishes them
+        if (nfull > 0) { tg_load<FMT, SPW, KC, true>(cur, P, strip, nstrips, 0, lane); glds_issue(0, 0, T_{}); }
+        else { tg_load<FMT, SPW, KC, false>(cur, P, strip, nstrips, 0, lane); glds_issue(0, 0, F_{}); }
+        __syncthreads();
+        for (int c = 0; c < nchunk; ++c) {
+            if (c + 1 < nfull) {
+                tg_load<FMT, SPW, KC, true>(nxt, P, strip, nstrips, (c + 1) * TG_KC, lane);
+                glds_issue(c + 1, (c + 1) & 1, T_{});
+                mma_chunk(cur, c, T_{});
+                __syncthreads();
+                cur = nxt;
+            } else {
+                if (c + 1 < nchunk) {
+                    tg_load<FMT, SPW, KC, false>(nxt, P, strip, nstrips, (c + 1) * TG_KC, lane);
+                    glds_issue(c + 1, (c + 1) & 1, F_{});
+                }
+                if (c < nfull) mma_chunk(cur, c, T_{}); else mma_chunk(cur, c, F_{});
+                if (c + 1 < nchunk) {
+                    __syncthreads();
+                    cur = nxt;
+                }
+            }
+        }
+    } else {
     XRegs xa;
     if (nfull > 0) { tg_load<FMT, SPW, KC, true>(cur, P, strip, nstrips, 0, lane); stage_load(xa, 0, T_{}); }
     else { tg_load<FMT, SPW, KC, false>(cur, P, strip, nstrips, 0, lane); stage_load(xa, 0, F_{}); }
@@ -1086,6 +1141,7 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
                 cur = nxt;
             }
         }
+    }
     }
     // ---- epilogue
 #pragma unroll
@@ -1122,20 +1178,21 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
     }
 }
 
-template <bool HILO, int WAVES, int SPW, int NTL, int KC>
+template <bool HILO, int WAVES, int SPW, int NTL, int KC, bool GLDS>
 __global__ __launch_bounds__(WAVES * 64) void gemm_tile_kernel(const GemmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int pi = 0;
     for (int i = 1; i < L.nprob; ++i)
         if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
     const GemmProb &P = L.p[pi];
-    if (P.fmt == W_F16) tg_body<HILO, WAVES, SPW, NTL, KC, W_F16>(L, P, smem);
-    else if (P.fmt == W_INT8) tg_body<HILO, WAVES, SPW, NTL, KC, W_INT8>(L, P, smem);
-    else tg_body<HILO, WAVES, SPW, NTL, KC, W_NF4>(L, P, smem);
+    if (P.fmt == W_F16) tg_body<HILO, WAVES, SPW, NTL, KC, W_F16, GLDS>(L, P, smem);
+    else if (P.fmt == W_INT8) tg_body<HILO, WAVES, SPW, NTL, KC, W_INT8, GLDS>(L, P, smem);
+    else tg_body<HILO, WAVES, SPW, NTL, KC, W_NF4, GLDS>(L, P, smem);
 }
 
 // tile shapes, largest first: {waves, strips per wave, n-tiles, k per chunk}
-static const int kTileShapes[GEMM_TILE_SHAPES][4] = {{8, 2, 8, 128}, {8, 1, 8, 128}, {4, 1, 8, 128}, {4, 1, 4, 128}, {4, 1, 4, 256}, {8, 1, 8, 256}};
+static const int kTileShapes[GEMM_TILE_SHAPES][5] = {{8, 2, 8, 128, 0}, {8, 1, 8, 128, 0}, {4, 1, 8, 128, 0}, {4, 1, 4, 128, 0}, {4, 1, 4, 256, 0}, {8, 1, 8, 256, 0},
+                                                     {4, 1, 4, 256, 1}, {4, 2, 4, 128, 1}, {4, 2, 8, 128, 1}, {8, 2, 8, 128, 1}};
 int gemm_tile_blocks(int shape, int rows, int T) {
     const int strips = kTileShapes[shape][0] * kTileShapes[shape][1], bt = kTileShapes[shape][2] * 16;
     return ((rows / 16 + strips - 1) / strips) * ((T + bt - 1) / bt);
@@ -1143,19 +1200,21 @@ int gemm_tile_blocks(int shape, int rows, int T) {
 
 void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s) {
     const int bt = kTileShapes[shape][2] * 16, kc = kTileShapes[shape][3];
-    const size_t lds = (size_t)2 * (hilo ? 2 : 1) * bt * (kc + 8) * 2;
+    const size_t lds = kTileShapes[shape][4] ? (size_t)2 * (hilo ? 2 : 1) * (bt / 16) * (kc / 32) * 1024
+                                             : (size_t)2 * (hilo ? 2 : 1) * bt * (kc + 8) * 2;
     static bool attr_done[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
-#define TG_SH(X, h) X(h, 8, 2, 8, 128, 0) X(h, 8, 1, 8, 128, 1) X(h, 4, 1, 8, 128, 2) X(h, 4, 1, 4, 128, 3) X(h, 4, 1, 4, 256, 4) X(h, 8, 1, 8, 256, 5)
+#define TG_SH(X, h) X(h, 8, 2, 8, 128, false, 0) X(h, 8, 1, 8, 128, false, 1) X(h, 4, 1, 8, 128, false, 2) X(h, 4, 1, 4, 128, false, 3) X(h, 4, 1, 4, 256, false, 4) \
+                    X(h, 8, 1, 8, 256, false, 5) X(h, 4, 1, 4, 256, true, 6) X(h, 4, 2, 4, 128, true, 7) X(h, 4, 2, 8, 128, true, 8) X(h, 8, 2, 8, 128, true, 9)
 #define TG_VARIANTS(X) TG_SH(X, true) TG_SH(X, false)
     if (!attr_done[dev & 15]) {
-#define SET_ATTR(h, w, p, n, k, i) (void)hipFuncSetAttribute((const void *)gemm_tile_kernel<h, w, p, n, k>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define SET_ATTR(h, w, p, n, k, g, i) (void)hipFuncSetAttribute((const void *)gemm_tile_kernel<h, w, p, n, k, g>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         TG_VARIANTS(SET_ATTR)
 #undef SET_ATTR
         attr_done[dev & 15] = true;
     }
-#define LAUNCH(h, w, p, n, k, i) if (hilo == h && shape == i) hipLaunchKernelGGL((gemm_tile_kernel<h, w, p, n, k>), dim3(L.total_blocks), dim3(w * 64), lds, s, L);
+#define LAUNCH(h, w, p, n, k, g, i) if (hilo == h && shape == i) hipLaunchKernelGGL((gemm_tile_kernel<h, w, p, n, k, g>), dim3(L.total_blocks), dim3(w * 64), lds, s, L);
     TG_VARIANTS(LAUNCH)
 #undef LAUNCH
 #undef TG_VARIANTS
