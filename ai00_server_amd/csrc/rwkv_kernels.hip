@@ -1559,7 +1559,7 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
 constexpr int WKV_CH = 32;                               // tokens per chunk: 8 per wave in the parallel phases
 constexpr int WKV_MAX_DD = 128;                          // V6 decay LoRA width held in registers (all released models: 64 / 128)
 template <int DD>
-__device__ __forceinline__ float wkv_decay_dot(const f16x8 (&d2r)[WKV_MAX_DD / 8], const float *tdl) {
+__device__ __forceinline__ float wkv_decay_dot(const f16x8 (&d2r)[DD / 8], const float *tdl) {
     constexpr int PER8 = DD / 32;
     float ps[4];
 #pragma unroll
@@ -1577,6 +1577,7 @@ __device__ __forceinline__ float wkv_decay_dot(const f16x8 (&d2r)[WKV_MAX_DD / 8
     }
     return (ps[0] + ps[1]) + (ps[2] + ps[3]);
 }
+template <int VER, int DD>
 __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
     __shared__ __attribute__((aligned(16))) float s_r[WKV_CH][64], s_k[WKV_CH][64], s_v[WKV_CH][64], s_w[WKV_CH][64];
     __shared__ __attribute__((aligned(16))) float s_kk[WKV_CH][64], s_ka[WKV_CH][64], s_o[WKV_CH][64];
@@ -1585,56 +1586,68 @@ __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
     const int seq = blockIdx.x, h = blockIdx.y;
     const int tid = threadIdx.x, ig = tid >> 4, jg = tid & 15, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    TRACE_K(3, 0);
     const int slot = a.seq_slot[seq], row0 = a.seq_begin[seq], nrow = a.seq_len[seq];
     const int C = a.C, cb = h * 64, Dd = a.Dd;
     float *st = a.state + (long)slot * a.slot_stride + (long)h * 4096;
     float4 T[4];
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa) T[aa] = __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4 *)(st + (aa * 16 + ig) * 64 + jg * 4)));
-    if (a.version != 7 && tid < 64) s_u[tid] = a.u[cb + tid];
+    if (VER != 7 && tid < 64) s_u[tid] = a.u[cb + tid];
     // per-channel parameters (channel = lane in phases A and C)
     const float lnw = a.lnx_w[cb + lane], lnb = a.lnx_b[cb + lane];
     float kk_p = 0.f, ka_p = 0.f, rk_p = 0.f, wconst = 0.f, decay0 = 0.f;
-    if (a.version == 7) { kk_p = a.k_k[cb + lane]; ka_p = a.k_a[cb + lane]; rk_p = a.r_k[cb + lane]; }
-    if (a.version == 5) wconst = a.wdec_or_decay[cb + lane];
-    f16x8 d2r[WKV_MAX_DD / 8];                           // V6: this channel's row of D2 (loop-invariant)
-    if (a.version == 6) {
-        decay0 = a.wdec_or_decay[cb + lane];
-        const _Float16 *d2 = a.D2 + (long)(cb + lane) * Dd;
-#pragma unroll
-        for (int d8 = 0; d8 < WKV_MAX_DD / 8; ++d8)
-            if (d8 * 8 < Dd) d2r[d8] = *(const f16x8 *)(d2 + d8 * 8);
-    }
+    if (VER == 7) { kk_p = a.k_k[cb + lane]; ka_p = a.k_a[cb + lane]; rk_p = a.r_k[cb + lane]; }
+    if (VER == 5) wconst = a.wdec_or_decay[cb + lane];
+    if (VER == 6) decay0 = a.wdec_or_decay[cb + lane];
 
     for (int c0 = 0; c0 < nrow; c0 += WKV_CH) {
         const int n = min(WKV_CH, nrow - c0);
         // ---- phase A: wave w prepares tokens w, w+4, ... (lane = channel).  A1: every global load of the chunk is issued
         //      back to back and parked RAW in the LDS rows (a lane only touches its own elements: no barrier);
         //      A2: a rolled loop transforms the rows in place.
+        {
+            float q0[WKV_CH / 4], q1[WKV_CH / 4], q2[WKV_CH / 4], q3[WKV_CH / 4], q4[WKV_CH / 4], q5[WKV_CH / 4], q6[WKV_CH / 4];
 #pragma unroll
-        for (int i = 0; i < WKV_CH / 4; ++i) {
-            const int tt = wave + 4 * i;
-            if (tt < n) {
-                const long rb = (long)(row0 + c0 + tt) * C + cb + lane;
-                s_r[tt][lane] = a.r[rb]; s_k[tt][lane] = a.k[rb]; s_v[tt][lane] = a.v[rb];
-                if (a.version == 7) {
-                    s_ka[tt][lane] = a.a7[rb]; s_w[tt][lane] = a.w7[rb];
-                    if (a.layer != 0) { s_o[tt][lane] = a.v_first[rb]; s_kk[tt][lane] = a.vg7[rb]; }
+            for (int i = 0; i < WKV_CH / 4; ++i) {               // rows clamped, not predicated: straight-line loads
+                const long rb = (long)(row0 + c0 + min(wave + 4 * i, n - 1)) * C + cb + lane;
+                q0[i] = a.r[rb]; q1[i] = a.k[rb]; q2[i] = a.v[rb];
+                if (VER == 7) {
+                    q3[i] = a.a7[rb]; q4[i] = a.w7[rb];
+                    if (a.layer != 0) { q5[i] = a.v_first[rb]; q6[i] = a.vg7[rb]; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WKV_CH / 4; ++i) {
+                const int tt = wave + 4 * i;
+                if (tt < n) {
+                    s_r[tt][lane] = q0[i]; s_k[tt][lane] = q1[i]; s_v[tt][lane] = q2[i];
+                    if (VER == 7) {
+                        s_ka[tt][lane] = q3[i]; s_w[tt][lane] = q4[i];
+                        if (a.layer != 0) { s_o[tt][lane] = q5[i]; s_kk[tt][lane] = q6[i]; }
+                    }
                 }
             }
         }
-        if (a.version == 6) {                            // td rows of the chunk -> LDS (coalesced), read back as broadcasts
+        if (c0 == 0) TRACE_K(3, 1);
+        if (VER == 6) {                            // td rows of the chunk -> LDS (coalesced), read back as broadcasts
             const float *tdp = a.td + (long)(row0 + c0) * Dd;
             for (int i = tid * 4; i < n * Dd; i += 256 * 4) *(float4 *)(s_td + i) = *(const float4 *)(tdp + i);
             __syncthreads();
         }
+        f16x8 d2r[DD / 8];                               // V6: this channel's row of D2 (L2-hot; scoped to the phase so that
+        if (VER == 6) {                            // its 64 registers are free again during the recurrence)
+            const _Float16 *d2 = a.D2 + (long)(cb + lane) * Dd;
+#pragma unroll
+            for (int d8 = 0; d8 < DD / 8; ++d8) d2r[d8] = *(const f16x8 *)(d2 + d8 * 8);
+        }
         for (int tt = wave; tt < n; tt += 4) {
-            if (a.version == 5) {
+            if (VER == 5) {
                 s_w[tt][lane] = wconst;
-            } else if (a.version == 6) {
+            } else if (VER == 6) {
                 // decay LoRA stage 2 in the decode kernel's order: four partial sums over Dd/4, combined (p0+p1)+(p2+p3)
                 const float *tdl = s_td + tt * Dd;
-                const float dd = Dd == 64 ? wkv_decay_dot<64>(d2r, tdl) : wkv_decay_dot<128>(d2r, tdl);
+                const float dd = wkv_decay_dot<DD>(d2r, tdl);
                 s_w[tt][lane] = expf(-expf(decay0 + dd));
             } else {
                 const float av = s_ka[tt][lane];
@@ -1650,19 +1663,19 @@ __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
                 s_k[tt][lane] = k; s_v[tt][lane] = v;
             }
         }
+        if (c0 == 0) TRACE_K(3, 2);
         __syncthreads();
+        if (c0 == 0) TRACE_K(3, 3);
         // ---- phase B: the recurrence; thread (ig, jg) owns T[p = aa*16+ig][q = jg*4 .. +4]
         float4 uq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.version != 7) uq = *(const float4 *)(s_u + jg * 4);
-        for (int tt = 0; tt < n; ++tt) {
-            const float4 rq = *(const float4 *)(&s_r[tt][jg * 4]);
-            const float4 kq = *(const float4 *)(&s_k[tt][jg * 4]);
-            const float4 wq = *(const float4 *)(&s_w[tt][jg * 4]);
+        if (VER != 7) uq = *(const float4 *)(s_u + jg * 4);
+        // one wave per SIMD: no other wave hides the LDS latency, so four tokens' LDS rows are fetched per trip
+        auto step = [&](int tt, const float4 &rq, const float4 &kq, const float4 &wq, const float4 &nk, const float4 &ka, const float (&vp4)[4]) {
             float outp[4];
-            if (a.version != 7) {
+            if (VER != 7) {
 #pragma unroll
                 for (int aa = 0; aa < 4; ++aa) {
-                    const float vp = s_v[tt][aa * 16 + ig];
+                    const float vp = vp4[aa];
                     float4 &S = T[aa];
                     float o, kv;
                     kv = kq.x * vp; o = rq.x * (uq.x * kv + S.x); S.x = kv + wq.x * S.x;
@@ -1672,11 +1685,9 @@ __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
                     outp[aa] = sum16(o);
                 }
             } else {
-                const float4 nk = *(const float4 *)(&s_kk[tt][jg * 4]);
-                const float4 ka = *(const float4 *)(&s_ka[tt][jg * 4]);
 #pragma unroll
                 for (int aa = 0; aa < 4; ++aa) {
-                    const float vp = s_v[tt][aa * 16 + ig];
+                    const float vp = vp4[aa];
                     float4 &S = T[aa];
                     float sa = S.x * nk.x + S.y * nk.y + S.z * nk.z + S.w * nk.w;
                     sa = sum16(sa);
@@ -1692,7 +1703,25 @@ __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
 #pragma unroll
                 for (int aa = 0; aa < 4; ++aa) s_o[tt][aa * 16 + ig] = outp[aa];
             }
+        };
+        for (int t4 = 0; t4 < n; t4 += 4) {
+            float4 rq[4], kq[4], wq[4], nk[4], ka[4];
+            float vp[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                        // rows beyond n are read (LDS, harmless) and never used
+                const int tt = min(t4 + u, WKV_CH - 1);
+                rq[u] = *(const float4 *)(&s_r[tt][jg * 4]);
+                kq[u] = *(const float4 *)(&s_k[tt][jg * 4]);
+                wq[u] = *(const float4 *)(&s_w[tt][jg * 4]);
+                if (VER == 7) { nk[u] = *(const float4 *)(&s_kk[tt][jg * 4]); ka[u] = *(const float4 *)(&s_ka[tt][jg * 4]); }
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa) vp[u][aa] = s_v[tt][aa * 16 + ig];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t4 + u < n) step(t4 + u, rq[u], kq[u], wq[u], nk[u], ka[u], vp[u]);
         }
+        if (c0 == 0) TRACE_K(3, 4);
         __syncthreads();
         // ---- phase C: GroupNorm over the head (eps 64e-5), bonus (V7), gate, operand emit; wave w takes tokens w, w+4, ...
 #pragma unroll
@@ -1707,7 +1736,7 @@ __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
             const float d = o - mean;
             const float var = wave_sum(d * d) * (1.0f / 64.0f);
             float y = d / sqrtf(var + 64e-5f) * lnw + lnb;
-            if (a.version == 7) {
+            if (VER == 7) {
                 const float bonus = wave_sum(s_r[tt][lane] * s_k[tt][lane] * rk_p);
                 y += bonus * s_v[tt][lane];
             }
@@ -1718,13 +1747,19 @@ __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
             a.yhi[yo] = hh;
             if (a.ylo) a.ylo[yo] = ll;
         }
+        if (c0 == 0) TRACE_K(3, 5);
         __syncthreads();                                   // the next chunk overwrites the LDS rows
     }
+    TRACE_K(3, 6);
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, T[aa]), (f32x4 *)(st + (aa * 16 + ig) * 64 + jg * 4));
+    TRACE_K(3, 7);
 }
 void launch_wkv(const WkvArgs &a, bool multi_row, hipStream_t s) {
-    if (multi_row && (a.version != 6 || a.Dd == 64 || a.Dd == 128)) hipLaunchKernelGGL(wkv_chunk_kernel, dim3(a.n_seq, a.H), dim3(256), 0, s, a);
+    if (multi_row && a.version == 5) hipLaunchKernelGGL((wkv_chunk_kernel<5, 64>), dim3(a.n_seq, a.H), dim3(256), 0, s, a);
+    else if (multi_row && a.version == 6 && a.Dd == 64) hipLaunchKernelGGL((wkv_chunk_kernel<6, 64>), dim3(a.n_seq, a.H), dim3(256), 0, s, a);
+    else if (multi_row && a.version == 6 && a.Dd == 128) hipLaunchKernelGGL((wkv_chunk_kernel<6, 128>), dim3(a.n_seq, a.H), dim3(256), 0, s, a);
+    else if (multi_row && a.version == 7) hipLaunchKernelGGL((wkv_chunk_kernel<7, 64>), dim3(a.n_seq, a.H), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(wkv_kernel, dim3(a.n_seq, a.H), dim3(256), 0, s, a);
 }
 
