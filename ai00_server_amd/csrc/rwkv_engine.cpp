@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -250,6 +251,7 @@ struct rwkv_engine {
     // graph cache for decode-shaped steps
     struct GraphEntry { hipGraphExec_t exec = nullptr; };
     std::map<uint64_t, GraphEntry> graphs;
+    std::set<uint64_t> graph_seen;
     bool use_graphs = true;
 
     template <class T>
@@ -1096,6 +1098,13 @@ void rwkv_engine::run_plan(const StepPlan &pl) {
     const uint64_t key = ((uint64_t)pl.T << 40) | ((uint64_t)pl.n_seq << 20) | (uint64_t)pl.n_out;
     if (use_graphs && !profiling) {
         auto it = graphs.find(key);
+        // a shape is captured the SECOND time it shows up: decode-shaped steps repeat at once, while the one-off shapes of
+        // prefill tails would pay capture + instantiation (milliseconds) for a single replay and churn the cache
+        if (it == graphs.end() && graph_seen.insert(key).second) {
+            if (graph_seen.size() > 4096) graph_seen.clear();
+            run_layers(pl.T, pl.n_seq, pl.n_out, d_meta);
+            return;
+        }
         if (it == graphs.end()) {
             hipGraph_t g = nullptr;
             HIP_CHECK(hipStreamBeginCapture(s_main, hipStreamCaptureModeThreadLocal));

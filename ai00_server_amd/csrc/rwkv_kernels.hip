@@ -1723,29 +1723,49 @@ __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
         }
         if (c0 == 0) TRACE_K(3, 4);
         __syncthreads();
-        // ---- phase C: GroupNorm over the head (eps 64e-5), bonus (V7), gate, operand emit; wave w takes tokens w, w+4, ...
+        // ---- phase C: GroupNorm over the head (eps 64e-5), bonus (V7), gate, operand emit — all tokens of the chunk at
+        //      once: thread = (token tid>>3, 8 channels (tid&7)*8 ..), sums over the 8 lanes of a token
+        {
+            const int tt = tid >> 3, c8 = (tid & 7) * 8;
+            auto sum8 = [](float v) {                            // the 8 lanes sharing tid>>3 (half a DPP row)
+                v = quad_sum(v);
+                return v + __shfl_xor(v, 4, 64);
+            };
+            if (tt < n) {                                         // the 8 lanes of a token take the branch together
+                const int t = row0 + c0 + tt;
+                const float4 g0 = *(const float4 *)(a.g + (long)t * C + cb + c8), g1 = *(const float4 *)(a.g + (long)t * C + cb + c8 + 4);
+                const float4 o0 = *(const float4 *)(&s_o[tt][c8]), o1 = *(const float4 *)(&s_o[tt][c8 + 4]);
+                float o[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                float sm = 0.f;
 #pragma unroll
-        for (int i = 0; i < WKV_CH / 4; ++i) {               // gates of the chunk: loads back to back, parked in s_w (free after B)
-            const int tt = wave + 4 * i;
-            if (tt < n) s_w[tt][lane] = a.g[(long)(row0 + c0 + tt) * C + cb + lane];
-        }
-        for (int tt = wave; tt < n; tt += 4) {
-            const int t = row0 + c0 + tt;
-            const float o = s_o[tt][lane];
-            const float mean = wave_sum(o) * (1.0f / 64.0f);
-            const float d = o - mean;
-            const float var = wave_sum(d * d) * (1.0f / 64.0f);
-            float y = d / sqrtf(var + 64e-5f) * lnw + lnb;
-            if (VER == 7) {
-                const float bonus = wave_sum(s_r[tt][lane] * s_k[tt][lane] * rk_p);
-                y += bonus * s_v[tt][lane];
+                for (int e = 0; e < 8; ++e) sm += o[e];
+                const float mean = sum8(sm) * (1.0f / 64.0f);
+                float sq = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { o[e] -= mean; sq += o[e] * o[e]; }
+                const float rstd = 1.0f / sqrtf(sum8(sq) * (1.0f / 64.0f) + 64e-5f);
+                float bonus = 0.f;
+                if (VER == 7) {
+                    float bs = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bs += s_r[tt][c8 + e] * s_k[tt][c8 + e] * a.r_k[cb + c8 + e];
+                    bonus = sum8(bs);
+                }
+                f16x8 hh, ll;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float y = o[e] * rstd * a.lnx_w[cb + c8 + e] + a.lnx_b[cb + c8 + e];
+                    if (VER == 7) y += bonus * s_v[tt][c8 + e];
+                    y *= gg[e];
+                    _Float16 h, l;
+                    split_hilo(y, h, l);
+                    hh[e] = h; ll[e] = l;
+                }
+                const long yo = opd_off(t, cb + c8, a.ldh);           // 8 consecutive k of one token: one 16-byte piece
+                *(f16x8 *)(a.yhi + yo) = hh;
+                if (a.ylo) *(f16x8 *)(a.ylo + yo) = ll;
             }
-            y *= s_w[tt][lane];
-            _Float16 hh, ll;
-            split_hilo(y, hh, ll);
-            const long yo = opd_off(t, cb + lane, a.ldh);
-            a.yhi[yo] = hh;
-            if (a.ylo) a.ylo[yo] = ll;
         }
         if (c0 == 0) TRACE_K(3, 5);
         __syncthreads();                                   // the next chunk overwrites the LDS rows
