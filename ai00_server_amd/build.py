@@ -13,7 +13,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librwkv_hip.so")
 SOURCES = ["rwkv_kernels.hip", "rwkv_engine.cpp", "tokenizer.cpp"]
 DEPS = SOURCES + ["rwkv_kernels.h", "safetensors.hpp", os.path.join("..", "..", "include", "rwkv_abi.h"),
-               os.path.join("..", "..", "include", "rwkv_runtime.hpp"), os.path.join("..", "..", "harness", "decode_loop.cpp")]
+               os.path.join("..", "..", "include", "rwkv_runtime.hpp"), os.path.join("..", "..", "include", "rwkv_scheduler.hpp"),
+               os.path.join("..", "..", "harness", "decode_loop.cpp"), os.path.join("..", "..", "harness", "serve_loop.cpp")]
 
 
 def _hipcc() -> str:
@@ -38,7 +39,7 @@ def _sources_digest() -> str:
 
 def needs_build() -> bool:
     """Content-based (mtimes do not survive the copy to a GPU box): rebuild when a source differs from the stamp."""
-    if not os.path.exists(LIB) or not os.path.exists(HARNESS_BIN) or not os.path.exists(STAMP):
+    if not os.path.exists(LIB) or not os.path.exists(HARNESS_BIN) or not os.path.exists(SERVE_BIN) or not os.path.exists(STAMP):
         return True
     return open(STAMP).read().strip() != _sources_digest()
 
@@ -70,14 +71,17 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 HARNESS_SRC = os.path.join(HERE, "..", "harness", "decode_loop.cpp")
 HARNESS_BIN = os.path.join(HERE, "..", "harness", "decode_loop")
+SERVE_SRC = os.path.join(HERE, "..", "harness", "serve_loop.cpp")
+SERVE_BIN = os.path.join(HERE, "..", "harness", "serve_loop")
 
 
 def build_harness(verbose: bool = True) -> str:
     """C++ mirror of ai00-core's infer task + greedy loop (harness/decode_loop.cpp), linked against the .so."""
-    cmd = ["g++", "-O2", "-std=c++17", HARNESS_SRC, "-o", HARNESS_BIN, "-L" + HERE, "-lrwkv_hip", "-Wl,-rpath," + HERE]
-    if verbose:
-        print("[build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    for src, exe in ((HARNESS_SRC, HARNESS_BIN), (SERVE_SRC, SERVE_BIN)):
+        cmd = ["g++", "-O2", "-std=c++17", src, "-o", exe, "-L" + HERE, "-lrwkv_hip", "-Wl,-rpath," + HERE]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return HARNESS_BIN
 
 

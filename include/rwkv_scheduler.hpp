@@ -1,0 +1,229 @@
+// rwkv_scheduler.hpp — C++ mirror of the scheduling core of ai00-core's runtime (crates/ai00-core/src/run.rs), on top
+// of anything shaped like rwkv::Runtime (include/rwkv_runtime.hpp).  SURVEY §8 row f-3.
+//
+//   SlotState / SlotChoice     run.rs:289-331   which idle slot takes a new request: continue > empty > back, ties by idle age
+//   PrefixCache::checkout      run.rs:441-485   longest cached token prefix -> (state, last output); miss -> initial state
+//   Scheduler::queue           run.rs:488-626   pick a slot, check the state out of the cache, load it, split prefix / suffix
+//   Scheduler::step            run.rs:1113-1157 one `infer` over EVERY slot that has tokens pending
+//   Scheduler::finish          run.rs:629-662   busy slot -> Idle(content), state + output cached under the content
+//
+// Differences from the reference, on purpose: (1) synchronous — the caller owns the thread (the reference spreads this over
+// tokio tasks and channels; the decisions are the same); (2) `step()` re-collects the pending tokens of all busy slots on
+// every call, so a request queued while others are mid-flight rides the very next device step (the reference only forms a
+// batch from what is already waiting when the infer task wakes up: run.rs:1120-1132, the "opportunistic batch gap");
+// (3) the cache is bounded by item count (`max_cached`), evicting the stalest items.
+//
+// Header-only, no HIP: `Engine` needs  int max_batch;  ModelInfo info;  State state (init/load/back);
+//                                       std::vector<RnnOutputBatch> infer(RnnInput &)  (consumes tokens in place).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <vector>
+
+#include "rwkv_runtime.hpp"
+
+namespace rwkv {
+
+using Tokens = std::vector<uint32_t>;
+
+struct CachedItem {                              // run.rs:201-223
+    std::vector<float> state;                    // public slab [C, N+2, L, 1]
+    std::vector<float> output;                   // logits of the last token of the cached prefix
+    uint64_t stamp = 0;                          // logical clock (the reference uses Instant)
+};
+
+class PrefixCache {                              // `Trie<Tokens, CachedItem>` keyed by whole token sequences
+   public:
+    explicit PrefixCache(size_t max_cached = 64) : max_cached_(max_cached) {}
+    struct Checkout { size_t prefix_len = 0; std::vector<float> state, output; bool hit = false; };
+    // longest cached key that is a prefix of `tokens` (run.rs:447-455); refreshes the item's stamp (CachedItem::update)
+    Checkout checkout(const Tokens &tokens, uint64_t now) {
+        Checkout c;
+        const Node *n = &root_;
+        const Node *best = nullptr;
+        size_t best_len = 0;
+        for (size_t i = 0; i < tokens.size(); ++i) {
+            auto it = n->next.find(tokens[i]);
+            if (it == n->next.end()) break;
+            n = it->second.get();
+            if (n->item) { best = n; best_len = i + 1; }
+        }
+        if (best) {
+            best->item->stamp = now;
+            c.prefix_len = best_len; c.state = best->item->state; c.output = best->item->output; c.hit = true;
+        }
+        return c;
+    }
+    void insert(const Tokens &tokens, std::vector<float> state, std::vector<float> output, uint64_t now) {
+        if (tokens.empty()) return;
+        Node *n = &root_;
+        for (uint32_t t : tokens) {
+            auto &slot = n->next[t];
+            if (!slot) slot.reset(new Node());
+            n = slot.get();
+        }
+        if (!n->item) { n->item.reset(new CachedItem()); ++count_; }
+        n->item->state = std::move(state); n->item->output = std::move(output); n->item->stamp = now;
+        while (count_ > max_cached_) evict_oldest();
+    }
+    size_t size() const { return count_; }
+
+   private:
+    struct Node { std::map<uint32_t, std::unique_ptr<Node>> next; std::unique_ptr<CachedItem> item; };
+    static void oldest(Node *n, Node *&arg, uint64_t &stamp) {
+        if (n->item && n->item->stamp < stamp) { stamp = n->item->stamp; arg = n; }
+        for (auto &kv : n->next) oldest(kv.second.get(), arg, stamp);
+    }
+    void evict_oldest() {
+        Node *arg = nullptr;
+        uint64_t stamp = ~0ull;
+        oldest(&root_, arg, stamp);
+        if (arg) { arg->item.reset(); --count_; }
+    }
+    Node root_;
+    size_t count_ = 0, max_cached_;
+};
+
+enum class SlotKind { Idle, Busy };
+struct SlotState {                               // run.rs:289-302 (Locked only exists between awaits there)
+    SlotKind kind = SlotKind::Idle;
+    Tokens content;                              // Idle: the tokens whose state the slot holds; Busy: prefix consumed so far
+    uint64_t since = 0;                          // Idle: when it became idle
+};
+
+struct SlotChoice {                              // run.rs:304-331
+    enum Kind { Back = 0, Empty = 1, Continue = 2 } kind;
+    int batch;
+    size_t len;                                  // Continue: length of the matching content
+    // priority: continue (longer match first) > empty > back
+    static int cmp(const SlotChoice &a, const SlotChoice &b) {
+        if (a.kind == Continue && b.kind == Continue) return a.len < b.len ? -1 : a.len > b.len ? 1 : 0;
+        return a.kind < b.kind ? -1 : a.kind > b.kind ? 1 : 0;
+    }
+};
+
+enum class SlotResult { Success, Fault, Failure };   // run.rs: Success(batch) / Fault(batch) (had to back a slot) / Failure (all busy)
+
+template <class Engine>
+class Scheduler {
+   public:
+    struct Request {
+        Tokens prefix, suffix;                   // consumed / still to feed (GenerateContext::{prefix, suffix})
+        std::vector<float> output;               // logits after the last consumed token (empty until one exists)
+        RnnOption option = RnnOption::Last;
+        std::vector<std::vector<float>> rows;    // Full: one entry per emitted row
+    };
+
+    explicit Scheduler(Engine &e, size_t max_cached = 64) : e_(e), slots_(e.max_batch), reqs_(e.max_batch), cache_(max_cached) {}
+
+    // run.rs:488-626.  On Success / Fault `batch` is the slot now Busy with the request.
+    SlotResult queue(Tokens tokens, int &batch, RnnOption option = RnnOption::Last) {
+        if (tokens.empty()) tokens = {0};                              // run.rs:489-492
+        ++clock_;
+        bool have = false;
+        SlotChoice best{SlotChoice::Back, -1, 0};
+        uint64_t best_idle = 0;
+        for (int b = 0; b < (int)slots_.size(); ++b) {
+            const SlotState &s = slots_[b];
+            if (s.kind != SlotKind::Idle) continue;
+            SlotChoice c{SlotChoice::Back, b, 0};
+            if (s.content.empty()) c.kind = SlotChoice::Empty;
+            else if (s.content.size() <= tokens.size() && std::equal(s.content.begin(), s.content.end(), tokens.begin())) {
+                c.kind = SlotChoice::Continue; c.len = s.content.size();
+            }
+            const uint64_t idle = clock_ - s.since;                    // `instant.elapsed()`
+            const int k = have ? SlotChoice::cmp(c, best) : 1;
+            // max_by keeps the LAST maximum on ties (Iterator::max_by), so `>=` on the secondary key
+            if (!have || k > 0 || (k == 0 && idle >= best_idle)) { best = c; best_idle = idle; have = true; }
+        }
+        if (!have) return SlotResult::Failure;                         // every slot is busy: hand the request back
+        batch = best.batch;
+        // check the state out of the cache (longest cached prefix, else the initial state) and load it into the slot.
+        // (The reference does this for all three choices, Continue included: run.rs:548-626.)
+        PrefixCache::Checkout co = cache_.checkout(tokens, clock_);
+        if (co.hit && co.prefix_len == tokens.size())     // the whole request is cached: replay its last token so that the
+            co = cache_.checkout(Tokens(tokens.begin(), tokens.end() - 1), clock_);   // output row comes from the engine
+        const size_t len = co.hit ? co.prefix_len : 0;
+        if (co.hit) e_.state.load(co.state, batch);
+        else e_.state.load(e_.state.init(), batch);
+        Request r;
+        r.prefix.assign(tokens.begin(), tokens.begin() + (long)len);
+        r.suffix.assign(tokens.begin() + (long)len, tokens.end());
+        r.output = co.hit ? co.output : std::vector<float>();
+        r.option = option;
+        reqs_[batch] = std::move(r);
+        const bool back = best.kind == SlotChoice::Back;
+        slots_[batch].kind = SlotKind::Busy;
+        slots_[batch].content.clear();
+        return back ? SlotResult::Fault : SlotResult::Success;
+    }
+
+    // feed more tokens to a busy slot (the decode loop appends the sampled token: run.rs:1004-1010)
+    void push(int batch, uint32_t token) { need_busy(batch); reqs_[batch].suffix.push_back(token); }
+    bool pending() const {
+        for (size_t b = 0; b < slots_.size(); ++b) if (slots_[b].kind == SlotKind::Busy && !reqs_[b].suffix.empty()) return true;
+        return false;
+    }
+
+    // one device step over every busy slot with tokens pending; returns the number of slots that rode it
+    int step() {
+        RnnInput in;
+        in.batches.resize(slots_.size());
+        int riders = 0;
+        for (size_t b = 0; b < slots_.size(); ++b) {
+            if (slots_[b].kind != SlotKind::Busy || reqs_[b].suffix.empty()) continue;
+            in.batches[b].tokens = reqs_[b].suffix;
+            in.batches[b].option = reqs_[b].option;
+            ++riders;
+        }
+        if (!riders) return 0;
+        std::vector<RnnOutputBatch> out = e_.infer(in);
+        const size_t V = (size_t)e_.info.num_vocab;
+        for (size_t b = 0; b < slots_.size(); ++b) {
+            if (slots_[b].kind != SlotKind::Busy || reqs_[b].suffix.empty()) continue;
+            Request &r = reqs_[b];
+            const size_t consumed = r.suffix.size() - in.batches[b].tokens.size();
+            r.prefix.insert(r.prefix.end(), r.suffix.begin(), r.suffix.begin() + (long)consumed);
+            r.suffix.erase(r.suffix.begin(), r.suffix.begin() + (long)consumed);
+            for (size_t row = 0; row + 1 <= out[b].size() / V; ++row) {
+                std::vector<float> lg(out[b].begin() + (long)(row * V), out[b].begin() + (long)((row + 1) * V));
+                if (r.option == RnnOption::Full) r.rows.push_back(lg);
+                r.output = std::move(lg);
+            }
+        }
+        return riders;
+    }
+
+    Request &request(int batch) { need_busy(batch); return reqs_[batch]; }
+
+    // run.rs:629-662 + the cache write at the end of `process` (run.rs:1012-1020): the slot becomes Idle(content) and its
+    // state + last output are cached under the content, so a later request with that prefix continues from it.
+    void finish(int batch) {
+        need_busy(batch);
+        Request &r = reqs_[batch];
+        if (!r.suffix.empty()) throw std::logic_error("finish(): tokens still pending");
+        ++clock_;
+        if (!r.prefix.empty() && !r.output.empty()) cache_.insert(r.prefix, e_.state.back(batch), r.output, clock_);
+        slots_[batch].kind = SlotKind::Idle;
+        slots_[batch].content = r.prefix;
+        slots_[batch].since = clock_;
+    }
+
+    const SlotState &slot(int batch) const { return slots_.at((size_t)batch); }
+    PrefixCache &cache() { return cache_; }
+
+   private:
+    void need_busy(int batch) const {
+        if (batch < 0 || batch >= (int)slots_.size() || slots_[(size_t)batch].kind != SlotKind::Busy) throw std::invalid_argument("slot is not busy");
+    }
+    Engine &e_;
+    std::vector<SlotState> slots_;
+    std::vector<Request> reqs_;
+    PrefixCache cache_;
+    uint64_t clock_ = 0;
+};
+
+}  // namespace rwkv

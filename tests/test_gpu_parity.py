@@ -486,3 +486,33 @@ def test_prefab_round_trip_is_bit_exact(name, quant, tmp_path):
     with pytest.raises(rt.RwkvError) as e:
         rt.ModelBuilder(image).lora(lora, 0.5).build(max_batch=1)
     assert e.value.code == -3
+
+
+def test_cpp_scheduler_serves_real_engine(tmp_path):
+    """harness/serve_loop.cpp: include/rwkv_scheduler.hpp (slot choice, prefix cache, continuous batching — run.rs:289-331,
+    441-662, 1113-1157) over the real engine.  A runs alone, B joins mid-flight, both decode greedily; C = A's whole
+    history + a tail continues from the cached state.  Token ids must equal the oracle's for every stage."""
+    import subprocess
+    from ai00_server_amd import build as B
+    B.build(verbose=False)
+    t = R.synth_named("v6-small")
+    path = tmp_path / "m.st"
+    path.write_bytes(R.st_serialize(t))
+    ref = R.RwkvRef(t, 2, R.QUANT_INT8)
+    p0, p1, tail = prompt(ref, 60, 21), prompt(ref, 61, 5), prompt(ref, 62, 4)
+    n_new = 6
+    args = [B.SERVE_BIN, str(path), "2", "1", "3", "8", str(n_new)] + [str(x) for x in p0] + ["/"] + [str(x) for x in p1] + ["/"] + [str(x) for x in tail]
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    gen_a, gen_b, gen_c = ([int(x) for x in ln.split()] for ln in lines[:3])
+    meta = [int(x) for x in lines[3].split()[1:]]
+    want_a, _ = ref.greedy(p0, n_new)
+    want_b, _ = ref.greedy(p1, n_new)
+    assert gen_a == want_a[:n_new] and gen_b == want_b[:n_new]
+    want_c, _ = ref.greedy(p0 + gen_a + tail, n_new)
+    assert gen_c == want_c[:n_new]
+    riders_first, riders_second, slot_a, slot_c, rc, c_prefix = meta
+    assert riders_first == 1 and riders_second == 2          # 21 prompt tokens at chunk 8: A is mid-flight when B joins
+    assert slot_c == slot_a and rc == 0                       # Continue on A's slot, SlotResult::Success
+    assert c_prefix == len(p0) + n_new                        # checked out at A's full history (prompt + every fed token)
