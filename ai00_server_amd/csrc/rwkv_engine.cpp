@@ -1159,7 +1159,9 @@ void rwkv_engine::infer_sample(const rwkv_slot_input *in, const rwkv_sample_para
         if (!(p.temperature > 0.f)) throw RwkvError(RWKV_ERR_INVALID, "temperature must be > 0");
         if (p.n_adj && (!p.adj_tokens || !p.adj_values)) throw RwkvError(RWKV_ERR_INVALID, "null adjustment arrays");
         if (nadj + p.n_adj > ADJ_CAP) throw RwkvError(RWKV_ERR_INVALID, "too many logit adjustments");
-        hs[r] = SampleRow{p.top_p, p.top_k, p.temperature, p.uniform};
+        if (p.kind != RWKV_SAMPLER_NUCLEUS && p.kind != RWKV_SAMPLER_TYPICAL)
+            throw RwkvError(RWKV_ERR_UNSUPPORTED, "on-device sampler kind must be Nucleus or Typical (Mirostat stays on the host)");
+        hs[r] = SampleRow{p.top_p, p.top_k, p.temperature, p.uniform, p.kind, p.tau};
         for (size_t i = 0; i < p.n_adj; ++i, ++nadj) { h_row[nadj] = r; h_tok[nadj] = (int)p.adj_tokens[i]; h_val[nadj] = p.adj_values[i]; }
     }
     run_plan(pl);

@@ -1932,7 +1932,27 @@ __global__ __launch_bounds__(NUC_THREADS) void nucleus_kernel(const float *logit
 #pragma unroll
     for (int j = 0; j < NUC_EPT; ++j) p[j] = p[j] / s;
 
-    // ---- radix select of the k-th largest probability (positive floats: bit patterns are order-preserving)
+    // ---- Typical sampling (typical.rs:70-108): the sort key is |(-ln p) - H| ascending over p > 0, H = sum p (-ln p).
+    //      The registers are re-used for the key, stored as 0xFFFFFFFF - bits(key) (0 for p == 0), so that the
+    //      "k largest, descending" machinery below selects the k smallest keys in ascending order; the few surviving
+    //      probabilities are recomputed from the logits with the same two operations.
+    const bool typical = P.kind == 1;
+    if (typical) {
+        float h = 0.f;
+#pragma unroll
+        for (int j = 0; j < NUC_EPT; ++j) h += p[j] > 0.f ? p[j] * -logf(p[j]) : 0.f;
+        h = block_reduce_1024(h, red, false);
+#pragma unroll
+        for (int j = 0; j < NUC_EPT; ++j)
+            p[j] = __uint_as_float(p[j] > 0.f ? 0xFFFFFFFFu - __float_as_uint(fabsf(-logf(p[j]) - h)) : 0u);
+    }
+    auto prob_of = [&](unsigned long long e) {                     // probability of a sorted candidate
+        if (!typical) return __uint_as_float((unsigned)(e >> 32));
+        const int id = (int)(0xFFFFFFFFu - (unsigned)(e & 0xFFFFFFFFull));
+        return expf(x[id] - m) / s;
+    };
+    const float cut = typical ? P.tau : P.top_p;
+    // ---- radix select of the k-th largest key (positive floats / complemented keys: bit patterns are order-preserving)
     int k = P.top_k < 1 ? 1 : (P.top_k > 256 ? 256 : P.top_k);
     if (k > V) k = V;
     if (tid == 0) { sel[0] = 0u; sel[1] = (unsigned)k; sel[2] = 0u; }
@@ -1992,14 +2012,14 @@ __global__ __launch_bounds__(NUC_THREADS) void nucleus_kernel(const float *logit
         float cum = 0.f;
         int n = 0;
         for (; n < ncand; ++n) {
-            if (cum > P.top_p) break;
-            cum += __uint_as_float((unsigned)(cand[n] >> 32));
+            if (cum > cut) break;
+            cum += prob_of(cand[n]);
         }
         sel[0] = (unsigned)(n < 1 ? 1 : n);
     }
     __syncthreads();
     const int n = (int)sel[0];
-    if (tid < n) qv[tid] = powf(__uint_as_float((unsigned)(cand[tid] >> 32)), 1.0f / P.temperature);   // nucleus.rs:92
+    if (tid < n) qv[tid] = powf(prob_of(cand[tid]), 1.0f / P.temperature);   // nucleus.rs:92, typical.rs:96
     __syncthreads();
     if (tid == 0) {
         float sum = 0.f;
@@ -2012,7 +2032,7 @@ __global__ __launch_bounds__(NUC_THREADS) void nucleus_kernel(const float *logit
         }
         const unsigned long long e = cand[pick];
         out_tok[row] = (int)(0xFFFFFFFFu - (unsigned)(e & 0xFFFFFFFFull));
-        if (out_prob) out_prob[row] = __uint_as_float((unsigned)(e >> 32));
+        if (out_prob) out_prob[row] = prob_of(e);
     }
 }
 

@@ -127,6 +127,18 @@ class NucleusSampler:
         self.penalties[token] = np.float32(self.penalties[token] + self.af) if token in self.penalties else self.ap
 
 
+class TypicalSampler(NucleusSampler):
+    """Host-side state of `TypicalSampler` (sampler/typical.rs:11-140): the same penalty state machine as the nucleus
+    sampler (init typical.rs:47-58, transform :62-68, update :122-133); the device applies tau / top_k / temperature."""
+    kind = 1
+
+    def __init__(self, tau=0.5, top_k=128, temperature=1.0, presence_penalty=0.3, frequency_penalty=0.3,
+                 penalty_decay=0.99654026, bias: dict | None = None):
+        super().__init__(top_p=0.0, top_k=top_k, temperature=temperature, presence_penalty=presence_penalty,
+                         frequency_penalty=frequency_penalty, penalty_decay=penalty_decay, bias=bias)
+        self.tau = float(tau)
+
+
 class ReplicaRouter:
     """Request-level sharding over independent engines (one per GPU): round-robin for batch jobs, least-busy for
     interactive requests.  No collective: each replica owns its weights, slots and stream."""

@@ -54,7 +54,8 @@ class _SlotInC(C.Structure):
 
 class _SampleC(C.Structure):
     _fields_ = [("top_p", C.c_float), ("top_k", C.c_int32), ("temperature", C.c_float), ("uniform", C.c_float),
-                ("adj_tokens", C.POINTER(C.c_uint32)), ("adj_values", C.POINTER(C.c_float)), ("n_adj", C.c_size_t)]
+                ("adj_tokens", C.POINTER(C.c_uint32)), ("adj_values", C.POINTER(C.c_float)), ("n_adj", C.c_size_t),
+                ("kind", C.c_int32), ("tau", C.c_float)]
 
 
 class _SlotOutC(C.Structure):
@@ -399,8 +400,9 @@ class Runtime:
         return self._collect(inp)
 
     def infer_sample(self, inp: RnnInput, samplers: list, uniforms: list):
-        """On-device sampling front-end (rwkv_infer_sample).  `samplers[b]` is None or an object with `.top_p`,
-        `.top_k`, `.temperature` and `.adjustments() -> {token: delta_logit}` (penalties and bias merged);
+        """On-device sampling front-end (rwkv_infer_sample).  `samplers[b]` is None or an object with `.top_k`,
+        `.temperature`, `.adjustments() -> {token: delta_logit}` (penalties and bias merged) and either `.top_p` (nucleus) or
+        `.kind = 1` + `.tau` (typical);
         `uniforms[b]` is the draw `fastrand::f32()` would make.  Returns (inp, [(token, prob) or None per slot])."""
         if len(inp.batches) != self.max_batch:
             raise RwkvError(-1, f"RnnInput must have max_batch={self.max_batch} entries")
@@ -413,15 +415,17 @@ class Runtime:
             ins[b] = _SlotInC(toks.ctypes.data_as(C.POINTER(C.c_uint32)) if toks.size else None, toks.size, 0, 0)
             s = samplers[b]
             if s is None:
-                sps[b] = _SampleC(0.0, 1, 1.0, 0.0, None, None, 0)
+                sps[b] = _SampleC(0.0, 1, 1.0, 0.0, None, None, 0, 0, 0.0)
                 continue
             adj = s.adjustments()
             at = np.fromiter(adj.keys(), dtype=np.uint32, count=len(adj))
             av = np.fromiter(adj.values(), dtype=np.float32, count=len(adj))
             keep += [at, av]
-            sps[b] = _SampleC(s.top_p, s.top_k, s.temperature, uniforms[b],
+            kind = int(getattr(s, "kind", 0))                       # 0 nucleus (top_p), 1 typical (tau)
+            sps[b] = _SampleC(getattr(s, "top_p", 0.0), s.top_k, s.temperature, uniforms[b],
                               at.ctypes.data_as(C.POINTER(C.c_uint32)) if at.size else None,
-                              av.ctypes.data_as(C.POINTER(C.c_float)) if av.size else None, at.size)
+                              av.ctypes.data_as(C.POINTER(C.c_float)) if av.size else None, at.size,
+                              kind, float(getattr(s, "tau", 0.0)))
         toks_o, probs_o = (C.c_uint32 * B)(), (C.c_float * B)()
         emitted, consumed = (C.c_uint8 * B)(), (C.c_size_t * B)()
         _check(lib().rwkv_infer_sample(self._h, ins, sps, toks_o, probs_o, emitted, consumed))

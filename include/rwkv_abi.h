@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RWKV_ABI_VERSION 1
+#define RWKV_ABI_VERSION 2   /* 2: rwkv_sample_params gained kind/tau; rwkv_engine_save_prefab */
 
 typedef int32_t rwkv_status;
 enum {
@@ -160,7 +160,13 @@ typedef struct rwkv_sample_params {
     const uint32_t *adj_tokens;    /* may be NULL when n_adj == 0 */
     const float *adj_values;       /* added to logits[adj_tokens[i]] before the softmax */
     size_t n_adj;
+    int32_t kind;                  /* RWKV_SAMPLER_NUCLEUS (top_p / top_k / temperature) or RWKV_SAMPLER_TYPICAL:          */
+    float tau;                     /* TypicalSampler::sample (sampler/typical.rs:70-120): keys |(-ln p) - H| ascending,     */
+                                   /* take top_k, keep while the cumulative probability before an element is <= tau        */
+                                   /* (TypicalParams defaults 0.5 / 128 / 1.0, typical.rs:11-27).  Mirostat (a state        */
+                                   /* machine over the full sorted distribution, mirostat.rs:44-90) stays on the host.      */
 } rwkv_sample_params;
+enum { RWKV_SAMPLER_NUCLEUS = 0, RWKV_SAMPLER_TYPICAL = 1 };
 /* Like rwkv_infer with RWKV_OPTION_LAST on every slot, but slots whose pending tokens are exhausted by this call
  * get a sampled token id (out_tokens[b], emitted[b] = 1, out_probs[b] = its softmax probability) instead of a
  * logits row; only 8 bytes per slot cross PCIe.  n_consumed[b] as in rwkv_slot_output.  num_vocab <= 65536. */

@@ -686,6 +686,41 @@ def nucleus_ref(probs: np.ndarray, top_p: float, top_k: int, temperature: float,
     return int(kept[0]), margin
 
 
+def typical_ref(probs: np.ndarray, tau: float, top_k: int, temperature: float, u: float, h_shift: float = 0.0):
+    """`TypicalSampler::sample` (typical.rs:70-120) with the random draw `u` made explicit: over p > 0, surprise
+    y = -ln p, entropy H = sum p y, sort by |y - H| ascending (ties: lower id first), take top_k, keep while the
+    cumulative probability BEFORE the element is <= tau, p^(1/T), renormalise, first element with u <= cumulative, else
+    the first.  Returns (token, margin of the decisive CDF comparison).  `h_shift` perturbs H: it is a many-term fp32 sum
+    whose last bits depend on the summation order, and two keys on opposite sides of H swap when H moves by half their
+    gap — a checker compares against the answers for a few shifts."""
+    p = probs.astype(np.float32)
+    ids = np.nonzero(p > 0)[0]
+    y = -np.log(p[ids]).astype(np.float32)
+    h = np.float32(0.0)
+    for a, b in zip(p[ids], y):
+        h = np.float32(h + np.float32(a * b))
+    h = np.float32(h + np.float32(h_shift))
+    key = np.abs(y - h).astype(np.float32)
+    order = np.lexsort((ids, key))[:max(1, top_k)]
+    kept, cum = [], np.float32(0.0)
+    for o in order:
+        if cum > np.float32(tau):
+            break
+        cum = np.float32(cum + p[ids[o]])
+        kept.append(o)
+    q = np.array([np.float32(p[ids[o]]) ** np.float32(1.0 / temperature) for o in kept], dtype=np.float32)
+    s_ = np.float32(0.0)
+    for x in q:
+        s_ = np.float32(s_ + x)
+    c, margin = np.float32(0.0), 1.0
+    for o, x in zip(kept, q):
+        c = np.float32(c + np.float32(x / s_))
+        margin = min(margin, abs(float(c) - u))
+        if np.float32(u) <= c:
+            return int(ids[o]), margin
+    return int(ids[kept[0]]), margin
+
+
 class NucleusRef:
     """State machine of `NucleusSampler` (nucleus.rs:13-122): penalties map, init/transform/update."""
 

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     for name in sorted(declared):
         assert hasattr(l, name), f"{name} declared in rwkv_abi.h but not exported"
     assert declared == set(rt.ABI_SYMBOLS), declared ^ set(rt.ABI_SYMBOLS)
-    assert rt.lib().rwkv_abi_version() == 1
+    assert rt.lib().rwkv_abi_version() == 2
 
 
 def test_model_info_and_format_errors(built_lib):

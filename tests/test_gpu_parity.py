@@ -516,3 +516,60 @@ def test_cpp_scheduler_serves_real_engine(tmp_path):
     assert riders_first == 1 and riders_second == 2          # 21 prompt tokens at chunk 8: A is mid-flight when B joins
     assert slot_c == slot_a and rc == 0                       # Continue on A's slot, SlotResult::Success
     assert c_prefix == len(p0) + n_new                        # checked out at A's full history (prompt + every fed token)
+
+
+def test_on_device_typical_sampling_matches_reference_sampler():
+    """rwkv_infer_sample with kind = Typical (keys |(-ln p) - H| ascending -> top_k -> tau -> temperature -> inverse CDF on
+    the device) against the restatement of sampler/typical.rs on the SAME logits, penalties and bias included."""
+    from ai00_server_amd.harness import TypicalSampler
+    t, eng = build("v6-small", rt.Precision.Fp16, B=3, chunk=16)
+    ref = R.RwkvRef(t)
+    rng = np.random.default_rng(78)
+    cfgs = [dict(tau=0.5, top_k=128, temperature=1.0), dict(tau=0.9, top_k=40, temperature=0.7),
+            dict(tau=0.3, top_k=256, temperature=1.5, presence_penalty=0.6, frequency_penalty=0.1)]
+    dev = [TypicalSampler(bias={5: 1.5, 9: -2.0}, **c) for c in cfgs]
+    prompts = [prompt(ref, 80 + b, 6 + b) for b in range(3)]
+    for b in range(3):
+        dev[b].init(prompts[b][-3:])
+    pending = [list(p) for p in prompts]
+    checked = skipped = 0
+    for step in range(24):
+        snaps = [eng.state.read(b) for b in range(3)]
+        inp = rt.RnnInput([rt.RnnInputBatch(list(pending[b]), rt.RnnOption.Last) for b in range(3)])
+        rows = [None] * 3
+        while inp.num_token() > 0:
+            inp, outs = eng.infer(inp)
+            for b, o in enumerate(outs):
+                if len(o):
+                    rows[b] = o[-1]
+        us = [float(rng.random()) for _ in range(3)]
+        want, margin = [], []
+        for b in range(3):
+            x = rows[b].astype(np.float32).copy()
+            for tk, dv in dev[b].adjustments().items():            # -penalty (typical.rs:62-68) + bias (run.rs:681-683)
+                x[tk] += np.float32(dv)
+            pr = R.softmax_ref(x[None])[0]
+            alts = [R.typical_ref(pr, dev[b].tau, dev[b].top_k, dev[b].temperature, us[b], h_shift=d)
+                    for d in (0.0, 1e-5, -1e-5, 4e-5, -4e-5)]   # H is a 65k-term fp32 sum: order-dependent last bits
+            want.append({a[0] for a in alts})
+            margin.append(min(a[1] for a in alts))
+        for b in range(3):
+            eng.state.write(snaps[b], b)
+        inp = rt.RnnInput([rt.RnnInputBatch(list(pending[b]), rt.RnnOption.Last) for b in range(3)])
+        got = [None] * 3
+        while inp.num_token() > 0:
+            inp, outs = eng.infer_sample(inp, dev, us)
+            for b, o in enumerate(outs):
+                if o is not None:
+                    got[b] = o
+        for b in range(3):
+            if margin[b] > 1e-4:
+                assert got[b][0] in want[b], (step, b, got[b], want[b], margin[b])
+                checked += len(want[b]) == 1                       # the answer did not depend on the last bits of H
+            else:
+                skipped += 1
+            dev[b].update(got[b][0])
+            pending[b] = [got[b][0]]
+            assert 0.0 < got[b][1] <= 1.0
+    assert checked >= 50 and skipped <= 8, (checked, skipped)
+    eng.close()

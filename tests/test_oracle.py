@@ -164,3 +164,34 @@ def test_nucleus_reference_semantics():
     assert abs(s.penalties[8] - ((0.3 + 0.3 * 0.99654026) * 0.99654026 + 0.3)) < 1e-6
     s.update(3)
     assert abs(s.penalties[3] - 0.3) < 1e-7
+
+
+def test_typical_ref_matches_a_literal_restatement():
+    """typical_ref against a from-the-text restatement of sampler/typical.rs:70-120 (sort of (|y - H|, id) pairs)."""
+    rng = np.random.default_rng(9)
+    for trial in range(20):
+        x = rng.standard_normal(300).astype(np.float32) * 3
+        p = R.softmax_ref(x[None])[0]
+        tau, top_k, temp, u = float(rng.uniform(0.2, 0.95)), int(rng.integers(1, 64)), float(rng.uniform(0.5, 1.5)), float(rng.random())
+        items = [(i, float(v), -float(np.log(np.float32(v)))) for i, v in enumerate(p) if v > 0]
+        h = np.float32(0)
+        for _, a, b in items:
+            h = np.float32(h + np.float32(np.float32(a) * np.float32(b)))
+        srt = sorted(((np.float32(abs(np.float32(b) - h)), i, a) for i, a, b in items))[:top_k]
+        kept, cum = [], np.float32(0)
+        for _, i, a in srt:
+            if cum > np.float32(tau):
+                break
+            cum = np.float32(cum + np.float32(a))
+            kept.append((i, np.float32(a) ** np.float32(1.0 / temp)))
+        tot = np.float32(0)
+        for _, q in kept:
+            tot = np.float32(tot + q)
+        c, want = np.float32(0), kept[0][0]
+        for i, q in kept:
+            c = np.float32(c + np.float32(q / tot))
+            if np.float32(u) <= c:
+                want = i
+                break
+        got, _ = R.typical_ref(p, tau, top_k, temp, u)
+        assert got == want
