@@ -1151,16 +1151,17 @@ void rwkv_engine::infer_sample(const rwkv_slot_input *in, const rwkv_sample_para
     int *h_tok = h_row + ADJ_CAP;
     float *h_val = (float *)(h_tok + ADJ_CAP);
     size_t nadj = 0;
+    bool any_nt = false, any_miro = false;
     for (int b = 0; b < max_batch; ++b) {
         if (pl.slot_out_rows[b] == 0) continue;
         const int r = pl.slot_out_begin[b];
         const rwkv_sample_params &p = sp[b];
-        if (p.top_k > 256) throw RwkvError(RWKV_ERR_UNSUPPORTED, "on-device sampling supports top_k <= 256");
-        if (!(p.temperature > 0.f)) throw RwkvError(RWKV_ERR_INVALID, "temperature must be > 0");
+        if (p.kind != RWKV_SAMPLER_MIROSTAT && p.top_k > 256) throw RwkvError(RWKV_ERR_UNSUPPORTED, "on-device sampling supports top_k <= 256");
+        if (p.kind != RWKV_SAMPLER_MIROSTAT && !(p.temperature > 0.f)) throw RwkvError(RWKV_ERR_INVALID, "temperature must be > 0");
         if (p.n_adj && (!p.adj_tokens || !p.adj_values)) throw RwkvError(RWKV_ERR_INVALID, "null adjustment arrays");
         if (nadj + p.n_adj > ADJ_CAP) throw RwkvError(RWKV_ERR_INVALID, "too many logit adjustments");
-        if (p.kind != RWKV_SAMPLER_NUCLEUS && p.kind != RWKV_SAMPLER_TYPICAL)
-            throw RwkvError(RWKV_ERR_UNSUPPORTED, "on-device sampler kind must be Nucleus or Typical (Mirostat stays on the host)");
+        if (p.kind < RWKV_SAMPLER_NUCLEUS || p.kind > RWKV_SAMPLER_MIROSTAT) throw RwkvError(RWKV_ERR_UNSUPPORTED, "unknown sampler kind");
+        if (p.kind == RWKV_SAMPLER_MIROSTAT) any_miro = true; else any_nt = true;
         hs[r] = SampleRow{p.top_p, p.top_k, p.temperature, p.uniform, p.kind, p.tau};
         for (size_t i = 0; i < p.n_adj; ++i, ++nadj) { h_row[nadj] = r; h_tok[nadj] = (int)p.adj_tokens[i]; h_val[nadj] = p.adj_values[i]; }
     }
@@ -1173,7 +1174,7 @@ void rwkv_engine::infer_sample(const rwkv_slot_input *in, const rwkv_sample_para
             HIP_CHECK(hipMemcpyAsync(d_adj_val, h_val, nadj * 4, hipMemcpyHostToDevice, s_main));
             launch_logit_adjust(logits, info.num_vocab, d_adj_row, d_adj_tok, d_adj_val, (int)nadj, s_main);
         }
-        launch_nucleus(logits, pl.n_out, info.num_vocab, d_samp, d_samp_tok, d_samp_prob, s_main);
+        launch_nucleus(logits, pl.n_out, info.num_vocab, d_samp, any_nt, any_miro, d_samp_tok, d_samp_prob, s_main);
         int *ht = (int *)h_meta;                                   // reuse the pinned meta buffer for the 8 bytes per row
         float *hp = (float *)(h_meta + chunk);
         HIP_CHECK(hipMemcpyAsync(ht, d_samp_tok, (size_t)pl.n_out * 4, hipMemcpyDeviceToHost, s_main));

@@ -1906,15 +1906,23 @@ __device__ __forceinline__ float block_reduce_1024(float v, float *red, bool is_
     return r;
 }
 
+// NC = candidate capacity; MIRO = the Mirostat instantiation (kind 2 rows only; the other one takes kinds 0 and 1).
+// Mirostat (mirostat.rs:44-90): sort descending, k = 1 + #(tokens whose surprise -log2 p does not exceed max_surprise)
+// (exact while that fits NC = 8192, i.e. max_surprise < 13; beyond, the tail below 2^-13 is cut), no temperature,
+// draw u * sum against the running sum; `out_prob` carries the token surprise log2(sum) - log2(p) the host needs for
+// its update of max_surprise.
+template <int NC, bool MIRO>
 __global__ __launch_bounds__(NUC_THREADS) void nucleus_kernel(const float *logits, int V, const SampleRow *sp, int *out_tok,
                                                                float *out_prob) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char nuc_smem[];
     __shared__ float red[16];
     __shared__ unsigned hist[256];
     __shared__ unsigned sel[3];                                    // prefix, remaining k, candidate counter
-    __shared__ unsigned long long cand[NUC_CAND];                  // (prob bits << 32) | ~id  -> sort descending
-    __shared__ float qv[256];
+    unsigned long long *cand = (unsigned long long *)nuc_smem;     // [NC] (key bits << 32) | ~id  -> sort descending
+    float *qv = (float *)(cand + NC);                              // [NC]
     const int row = blockIdx.x, tid = threadIdx.x;
     const SampleRow P = sp[row];
+    if ((P.kind == 2) != MIRO) return;                             // uniform per block
     const float *x = logits + (long)row * V;
     float p[NUC_EPT];
     float m = -INFINITY;
@@ -1954,6 +1962,13 @@ __global__ __launch_bounds__(NUC_THREADS) void nucleus_kernel(const float *logit
     const float cut = typical ? P.tau : P.top_p;
     // ---- radix select of the k-th largest key (positive floats / complemented keys: bit patterns are order-preserving)
     int k = P.top_k < 1 ? 1 : (P.top_k > 256 ? 256 : P.top_k);
+    if (MIRO) {
+        float c = 0.f;
+#pragma unroll
+        for (int j = 0; j < NUC_EPT; ++j) c += (p[j] > 0.f && !(-log2f(p[j]) > P.tau)) ? 1.f : 0.f;   // counts < 2^24: exact in fp32
+        k = (int)block_reduce_1024(c, red, false) + 1;              // ... and the first token beyond max_surprise
+        if (k > NC) k = NC;
+    }
     if (k > V) k = V;
     if (tid == 0) { sel[0] = 0u; sel[1] = (unsigned)k; sel[2] = 0u; }
     unsigned prefix = 0u, mask = 0u;
@@ -1983,7 +1998,7 @@ __global__ __launch_bounds__(NUC_THREADS) void nucleus_kernel(const float *logit
     }
     const unsigned thr = prefix;                                    // bits of the k-th largest probability
     // ---- gather everything >= thr (ties included; zero-probability ties are skipped), sort, keep k
-    for (int i = tid; i < NUC_CAND; i += NUC_THREADS) cand[i] = 0ull;
+    for (int i = tid; i < NC; i += NUC_THREADS) cand[i] = 0ull;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NUC_EPT; ++j) {
@@ -1991,56 +2006,70 @@ __global__ __launch_bounds__(NUC_THREADS) void nucleus_kernel(const float *logit
         const unsigned key = __float_as_uint(p[j]);
         if (i < V && key >= thr && key != 0u) {
             const unsigned slot = atomicAdd(&sel[2], 1u);
-            if (slot < NUC_CAND) cand[slot] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+            if (slot < NC) cand[slot] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
         }
     }
     __syncthreads();
-    for (int size = 2; size <= NUC_CAND; size <<= 1) {              // bitonic sort, descending
+    for (int size = 2; size <= NC; size <<= 1) {                    // bitonic sort, descending
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const int i = tid, j = i ^ stride;
-            if (j > i) {
-                const bool desc = (i & size) == 0;
-                const unsigned long long a = cand[i], b = cand[j];
-                if ((a < b) == desc) { cand[i] = b; cand[j] = a; }
+            for (int i = tid; i < NC; i += NUC_THREADS) {
+                const int j = i ^ stride;
+                if (j > i) {
+                    const bool desc = (i & size) == 0;
+                    const unsigned long long a = cand[i], b = cand[j];
+                    if ((a < b) == desc) { cand[i] = b; cand[j] = a; }
+                }
             }
             __syncthreads();
         }
     }
-    const int ncand = min((int)min(sel[2], (unsigned)NUC_CAND), k);
+    const int ncand = min((int)min(sel[2], (unsigned)NC), k);
     // ---- nucleus: keep while the cumulative probability BEFORE the element is <= top_p (nucleus.rs:84-91)
     if (tid == 0) {
         float cum = 0.f;
         int n = 0;
         for (; n < ncand; ++n) {
-            if (cum > cut) break;
+            if (!MIRO && cum > cut) break;
             cum += prob_of(cand[n]);
         }
         sel[0] = (unsigned)(n < 1 ? 1 : n);
     }
     __syncthreads();
     const int n = (int)sel[0];
-    if (tid < n) qv[tid] = powf(prob_of(cand[tid]), 1.0f / P.temperature);   // nucleus.rs:92, typical.rs:96
+    for (int i = tid; i < n; i += NUC_THREADS)
+        qv[i] = MIRO ? prob_of(cand[i]) : powf(prob_of(cand[i]), 1.0f / P.temperature);   // nucleus.rs:92, typical.rs:96
     __syncthreads();
     if (tid == 0) {
         float sum = 0.f;
         for (int i = 0; i < n; ++i) sum += qv[i];
         float c = 0.f;
         int pick = 0;                                               // find_or_first: nothing found -> first element
+        const float r = P.uniform * sum;                            // mirostat.rs:78-79
         for (int i = 0; i < n; ++i) {
-            c += qv[i] / sum;
-            if (P.uniform <= c) { pick = i; break; }
+            if (MIRO) { c += qv[i]; if (r <= c) { pick = i; break; } }
+            else { c += qv[i] / sum; if (P.uniform <= c) { pick = i; break; } }
         }
         const unsigned long long e = cand[pick];
         out_tok[row] = (int)(0xFFFFFFFFu - (unsigned)(e & 0xFFFFFFFFull));
-        if (out_prob) out_prob[row] = prob_of(e);
+        if (out_prob) out_prob[row] = MIRO ? log2f(sum) - log2f(prob_of(e)) : prob_of(e);
     }
 }
 
 void launch_logit_adjust(float *logits, int V, const int *rows, const int *toks, const float *vals, int n, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(logit_adjust_kernel, dim3((n + 255) / 256), dim3(256), 0, s, logits, V, rows, toks, vals, n);
 }
-void launch_nucleus(const float *logits, int n_rows, int V, const SampleRow *sp, int *out_tok, float *out_prob, hipStream_t s) {
-    hipLaunchKernelGGL(nucleus_kernel, dim3(n_rows), dim3(NUC_THREADS), 0, s, logits, V, sp, out_tok, out_prob);
+void launch_nucleus(const float *logits, int n_rows, int V, const SampleRow *sp, bool any_nucleus_typical, bool any_mirostat,
+                    int *out_tok, float *out_prob, hipStream_t s) {
+    constexpr int NC0 = NUC_CAND, NC2 = 8192;
+    static bool attr_done[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_done[dev & 15]) {
+        (void)hipFuncSetAttribute((const void *)nucleus_kernel<NC2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NC2 * 12);
+        attr_done[dev & 15] = true;
+    }
+    if (any_nucleus_typical) hipLaunchKernelGGL((nucleus_kernel<NC0, false>), dim3(n_rows), dim3(NUC_THREADS), NC0 * 12, s, logits, V, sp, out_tok, out_prob);
+    if (any_mirostat) hipLaunchKernelGGL((nucleus_kernel<NC2, true>), dim3(n_rows), dim3(NUC_THREADS), NC2 * 12, s, logits, V, sp, out_tok, out_prob);
 }
 
 // =====================================================================================

@@ -139,6 +139,31 @@ class TypicalSampler(NucleusSampler):
         self.tau = float(tau)
 
 
+class MirostatSampler:
+    """Host-side state of `MirostatSampler` (sampler/mirostat.rs:11-90): `max_surprise` lives here; the device sorts,
+    truncates at max_surprise, samples and returns the token surprise; `update()` applies mirostat.rs:85-87."""
+    kind = 2
+    top_k, temperature, top_p = 1, 1.0, 0.0
+
+    def __init__(self, tau=3.0, rate=0.1):
+        self.target, self.rate = np.float32(tau), np.float32(rate)
+        self.max_surprise = np.float32(2.0 * tau)
+
+    @property
+    def tau(self):                                                    # what the device calls tau for kind 2
+        return float(self.max_surprise)
+
+    def init(self, model_tokens):                                     # mirostat.rs:38
+        pass
+
+    def adjustments(self) -> dict:                                    # transform is a no-op (mirostat.rs:40)
+        return {}
+
+    def update(self, token_surprise: float):
+        err = np.float32(np.float32(token_surprise) - self.target)
+        self.max_surprise = np.float32(min(np.float32(self.max_surprise - self.rate * err), np.float32(4.0) * self.target))
+
+
 class ReplicaRouter:
     """Request-level sharding over independent engines (one per GPU): round-robin for batch jobs, least-busy for
     interactive requests.  No collective: each replica owns its weights, slots and stream."""

@@ -160,13 +160,15 @@ typedef struct rwkv_sample_params {
     const uint32_t *adj_tokens;    /* may be NULL when n_adj == 0 */
     const float *adj_values;       /* added to logits[adj_tokens[i]] before the softmax */
     size_t n_adj;
-    int32_t kind;                  /* RWKV_SAMPLER_NUCLEUS (top_p / top_k / temperature) or RWKV_SAMPLER_TYPICAL:          */
-    float tau;                     /* TypicalSampler::sample (sampler/typical.rs:70-120): keys |(-ln p) - H| ascending,     */
-                                   /* take top_k, keep while the cumulative probability before an element is <= tau        */
-                                   /* (TypicalParams defaults 0.5 / 128 / 1.0, typical.rs:11-27).  Mirostat (a state        */
-                                   /* machine over the full sorted distribution, mirostat.rs:44-90) stays on the host.      */
+    int32_t kind;                  /* RWKV_SAMPLER_NUCLEUS: top_p / top_k / temperature (nucleus.rs:69-101).                 */
+    float tau;                     /* RWKV_SAMPLER_TYPICAL (typical.rs:70-120; defaults 0.5 / 128 / 1.0): keys |(-ln p) - H|  */
+                                   /*   ascending, take top_k, keep while the cumulative probability before an element <= tau */
+                                   /* RWKV_SAMPLER_MIROSTAT (mirostat.rs:44-90): tau = the sampler's current `max_surprise`;  */
+                                   /*   top_p / top_k / temperature unused; out_probs[b] returns the TOKEN SURPRISE           */
+                                   /*   log2(sum) - log2(p) the caller needs for `max_surprise -= rate * (surprise - tau)`.   */
+                                   /*   Exact while max_surprise < 13 (<= 8192 candidates); beyond, the tail below 2^-13 is cut. */
 } rwkv_sample_params;
-enum { RWKV_SAMPLER_NUCLEUS = 0, RWKV_SAMPLER_TYPICAL = 1 };
+enum { RWKV_SAMPLER_NUCLEUS = 0, RWKV_SAMPLER_TYPICAL = 1, RWKV_SAMPLER_MIROSTAT = 2 };
 /* Like rwkv_infer with RWKV_OPTION_LAST on every slot, but slots whose pending tokens are exhausted by this call
  * get a sampled token id (out_tokens[b], emitted[b] = 1, out_probs[b] = its softmax probability) instead of a
  * logits row; only 8 bytes per slot cross PCIe.  n_consumed[b] as in rwkv_slot_output.  num_vocab <= 65536. */

@@ -721,6 +721,29 @@ def typical_ref(probs: np.ndarray, tau: float, top_k: int, temperature: float, u
     return int(ids[kept[0]]), margin
 
 
+def mirostat_ref(probs: np.ndarray, max_surprise: float, u: float):
+    """`MirostatSampler::sample` (mirostat.rs:44-84) with the draw explicit: sort descending (ties: lower id first),
+    running sum, k = 1 + position of the first token whose surprise -log2 p exceeds max_surprise (all if none), draw
+    u * sum against the running sum.  Returns (token, token_surprise = log2(sum) - log2(p), margin)."""
+    p = probs.astype(np.float32)
+    order = np.lexsort((np.arange(p.size), -p))
+    with np.errstate(divide="ignore"):
+        over = np.nonzero(-np.log2(p[order]) > np.float32(max_surprise))[0]
+    k = int(over[0]) + 1 if over.size else p.size
+    cum, c = [], np.float32(0.0)
+    for i in order[:k]:
+        c = np.float32(c + p[i])
+        cum.append(c)
+    total = cum[-1]
+    r = np.float32(np.float32(u) * total)
+    margin = 1.0
+    for i, cc in zip(order[:k], cum):
+        margin = min(margin, abs(float(cc) - float(r)))
+        if r <= cc:
+            return int(i), float(np.log2(total) - np.log2(p[i])), margin
+    return int(order[0]), float(np.log2(total) - np.log2(p[order[0]])), margin
+
+
 class NucleusRef:
     """State machine of `NucleusSampler` (nucleus.rs:13-122): penalties map, init/transform/update."""
 

@@ -573,3 +573,56 @@ def test_on_device_typical_sampling_matches_reference_sampler():
             assert 0.0 < got[b][1] <= 1.0
     assert checked >= 50 and skipped <= 8, (checked, skipped)
     eng.close()
+
+
+def test_on_device_mirostat_sampling_matches_reference_sampler():
+    """rwkv_infer_sample with kind = Mirostat (sort descending -> truncate at max_surprise -> u * sum against the running
+    sum, token surprise returned) against the restatement of sampler/mirostat.rs on the SAME logits; the host state
+    machine (max_surprise update, mirostat.rs:85-87) runs on both sides and must stay in step.  One slot mixes in a
+    nucleus sampler so that both kernel instantiations run in one call."""
+    from ai00_server_amd.harness import MirostatSampler, NucleusSampler
+    t, eng = build("v6-small", rt.Precision.Fp16, B=3, chunk=16)
+    ref = R.RwkvRef(t)
+    rng = np.random.default_rng(79)
+    dev = [MirostatSampler(tau=3.0, rate=0.1), MirostatSampler(tau=2.0, rate=0.3), NucleusSampler(top_p=0.8, top_k=50)]
+    orc_ms = [np.float32(6.0), np.float32(4.0)]
+    pending = [prompt(ref, 90 + b, 5 + b) for b in range(3)]
+    checked = skipped = 0
+    for step in range(20):
+        snaps = [eng.state.read(b) for b in range(3)]
+        inp = rt.RnnInput([rt.RnnInputBatch(list(pending[b]), rt.RnnOption.Last) for b in range(3)])
+        rows = [None] * 3
+        while inp.num_token() > 0:
+            inp, outs = eng.infer(inp)
+            for b, o in enumerate(outs):
+                if len(o):
+                    rows[b] = o[-1]
+        us = [float(rng.random()) for _ in range(3)]
+        want = [R.mirostat_ref(R.softmax_ref(rows[b][None])[0], float(orc_ms[b]), us[b]) for b in range(2)]
+        for b in range(3):
+            eng.state.write(snaps[b], b)
+        inp = rt.RnnInput([rt.RnnInputBatch(list(pending[b]), rt.RnnOption.Last) for b in range(3)])
+        got = [None] * 3
+        while inp.num_token() > 0:
+            inp, outs = eng.infer_sample(inp, dev, us)
+            for b, o in enumerate(outs):
+                if o is not None:
+                    got[b] = o
+        for b in range(2):
+            tok, surprise, margin = want[b]
+            assert abs(float(dev[b].max_surprise) - float(orc_ms[b])) < 1e-3
+            if margin > 1e-5:
+                assert got[b][0] == tok, (step, b, got[b], want[b])
+                assert abs(got[b][1] - surprise) < 1e-3 * max(1.0, abs(surprise))
+                checked += 1
+            else:
+                skipped += 1
+            # both state machines follow the reference trajectory (mirostat.rs:85-87)
+            tgt, rate = (3.0, 0.1) if b == 0 else (2.0, 0.3)
+            orc_ms[b] = np.float32(min(np.float32(orc_ms[b] - np.float32(rate) * np.float32(np.float32(surprise) - np.float32(tgt))), np.float32(4.0 * tgt)))
+            dev[b].update(surprise)
+            pending[b] = [tok]
+        dev[2].update(got[2][0])
+        pending[2] = [got[2][0]]
+    assert checked >= 36 and skipped <= 4, (checked, skipped)
+    eng.close()
