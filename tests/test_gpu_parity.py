@@ -626,3 +626,25 @@ def test_on_device_mirostat_sampling_matches_reference_sampler():
         pending[2] = [got[2][0]]
     assert checked >= 36 and skipped <= 4, (checked, skipped)
     eng.close()
+
+
+def test_full_width_v7_shapes_two_layers_nf4():
+    """BASELINE config #4 shapes (RWKV-V7 2.9B: C=2560, V=65536; 2 layers), NF4: a chunked prompt (chunk WKV kernel,
+    tile-free GEMMs) followed by single-token steps (LayerNorm prologue in the grouped r/k/v/LoRA GEMM and in Fk) against
+    the oracle, logits and state."""
+    _, _, C, F, V = R.CONFIGS["v7-2.9b"]
+    tens = R.synth_checkpoint(7, 2, C, F, V, seed=13)
+    st = R.st_serialize(tens)
+    ref = R.RwkvRef(tens, 2, R.QUANT_NF4)
+    eng = rt.ModelBuilder(st).quant(2, rt.Quant.NF4).build(max_batch=2, token_chunk_size=16, precision=rt.Precision.Fp16)
+    p = [int(x) for x in R.synth_prompt(14, 19)]
+    s = ref.init_state()
+    want = ref.forward(p, s, full=True)
+    got = run_prompts(eng, [[], p[:13]])[1][0]                    # slot 1: prompt in one chunked call
+    assert np.abs(got - want[12]).max() <= tol(rt.Precision.Fp16, want[12])
+    for i in range(13, 19):                                        # then token by token (T = 1 steps)
+        got = run_prompts(eng, [[], [p[i]]])[1][0]
+        assert np.abs(got - want[i]).max() <= tol(rt.Precision.Fp16, want[i])
+        assert int(np.argmax(got)) == int(np.argmax(want[i]))
+    assert np.abs(eng.state.back(1) - s).max() <= tol(rt.Precision.Fp16, s)
+    eng.close()
