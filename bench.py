@@ -8,6 +8,11 @@ inputs (weights, recurrent state, token ids) resident in HBM: the arg-max token 
 (`rwkv_decode_greedy`), so no PCIe traffic sits inside the timed region.  N > 1: one process per GPU
 (launched by torch.distributed.run), every rank is an independent replica with its own weights, slots and
 stream (replicas only, no collective on the data path); weak scaling.
+
+What this file takes from oracle/ (test infrastructure): the SYNTHETIC CHECKPOINT of the named shapes (`synth_st`,
+`model_info`, `synth_prompt`: there is no network for real weights), the byte accounting of the roofline
+(`algorithmic_bytes`), and the `cpu_baseline` leg (the numpy restatement timed on the host cores).  The measured
+path never touches it: the engine is librwkv_hip.so through ai00_server_amd.runtime.
 """
 from __future__ import annotations
 
