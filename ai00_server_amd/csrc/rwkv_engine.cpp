@@ -727,7 +727,7 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
         }
         const int Kb = K / ksb;
         const int nslice = (Kb + KW - 1) / KW;                 // balanced: every wave owns the same number of slices
-        const int maxw = gemm_variant_max_waves(KSW), per_wave = (nslice + maxw - 1) / maxw;
+        const int maxw = gemm_variant_max_waves(NT, KSW), per_wave = (nslice + maxw - 1) / maxw;
         const int nw = (nslice + per_wave - 1) / per_wave;
         // strips per block: the whole grid should be resident at once (~164 VGPRs -> 12 waves per CU), and a wave's
         // rounds should fit in registers so that every load is issued up-front (single shot); the head matrix is too

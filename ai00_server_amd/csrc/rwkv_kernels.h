@@ -13,8 +13,8 @@ enum Post : int { POST_NONE = 0, POST_MUL = 1, POST_MIX = 2 };
 constexpr int TILE_ROWS = 16;        // output rows per strip (MFMA 16x16x32 M)
 constexpr int KSTEP = 32;            // K per MFMA
 constexpr int GEMM_MAX_WAVES = 10;    // 640-thread blocks: <= 168 VGPRs per lane (KSW = 8 variants)
-constexpr int GEMM_MAX_WAVES_K16 = 8; // KSW = 16 variants: 512-thread blocks, 2 waves per SIMD -> 256 VGPRs per lane
-int gemm_variant_max_waves(int KSW);
+constexpr int GEMM_MAX_WAVES_K16 = 8; // KSW = 16 and four-tile (NT = 4) variants: 512-thread blocks, 2 waves per SIMD -> 256 VGPRs per lane
+int gemm_variant_max_waves(int NT, int KSW);
 constexpr int GEMM_MAXP = 8;
 constexpr int INT8_BLOCK = 128;
 constexpr int NF4_BLOCK = 64;
@@ -111,7 +111,7 @@ size_t lnp_lds_bytes(int T, int C, bool hilo);                       // extra dy
 void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s);
 int gemm_max_rounds(int fmt, int NT, bool hilo);
 // prefill path (T >= GEMM_TILE_MIN_T): LDS-tiled MFMA GEMM, no K split; uses p[].block_begin and total_blocks only
-constexpr int GEMM_TILE_MIN_T = 64;
+constexpr int GEMM_TILE_MIN_T = 193;                     // measured crossover (V6-3B Int8): up to 192 rows the decode kernel's 64-row passes win or tie
 constexpr int GEMM_TILE_SHAPES = 10;                      // 256x128, 128x128, 64x128, 64x64 (rows x tokens, 128-k chunks); 64x64 and 128x128 with 256-k chunks
 int gemm_tile_blocks(int shape, int rows, int T);
 void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s);                             // rounds of 256 k a wave can hold at once (single-shot)

@@ -454,12 +454,12 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
             // X first, weights after: the X fragments are L2 hits and complete first, so (in-order vmcnt) the MFMAs of round
             // r only wait for rounds <= r while later rounds are still streaming in from HBM.  (Weights-first was measured
             // and is slower: issuing is throttled by the CU's memory pipeline either way, and X then lands last.)
-            constexpr int MAXR = FMT == W_F16 ? 2 : ((NT == 2 || HILO) ? 3 : 4);   // rounds a wave holds in registers at once (gemm_max_rounds)
+            constexpr int MAXR = NT == 4 ? 2 : (FMT == W_F16 ? 2 : ((NT == 2 || HILO) ? 3 : 4));   // rounds a wave holds in registers at once (gemm_max_rounds)
             WRound<FMT> cur, nxt, w[SHOT ? MAXR : 1];
             // streamed (not single-shot) quantised weights: a ring of RD rounds in flight per wave.  With only cur/nxt
             // (one round ahead) a wave's K slice is a serial chain of memory latencies — 6 rounds x ~0.9 us at T = 1
             // (scripts/trace_gemm.py); fp16 rounds are twice the registers and stay at one round ahead.
-            constexpr int RD = (!SHOT && FMT != W_F16) ? ((NT == 2 || HILO || LNP) ? 2 : 4) : 1;
+            constexpr int RD = (!SHOT && FMT != W_F16) ? ((NT >= 2 || HILO || LNP) ? 2 : 4) : 1;
             WRound<FMT> ring[RD];
             const bool ringed = RD > 1 && nsub == SUB;
             auto load_x = [&]() {
@@ -644,7 +644,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
 }
 
 template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, bool LNP>
-__global__ __launch_bounds__((KSW == 16 ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES) * 64) void gemm_kernel(const GemmLaunch L) {
+__global__ __launch_bounds__(((KSW == 16 || NT == 4) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES) * 64) void gemm_kernel(const GemmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x >= L.total_blocks) {                      // the extra block of a launch that carries a commit
         shift_commit(L.commit);
@@ -659,13 +659,14 @@ __global__ __launch_bounds__((KSW == 16 ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES) *
     else gemm_body<NT, KSW, HILO, SHOT, false, W_NF4, LNP>(L, P, smem);
 }
 
-int gemm_variant_max_waves(int KSW) { return KSW == 16 ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES; }
+int gemm_variant_max_waves(int NT, int KSW) { return (KSW == 16 || NT == 4) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES; }
 
 void gemm_variant(int T, bool hilo, int &NT, int &KSW) {
     static const int ksw8 = std::getenv("RWKV_KSW8") ? std::atoi(std::getenv("RWKV_KSW8")) : 0;
     if (hilo) { NT = 1; KSW = 8; }
     else if (T <= 16) { NT = 1; KSW = ksw8 ? 8 : 16; }
-    else { NT = 2; KSW = 8; }
+    else if (T <= 32) { NT = 2; KSW = 8; }
+    else { NT = 4; KSW = 8; }                                    // 33..64 rows in ONE pass over the weights (128 X registers)
 }
 
 void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
@@ -677,7 +678,8 @@ void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
     static bool attr_done[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
-#define GEMM_V3(X, sh, tl) X(1, 8, true, sh, tl, false) X(1, 16, false, sh, tl, false) X(2, 8, false, sh, tl, false) X(1, 8, false, sh, tl, false) X(1, 16, false, sh, tl, true)
+#define GEMM_V3(X, sh, tl) X(1, 8, true, sh, tl, false) X(1, 16, false, sh, tl, false) X(2, 8, false, sh, tl, false) X(1, 8, false, sh, tl, false) X(1, 16, false, sh, tl, true) \
+                           X(4, 8, false, sh, tl, false)
 #define GEMM_VARIANTS(X) GEMM_V3(X, true, true) GEMM_V3(X, true, false) GEMM_V3(X, false, true) GEMM_V3(X, false, false)
     if (!attr_done[dev & 15]) {                               // allow > 64 KiB dynamic LDS (gfx950: 160 KiB / CU)
         const int cap = 160 * 1024;
@@ -694,7 +696,7 @@ void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
 #undef GEMM_V3
 }
 
-int gemm_max_rounds(int fmt, int NT, bool hilo) { return fmt == W_F16 ? 2 : ((NT == 2 || hilo) ? 3 : 4); }   // 64 X registers in a 168-VGPR budget: 3
+int gemm_max_rounds(int fmt, int NT, bool hilo) { return NT == 4 ? 2 : (fmt == W_F16 ? 2 : ((NT == 2 || hilo) ? 3 : 4)); }   // X registers vs the VGPR budget
 
 __device__ __forceinline__ void store_operand4(_Float16 *__restrict__ hi, _Float16 *__restrict__ lo, long off, float4 o);
 

@@ -279,8 +279,9 @@ def test_full_width_3b_shapes_two_layers():
                                              ("v5-small", (2, 1), rt.Precision.Fp32), ("v7-small", (3, 2), rt.Precision.Fp32),
                                              ("v7-tiny", (0, 0), rt.Precision.Fp16), ("v5-tiny", (0, 0), rt.Precision.Fp32)])
 def test_prefill_tile_gemm_path(name, quant, prec):
-    """Steps with >= 64 rows go through the LDS-tiled MFMA GEMM (gemm_tile_kernel): ragged multi-slot prefill,
-    Last and Full outputs, against the oracle and against the same prompts fed in small chunks (decode path)."""
+    """Steps with >= 193 rows go through the LDS-tiled MFMA GEMM (gemm_tile_kernel; the 246-row step here), steps with
+    33..192 rows through the four-tile decode GEMM (the 70-row Full request): ragged multi-slot prefill, Last and Full
+    outputs, against the oracle and against the same prompts fed in small chunks (decode path)."""
     t, eng = build(name, prec, quant=quant, B=3, chunk=256)
     ref = R.RwkvRef(t, quant_layers=quant[0], quant_type=quant[1])
     ps = [prompt(ref, 20, 70), prompt(ref, 21, 131), prompt(ref, 22, 45)]
