@@ -891,7 +891,7 @@ bool v6_mix_ln_supported(int T, int C, int Dm, bool hilo, int np) {
 }
 
 // =====================================================================================
-// Prefill GEMM (T >= 64): LDS-tiled MFMA GEMM over the same pre-tiled weights.
+// Prefill GEMM (T >= GEMM_TILE_MIN_T = 193): LDS-tiled MFMA GEMM over the same pre-tiled weights.
 // Block = 8 waves; wave w owns strips {2w, 2w+1} of the block's 16 strips (256 output rows) and all 8 n-tiles of
 // the block's 128-token tile (64 accumulator registers).  K is walked in chunks of 128: the X chunk
 // [128 tokens][128 k] is staged through LDS (register-staged, double-buffered, one barrier per chunk) and shared
