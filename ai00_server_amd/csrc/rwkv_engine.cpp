@@ -712,7 +712,6 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
         // to spread small matrices over more CUs
         int ksb = 1;
         auto valid = [&](int b) { return K % b == 0 && (K / b) % align == 0; };
-        const int need = 1;                                   // slices beyond the block's waves are looped over
         if (s.partial) {
             // smallest split that gives >= 1.5 blocks per CU (one strip per block), else the largest valid one <= 8
             int best = 0;
@@ -913,7 +912,7 @@ void rwkv_engine::upload_plan(const StepPlan &pl) {
 // the forward pass: enqueue every kernel of one step on s_main
 // ------------------------------------------------------------------------------------------------
 void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token) {
-    const int C = info.num_emb, F = info.num_hidden, V = info.num_vocab, H = info.num_head, L = info.num_layer;
+    const int C = info.num_emb, V = info.num_vocab, H = info.num_head, L = info.num_layer;
     RowMeta rm = meta_ptrs(T);
     rm.token = d_token;
     const int *seq_slot = d_meta + 5 * chunk, *seq_begin = seq_slot + max_batch, *seq_len = seq_begin + max_batch;

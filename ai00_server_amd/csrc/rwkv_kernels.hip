@@ -1559,7 +1559,6 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
 // to ~20 LDS reads + 48 FMAs + 16 DPP adds.
 // =====================================================================================
 constexpr int WKV_CH = 32;                               // tokens per chunk: 8 per wave in the parallel phases
-constexpr int WKV_MAX_DD = 128;                          // V6 decay LoRA width held in registers (all released models: 64 / 128)
 template <int DD>
 __device__ __forceinline__ float wkv_decay_dot(const f16x8 (&d2r)[DD / 8], const float *tdl) {
     constexpr int PER8 = DD / 32;
@@ -1596,10 +1595,9 @@ __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa) T[aa] = __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4 *)(st + (aa * 16 + ig) * 64 + jg * 4)));
     if (VER != 7 && tid < 64) s_u[tid] = a.u[cb + tid];
-    // per-channel parameters (channel = lane in phases A and C)
-    const float lnw = a.lnx_w[cb + lane], lnb = a.lnx_b[cb + lane];
-    float kk_p = 0.f, ka_p = 0.f, rk_p = 0.f, wconst = 0.f, decay0 = 0.f;
-    if (VER == 7) { kk_p = a.k_k[cb + lane]; ka_p = a.k_a[cb + lane]; rk_p = a.r_k[cb + lane]; }
+    // per-channel parameters of phase A (channel = lane)
+    float kk_p = 0.f, ka_p = 0.f, wconst = 0.f, decay0 = 0.f;
+    if (VER == 7) { kk_p = a.k_k[cb + lane]; ka_p = a.k_a[cb + lane]; }
     if (VER == 5) wconst = a.wdec_or_decay[cb + lane];
     if (VER == 6) decay0 = a.wdec_or_decay[cb + lane];
 
