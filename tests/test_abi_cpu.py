@@ -21,7 +21,8 @@ def test_library_exports_every_declared_symbol(built_lib):
     for name in sorted(declared):
         assert hasattr(l, name), f"{name} declared in rwkv_abi.h but not exported"
     assert declared == set(rt.ABI_SYMBOLS), declared ^ set(rt.ABI_SYMBOLS)
-    assert rt.lib().rwkv_abi_version() == 2
+    want = int(re.search(r"#define\s+RWKV_ABI_VERSION\s+(\d+)", header).group(1))
+    assert rt.lib().rwkv_abi_version() == want
 
 
 def test_model_info_and_format_errors(built_lib):
@@ -143,3 +144,10 @@ def test_prefab_images_are_sniffed_and_bad_ones_rejected(built_lib):
     assert e.value.code == -3
     with pytest.raises(rt.RwkvError):
         rt.Loader.info(b"RWKVHIP\0" + b"\x01\x00")             # shorter than a header: falls through to the safetensors parser
+
+
+def test_graft_entry_build_is_green(built_lib):
+    """`__graft_entry__.build()` is the driver's does-it-build check: it must pass on the tree as committed (a stale
+    hard-coded ABI version once made it fail while every other test was green)."""
+    import __graft_entry__ as g
+    g.build()
