@@ -195,3 +195,34 @@ def test_typical_ref_matches_a_literal_restatement():
                 break
         got, _ = R.typical_ref(p, tau, top_k, temp, u)
         assert got == want
+
+
+def test_mirostat_ref_matches_a_literal_restatement():
+    """mirostat_ref against a from-the-text restatement of sampler/mirostat.rs:44-84 (sort, running sum, truncate at the
+    first token whose surprise exceeds max_surprise, draw u * sum), and the surprise it reports."""
+    rng = np.random.default_rng(10)
+    for trial in range(20):
+        x = rng.standard_normal(400).astype(np.float32) * 3
+        p = R.softmax_ref(x[None])[0]
+        ms, u = float(rng.uniform(2.0, 9.0)), float(rng.random())
+        srt = sorted(((-float(v), i) for i, v in enumerate(p)))                  # descending by p, ties by id
+        cum, c = [], np.float32(0)
+        for nv, i in srt:
+            c = np.float32(c + np.float32(-nv))
+            cum.append((i, c, np.float32(-nv)))
+        k = len(cum)
+        for pos, (_, _, v) in enumerate(cum):
+            if -np.log2(v) > np.float32(ms):
+                k = pos + 1
+                break
+        cum = cum[:k]
+        total = cum[-1][1]
+        r = np.float32(np.float32(u) * total)
+        tok, prob = cum[0][0], cum[0][2]
+        for i, cc, v in cum:
+            if r <= cc:
+                tok, prob = i, v
+                break
+        got_tok, got_surprise, _ = R.mirostat_ref(p, ms, u)
+        assert got_tok == tok
+        assert abs(got_surprise - float(np.log2(total) - np.log2(prob))) < 1e-6
