@@ -44,21 +44,36 @@ def needs_build() -> bool:
     return open(STAMP).read().strip() != _sources_digest()
 
 
+KERNEL_PARTS = 5      # rwkv_kernels.hip is compiled once per part (-DRWKV_PART=k), in parallel
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = _hipcc()
-    objs = []
+    jobs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        stem = os.path.splitext(src)[0]
+        base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
         if src.endswith(".cpp"):
-            cmd.insert(1, "-x")
-            cmd.insert(2, "hip")
+            base += ["-x", "hip"]
+        if src == "rwkv_kernels.hip":
+            for k in range(KERNEL_PARTS):
+                obj = os.path.join(CSRC, f"{stem}.p{k}.o")
+                jobs.append((base + [f"-DRWKV_PART={k}", "-c", os.path.join(CSRC, src), "-o", obj], obj))
+        else:
+            obj = os.path.join(CSRC, stem + ".o")
+            jobs.append((base + ["-c", os.path.join(CSRC, src), "-o", obj], obj))
+
+    def run(job):
         if verbose:
-            print("[build]", " ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+            print("[build]", " ".join(job[0]), flush=True)
+        subprocess.check_call(job[0])
+        return job[1]
+
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(run, jobs))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print("[build]", " ".join(cmd), flush=True)

@@ -796,7 +796,8 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         // 64x64 tiles measured best everywhere (tile_bench): with 256-k chunks while the launch is latency-bound
         // (few blocks: one L2 round trip per chunk dominates), with 128-k chunks (more blocks per CU) once it is
         // throughput-bound.  RWKV_TILE_SHAPE overrides (0..9) for experiments.
-        static const int f_shape = (std::getenv("RWKV_TILE_SHAPE") && *std::getenv("RWKV_TILE_SHAPE")) ? env_int("RWKV_TILE_SHAPE") : -1;
+        const char *ev_shape = std::getenv("RWKV_TILE_SHAPE");     // read per call: the parity tests force every shape in one process
+        const int f_shape = (ev_shape && *ev_shape) ? std::atoi(ev_shape) : -1;
         long tot64 = 0;
         for (auto &s : ps) tot64 += gemm_tile_blocks(3, s.W->rows, T);
         int shape = tot64 <= 1536 ? 4 : 3;

@@ -16,6 +16,19 @@
 #include <type_traits>
 #include <cstdlib>
 
+
+// Build parts: the product build compiles this file once per part (-DRWKV_PART=k, k = 0..4, in parallel: one pass takes
+// ~3 minutes, the parts ~1); without RWKV_PART everything is one translation unit (trace builds of scripts/build_variant.py,
+// whose `__device__` probe buffers cannot span translation units).
+#ifdef RWKV_PART
+#define RWKV_PART_ON(k) (RWKV_PART == (k))
+#else
+#define RWKV_PART_ON(k) 1
+#endif
+#if defined(RWKV_TRACE) && defined(RWKV_PART)
+#error "trace builds are single-part"
+#endif
+
 namespace rwkv {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -52,6 +65,17 @@ __device__ __forceinline__ void split_hilo(float v, _Float16 &hi, _Float16 &lo) 
 // (scripts/trace_gemm.py).  `ld` (k per token row) is a multiple of 32; token capacity is a multiple of 16.
 __device__ __forceinline__ long opd_off(int t, int k, int ld) {
     return ((long)(t >> 4) * (ld >> 5) + (k >> 5)) * 512 + ((((k >> 3) & 3) << 4) + (t & 15)) * 8 + (k & 7);
+}
+
+__device__ __forceinline__ void store_operand4(_Float16 *__restrict__ hi, _Float16 *__restrict__ lo, long off, float4 o) {
+    f16x4 h, l;
+    _Float16 a, b;
+    split_hilo(o.x, a, b); h[0] = a; l[0] = b;
+    split_hilo(o.y, a, b); h[1] = a; l[1] = b;
+    split_hilo(o.z, a, b); h[2] = a; l[2] = b;
+    split_hilo(o.w, a, b); h[3] = a; l[3] = b;
+    *(f16x4 *)(hi + off) = h;
+    if (lo) *(f16x4 *)(lo + off) = l;
 }
 
 // Cross-lane sums on the DPP path (v_add_f32 with a dpp source modifier, a few cycles each) instead of `__shfl_xor`,
@@ -165,7 +189,7 @@ __device__ __forceinline__ u32 dq8(u32 d, u32 sel, f16x2 a2, f16x2 b2) {
 }
 
 // NF4 code points rounded to fp16 (oracle: NF4_TABLE_F16), as byte tables for v_perm lookups.
-__device__ __constant__ unsigned short nf4_f16_bits[16] = {
+static __device__ __constant__ unsigned short nf4_f16_bits[16] = {
     0xBC00, 0xB992, 0xB833, 0xB652, 0xB48D, 0xB1EA, 0xADD4, 0x0000,
     0x2D18, 0x3126, 0x33E0, 0x3568, 0x370D, 0x3880, 0x39C9, 0x3C00};
 
@@ -393,7 +417,9 @@ __device__ __forceinline__ void ln_prologue_finish(const LnProArgs &a, int T, co
     __syncthreads();
 }
 __device__ __forceinline__ size_t lnp_op_off(int T, int k, int tl) { return (size_t)((k >> 3) * T + tl) * 8; }   // k multiple of 8
+#if RWKV_PART_ON(0)
 size_t lnp_lds_bytes(int T, int C, bool hilo) { return (size_t)(2 * T * (C + LNP_PAD) + 64) * 4 + (size_t)T * C * 2 * (hilo ? 2 : 1); }
+#endif
 
 // token-shift state commit of the previous launch's prologue (one extra block)
 __device__ __forceinline__ void shift_commit(const ShiftCommit &c) {
@@ -406,6 +432,7 @@ __device__ __forceinline__ void shift_commit(const ShiftCommit &c) {
     }
 }
 
+#if RWKV_PART_ON(0)
 template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, int FMT, bool LNP>
 __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
     constexpr int KW = KSW * 32, SUB = KSW / RS, RK = RS * 32;
@@ -697,9 +724,10 @@ void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
 }
 
 int gemm_max_rounds(int fmt, int NT, bool hilo) { return NT == 4 ? 2 : (fmt == W_F16 ? 2 : ((NT == 2 || hilo) ? 3 : 4)); }   // X registers vs the VGPR budget
+#endif  // part 0: decode GEMM
 
-__device__ __forceinline__ void store_operand4(_Float16 *__restrict__ hi, _Float16 *__restrict__ lo, long off, float4 o);
 
+#if RWKV_PART_ON(1)
 // =====================================================================================
 // V6 data-dependent token-shift, fused (decode, T <= 32):  x_c = xx + dx * (mu_c + W2_c * tanh(W1_c * z)),
 // c in (w,k,v,r,g) — SURVEY A.4.  One launch instead of two dependent GEMMs: a block owns one mix c and 8 strips
@@ -890,6 +918,9 @@ bool v6_mix_ln_supported(int T, int C, int Dm, bool hilo, int np) {
     return v6_mix_supported(T, C, Dm) && T <= LNP_MAX_T && !hilo && np <= LNP_MAX_NP && C <= 8 * 512;
 }
 
+#endif  // part 1: fused V6 mix
+
+#if RWKV_PART_ON(2)
 // =====================================================================================
 // Prefill GEMM (T >= GEMM_TILE_MIN_T = 193): LDS-tiled MFMA GEMM over the same pre-tiled weights.
 // Block = 8 waves; wave w owns strips {2w, 2w+1} of the block's 16 strips (256 output rows) and all 8 n-tiles of
@@ -1223,6 +1254,9 @@ void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s) 
 #undef TG_SH
 }
 
+#endif  // part 2: prefill tile GEMM
+
+#if RWKV_PART_ON(3)
 // =====================================================================================
 // Row kernels (one 256-thread block per row)
 // =====================================================================================
@@ -1279,16 +1313,6 @@ __device__ __forceinline__ void row_layernorm(float4 (&v)[PT], int C, const floa
     }
 }
 
-__device__ __forceinline__ void store_operand4(_Float16 *__restrict__ hi, _Float16 *__restrict__ lo, long off, float4 o) {
-    f16x4 h, l;
-    _Float16 a, b;
-    split_hilo(o.x, a, b); h[0] = a; l[0] = b;
-    split_hilo(o.y, a, b); h[1] = a; l[1] = b;
-    split_hilo(o.z, a, b); h[2] = a; l[2] = b;
-    split_hilo(o.w, a, b); h[3] = a; l[3] = b;
-    *(f16x4 *)(hi + off) = h;
-    if (lo) *(f16x4 *)(lo + off) = l;
-}
 
 template <int PT>
 __global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
@@ -1783,6 +1807,9 @@ void launch_wkv(const WkvArgs &a, bool multi_row, hipStream_t s) {
     else hipLaunchKernelGGL(wkv_kernel, dim3(a.n_seq, a.H), dim3(256), 0, s, a);
 }
 
+#endif  // part 3: row kernels + WKV
+
+#if RWKV_PART_ON(4)
 // =====================================================================================
 // State slab <-> internal.  slab[l][0][c]=sx_att, slab[l][1+i][h*64+j]=S_h[i][j], slab[l][65][c]=sx_ffn
 // internal wkv T[l][h][p][q]:  transposed (v5/v6): S[i][j] = T[p=j][q=i];  v7: S[i][j] = T[p=i][q=j]
@@ -2209,4 +2236,5 @@ void launch_lora_blend(_Float16 *W, const _Float16 *B, const _Float16 *A, int ro
     hipLaunchKernelGGL(lora_blend_kernel, dim3(2048), dim3(256), 0, s, W, B, A, rows, K, r, alpha);
 }
 
+#endif  // part 4: state pack, softmax / arg-max / samplers, load-time kernels
 }  // namespace rwkv

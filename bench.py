@@ -41,7 +41,8 @@ def main():
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-only", action="store_true", help="skip the embeddings / PCIe / sampling / CPU legs (profiling)")
-    ap.add_argument("--sweep", default="", help="extra batch sizes reported under 'sweep', e.g. 1,8")
+    ap.add_argument("--sweep", default="1,8", help="extra batch sizes reported under 'sweep' (north_star: batch 1-32)")
+    ap.add_argument("--verify-steps", type=int, default=8, help="decode steps re-run through rwkv_infer + host arg-max and compared")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -55,7 +56,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("gloo" if os.environ.get("BENCH_SHARE_GPU") else "nccl")
+        dist.init_process_group("gloo")     # replicas only: the barrier and the MAX of the timing are host-side, no RCCL
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
@@ -97,7 +98,7 @@ def main():
         dt = time.perf_counter() - t
         barrier()
         if dist is not None:
-            x = torch.tensor([dt], dtype=torch.float64, device="cpu" if os.environ.get("BENCH_SHARE_GPU") else "cuda")
+            x = torch.tensor([dt], dtype=torch.float64, device="cpu")
             dist.all_reduce(x, op=dist.ReduceOp.MAX)
             dt = float(x.item())
         return dt, dev_ms, toks
@@ -105,6 +106,26 @@ def main():
     dt, dev_ms, toks = timed(B, args.steps, args.warmup)
     ms_per_step = dt * 1e3 / args.steps
     value = B * world * args.steps / dt
+
+    # ---- the timed call's own output, checked: the same first steps from a zero state through rwkv_infer (logits to the
+    # host, arg-max there, run.rs:809-832) must give the ids rwkv_decode_greedy produced on the device, for every slot
+    tokens_verified = None
+    if rank == 0 and args.verify_steps > 0:
+        zero = eng.state.init()
+        for b in range(B):
+            eng.state.load(zero, b)
+        dev_ids, _ = eng.decode_greedy(first, args.verify_steps)
+        for b in range(B):
+            eng.state.load(zero, b)
+        cur = [int(x) for x in first]
+        host_ids = np.zeros((args.verify_steps, B), dtype=np.int64)
+        for s_ in range(args.verify_steps):
+            inp = rt.RnnInput([rt.RnnInputBatch([cur[b]] if b < B else [], rt.RnnOption.Last) for b in range(eng.max_batch)])
+            _, outs = eng.infer(inp)
+            cur = [int(np.argmax(outs[b][-1])) for b in range(B)]
+            host_ids[s_] = cur
+        tokens_verified = bool(np.array_equal(np.asarray(dev_ids, dtype=np.int64)[:, :B], host_ids))
+        assert tokens_verified, "rwkv_decode_greedy ids differ from rwkv_infer + host arg-max"
 
     ab = R.algorithmic_bytes(info, shapes, ql, qt, B)
     step_frac = ab["per_step"] * (args.steps / dt) / HBM_PEAK
@@ -218,19 +239,38 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.decode_only:
-        # the oracle ("port") on the host cores, B=1, bounded sample (fp32 weights, no quantisation on the CPU side)
-        t0 = time.time()
-        ref = R.RwkvRef(tensors)
-        s = ref.init_state()
-        ref.forward([int(first[0])], s)                # warm
-        n_tok, t1 = 0, time.time()
-        while time.time() - t1 < 12.0 and n_tok < 64:
-            ref.forward([int(toks[n_tok % len(toks), 0])], s)
-            n_tok += 1
+        # the oracle ("port") on the host cores: the SAME batch in lock step (RwkvRefBatch: one pass over the weights per
+        # step for all B slots), bounded sample.  fp32 arithmetic on the fp16-rounded weights; the Int8/NF4 storage formats
+        # are a GPU-side layout (quantising 3 G weights in numpy would take minutes and the CPU arithmetic is the same).
+        ref = R.RwkvRefBatch(tensors)
+        st_cpu = ref.init_states(B)
+        cur = [int(x) for x in first]
+        ref.step(cur, st_cpu, want_logits=False)       # warm
+        n_step, t1 = 0, time.time()
+        while time.time() - t1 < 15.0 and n_step < 64:
+            lg = ref.step(cur, st_cpu)
+            cur = [int(x) for x in np.argmax(lg, axis=1)]
+            n_step += 1
         cdt = time.time() - t1
-        cpu = {"value": n_tok / cdt, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
-               "sample": f"{n_tok} decode tokens, batch 1, numpy fp32 oracle (weights fp16-rounded, unquantised), "
-                         f"{args.workload}"}
+        cpu = {"value": B * n_step / cdt, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+               "sample": f"{n_step} lock-step decode steps of {B} slots ({B * n_step} tokens), numpy/BLAS fp32 oracle on all host cores, "
+                         f"weights fp16-rounded (unquantised on the CPU side), {args.workload}"}
+        del ref, st_cpu
+        # BASELINE config #1: RWKV-V5-World-0.4B fp16, batch 1, greedy, on the CPU path (the reference has no CPU backend,
+        # lib.rs:339-368; this is the oracle port)
+        try:
+            _, t5 = R.synth_st("v5-0.4b", fast=True)
+            r5 = R.RwkvRef(t5)
+            s5 = r5.init_state()
+            lg = r5.forward([int(first[0]) % r5.info.num_vocab], s5)[-1]
+            n5, t1 = 0, time.time()
+            while time.time() - t1 < 6.0 and n5 < 256:
+                lg = r5.forward([int(np.argmax(lg))], s5)[-1]
+                n5 += 1
+            cpu["config1_v5_0.4b_b1_tokens_per_s"] = n5 / (time.time() - t1)
+            del r5, t5
+        except MemoryError:
+            pass
     eng.close()
 
     if rank == 0:
@@ -242,7 +282,7 @@ def main():
                            "quant": args.quant, "batch_per_gpu": B, "precision": args.precision,
                            "parallelism": f"replicas x{world} (no collective)"},
                 "tokens_per_s_per_gpu": value / world, "device_ms_per_step": dev_ms / args.steps,
-                "roofline": roof, "cpu_baseline": cpu, "embeddings": emb, "pcie_inclusive_tokens_per_s": pcie, "on_device_sampling_tokens_per_s": sampled, "sweep": sweep or None,
+                "roofline": roof, "cpu_baseline": cpu, "embeddings": emb, "pcie_inclusive_tokens_per_s": pcie, "on_device_sampling_tokens_per_s": sampled, "sweep": sweep or None, "tokens_verified": tokens_verified,
                 "load_s": t_load, "synth_s": t_synth}
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -438,6 +438,188 @@ class RwkvRef:
         return out, state
 
 
+def _ln_rows(x, w, b, eps=LN_EPS):
+    x = x.astype(np.float32)
+    m = x.mean(axis=-1, keepdims=True, dtype=np.float32)
+    v = ((x - m) ** 2).mean(axis=-1, keepdims=True, dtype=np.float32)
+    return (x - m) / np.sqrt(v + np.float32(eps)) * w + b
+
+
+class RwkvRefBatch(RwkvRef):
+    """Lock-step form of RwkvRef for multi-slot tests: B independent slots advance ONE token each per `step`
+    (the batch `runtime.infer` is handed at run.rs:1121-1132, one RnnInputBatch per slot).  Formula for formula the
+    same restatement as `RwkvRef._token` / `_att5` / `_att6` / `_att7` / `_ffn*` with a leading slot axis: every
+    `W @ x` becomes `X @ W.T`, so the weights are streamed once per step instead of once per slot.  BLAS may sum a
+    matrix-matrix product in a different order than a matrix-vector product, so the two forms agree to fp32 round-off
+    (tests/test_oracle.py pins that), not bit for bit.  `states` is [B, L, N+2, C], mutated in place."""
+
+    def step(self, tokens, states: np.ndarray, want_logits: bool = True):
+        i, w = self.info, self.w
+        H, N, C, B = i.num_head, i.head_size, i.num_emb, len(tokens)
+        x = _ln_rows(w["emb.weight"][np.asarray(tokens, dtype=np.int64)], w["blocks.0.ln0.weight"], w["blocks.0.ln0.bias"])
+        v_first = None
+        for l in range(i.num_layer):
+            p = f"blocks.{l}."
+            xx = _ln_rows(x, w[p + "ln1.weight"], w[p + "ln1.bias"])
+            sx = states[:, l, 0].copy()
+            S = states[:, l, 1:1 + N].reshape(B, N, H, N).transpose(0, 2, 1, 3).copy()      # [B, H, i, j]
+            states[:, l, 0] = xx
+            if i.version == 5:
+                att, S = self._batt5(p, xx, sx, S)
+            elif i.version == 6:
+                att, S = self._batt6(p, xx, sx, S)
+            else:
+                att, S, v_first = self._batt7(p, l, xx, sx, S, v_first)
+            states[:, l, 1:1 + N] = S.transpose(0, 2, 1, 3).reshape(B, N, C)
+            x = x + att
+            xx = _ln_rows(x, w[p + "ln2.weight"], w[p + "ln2.bias"])
+            sx = states[:, l, N + 1].copy()
+            states[:, l, N + 1] = xx
+            x = x + (self._bffn7(p, xx, sx) if i.version == 7 else self._bffn56(p, xx, sx))
+        if not want_logits:
+            return None
+        xo = _ln_rows(x, w["ln_out.weight"], w["ln_out.bias"])
+        return (xo @ w["head.weight"].T).astype(np.float32)
+
+    def _bgn(self, x, wt, b):                                    # GroupNorm over each head, x [B, C]
+        B = x.shape[0]
+        H = self.info.num_head
+        x = x.reshape(B, H, -1).astype(np.float32)
+        m = x.mean(axis=2, keepdims=True, dtype=np.float32)
+        v = ((x - m) ** 2).mean(axis=2, keepdims=True, dtype=np.float32)
+        return ((x - m) / np.sqrt(v + np.float32(GN_EPS))).reshape(B, -1) * wt + b
+
+    def _bwkv56(self, r, k, v, wdec, u, S):
+        B = r.shape[0]
+        H, N = self.info.num_head, self.info.head_size
+        r, k, v, wdec = (t.reshape(B, H, N) for t in (r, k, v, wdec))
+        u = u.reshape(1, H, N)
+        a = k[:, :, :, None] * v[:, :, None, :]
+        out = np.einsum("bhi,bhij->bhj", r, u[:, :, :, None] * a + S)
+        S = a + wdec[:, :, :, None] * S
+        return out.reshape(B, -1).astype(np.float32), S.astype(np.float32)
+
+    def _batt5(self, p, xx, sx, S):
+        w = self.w
+        mix = lambda n: xx * w[p + f"att.time_mix_{n}"].reshape(-1) + sx * (1 - w[p + f"att.time_mix_{n}"].reshape(-1))
+        r = mix("r") @ w[p + "att.receptance.weight"].T
+        k = mix("k") @ w[p + "att.key.weight"].T
+        v = mix("v") @ w[p + "att.value.weight"].T
+        g = mix("g") @ w[p + "att.gate.weight"].T
+        g = g * _sigmoid(g)
+        wdec = np.exp(-np.exp(w[p + "att.time_decay"].reshape(-1)))
+        wdec = np.broadcast_to(wdec, r.shape)
+        out, S = self._bwkv56(r, k, v, wdec, w[p + "att.time_first"].reshape(-1), S)
+        y = self._bgn(out, w[p + "att.ln_x.weight"], w[p + "att.ln_x.bias"]) * g
+        return y @ w[p + "att.output.weight"].T, S
+
+    def _batt6(self, p, xx, sx, S):
+        w = self.w
+        B = xx.shape[0]
+        dx = sx - xx
+        z = xx + dx * w[p + "att.time_mix_x"].reshape(-1)
+        m = np.tanh(z @ w[p + "att.time_mix_w1"].T)
+        w2 = w[p + "att.time_mix_w2"]
+        Dm = w2.shape[2]
+        m = m.reshape(B, 5, Dm)
+        xs = {}
+        for c, n in enumerate("wkvrg"):
+            mc = m[:, c] @ w2[c].T
+            xs[n] = xx + dx * (w[p + f"att.time_mix_{n}"].reshape(-1) + mc)
+        r = xs["r"] @ w[p + "att.receptance.weight"].T
+        k = xs["k"] @ w[p + "att.key.weight"].T
+        v = xs["v"] @ w[p + "att.value.weight"].T
+        g = xs["g"] @ w[p + "att.gate.weight"].T
+        g = g * _sigmoid(g)
+        td = np.tanh(xs["w"] @ w[p + "att.time_decay_w1"].T)
+        d = w[p + "att.time_decay"].reshape(-1) + td @ w[p + "att.time_decay_w2"].T
+        wdec = np.exp(-np.exp(d.astype(np.float32)))
+        out, S = self._bwkv56(r, k, v, wdec, w[p + "att.time_first"].reshape(-1), S)
+        y = self._bgn(out, w[p + "att.ln_x.weight"], w[p + "att.ln_x.bias"]) * g
+        return y @ w[p + "att.output.weight"].T, S
+
+    def _bffn56(self, p, xx, sx):
+        w = self.w
+        if self.info.version == 5:
+            mk, mr = w[p + "ffn.time_mix_k"].reshape(-1), w[p + "ffn.time_mix_r"].reshape(-1)
+            xk = xx * mk + sx * (1 - mk)
+            xr = xx * mr + sx * (1 - mr)
+        else:
+            dx = sx - xx
+            xk = xx + dx * w[p + "ffn.time_mix_k"].reshape(-1)
+            xr = xx + dx * w[p + "ffn.time_mix_r"].reshape(-1)
+        r = _sigmoid(xr @ w[p + "ffn.receptance.weight"].T)
+        k = np.maximum(xk @ w[p + "ffn.key.weight"].T, 0) ** 2
+        return r * (k @ w[p + "ffn.value.weight"].T)
+
+    def _batt7(self, p, l, xx, sx, S, v_first):
+        w = self.w
+        B = xx.shape[0]
+        H, N = self.info.num_head, self.info.head_size
+        dx = sx - xx
+        xm = {n: xx + dx * w[p + f"att.x_{n}"].reshape(-1) for n in "rwkvag"}
+        r = xm["r"] @ w[p + "att.receptance.weight"].T
+        k = xm["k"] @ w[p + "att.key.weight"].T
+        v = xm["v"] @ w[p + "att.value.weight"].T
+        wd = np.tanh(xm["w"] @ w[p + "att.w1"].T) @ w[p + "att.w2"].T
+        a = _sigmoid(w[p + "att.a0"].reshape(-1) + (xm["a"] @ w[p + "att.a1"].T) @ w[p + "att.a2"].T)
+        g = _sigmoid(xm["g"] @ w[p + "att.g1"].T) @ w[p + "att.g2"].T
+        kk = (k * w[p + "att.k_k"].reshape(-1)).reshape(B, H, N)
+        kk = kk / np.maximum(np.sqrt((kk * kk).sum(axis=2, keepdims=True)), np.float32(1e-12))
+        kk = kk.reshape(B, -1)
+        k = k * (1 + (a - 1) * w[p + "att.k_a"].reshape(-1))
+        if l == 0:
+            v_first = v
+        else:
+            v = v + (v_first - v) * _sigmoid(w[p + "att.v0"].reshape(-1) + (xm["v"] @ w[p + "att.v1"].T) @ w[p + "att.v2"].T)
+        wdec = np.exp(np.float32(-0.606531) * _sigmoid((w[p + "att.w0"].reshape(-1) + wd).astype(np.float32)))
+        rh, kh, vh, kkh, ah, wh = (t.reshape(B, H, N) for t in (r, k, v, kk, a, wdec))
+        sa = np.einsum("bhij,bhj->bhi", S, -kkh)
+        S = S * wh[:, :, None, :] + sa[:, :, :, None] * (kkh * ah)[:, :, None, :] + vh[:, :, :, None] * kh[:, :, None, :]
+        S = S.astype(np.float32)
+        out = np.einsum("bhij,bhj->bhi", S, rh).reshape(B, -1)
+        y = self._bgn(out, w[p + "att.ln_x.weight"], w[p + "att.ln_x.bias"])
+        bonus = (rh * kh * w[p + "att.r_k"].reshape(1, H, N)).sum(axis=2, keepdims=True) * vh
+        y = y + bonus.reshape(B, -1)
+        return (y * g) @ w[p + "att.output.weight"].T, S, v_first
+
+    def _bffn7(self, p, xx, sx):
+        w = self.w
+        xk = xx + (sx - xx) * w[p + "ffn.x_k"].reshape(-1)
+        k = np.maximum(xk @ w[p + "ffn.key.weight"].T, 0) ** 2
+        return k @ w[p + "ffn.value.weight"].T
+
+    def init_states(self, B: int) -> np.ndarray:
+        i = self.info
+        return np.zeros((B, i.num_layer, i.head_size + 2, i.num_emb), dtype=np.float32)
+
+    def prefill(self, prompts, states: np.ndarray):
+        """Feed ragged prompts (one per slot) in lock step; returns the last-token logits of every slot [B, V]."""
+        B = len(prompts)
+        last = np.zeros((B, self.info.num_vocab), np.float32)
+        for t in range(max(len(p) for p in prompts)):
+            act = [b for b in range(B) if t < len(prompts[b])]
+            sub = states[act].copy()
+            lg = self.step([prompts[b][t] for b in act], sub)
+            states[act] = sub
+            for j, b in enumerate(act):
+                if t == len(prompts[b]) - 1:
+                    last[b] = lg[j]
+        return last
+
+    def greedy_batch(self, first_tokens, n_steps: int, states: np.ndarray):
+        """`n_steps` decode steps for every slot, arg-max fed back (Nucleus top_k=1, nucleus.rs:77-89); returns ids [n_steps, B]
+        (row s = the token chosen after step s) and the logits of the last step."""
+        cur = [int(t) for t in first_tokens]
+        out = np.zeros((n_steps, len(cur)), np.int64)
+        lg = None
+        for s in range(n_steps):
+            lg = self.step(cur, states)
+            cur = [int(t) for t in np.argmax(lg, axis=1)]
+            out[s] = cur
+        return out, lg
+
+
 def softmax_ref(logits: np.ndarray) -> np.ndarray:
     """`softmax::softmax` (run.rs:1179): numerically-stable softmax over the vocab, fp32."""
     x = logits.astype(np.float32)

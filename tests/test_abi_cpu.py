@@ -91,6 +91,46 @@ def test_tokenizer_matches_reference_algorithm(built_lib):
         tk.decode([10 ** 7])
 
 
+REF_VOCAB = "/root/reference/assets/tokenizer/rwkv_vocab_v20230424.json"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_VOCAB), reason="the reference checkout (and its full World vocabulary) is not on this machine")
+def test_tokenizer_on_the_full_reference_vocabulary(built_lib):
+    """The reference's own 65 529-entry vocabulary file (lib.rs:375 loads exactly this asset), read in place: table identical,
+    encode == greedy longest match over the whole vocabulary, decode round-trips, on the reference's README texts + random bytes."""
+    import json
+    raw = open(REF_VOCAB, encoding="utf-8").read()
+    tk = rt.Tokenizer(raw)
+    vocab = {int(k): (v.encode("utf-8") if isinstance(v, str) else bytes(v)) for k, v in json.loads(raw).items()}
+    assert len(vocab) == 65529 and min(vocab) == 1 and max(vocab) == 65529
+    table = tk.token_index_to_bytes()
+    for i, b in vocab.items():
+        assert table[i] == b
+    texts = []
+    for f in ("README.md", "README.zh.md"):
+        path = os.path.join("/root/reference", f)
+        if os.path.exists(path):
+            texts.append(open(path, "rb").read())
+    texts.append(np.random.default_rng(5).integers(0, 256, 5000, dtype=np.uint8).tobytes())
+    # longest-match oracle with a first-byte index (the plain _py_encode is quadratic in the vocabulary size)
+    by_first = {}
+    for i, b in vocab.items():
+        by_first.setdefault(b[0], []).append((len(b), b, i))
+    for v in by_first.values():
+        v.sort(reverse=True)
+    for data in texts:
+        want, pos = [], 0
+        while pos < len(data):
+            for n, b, i in by_first[data[pos]]:
+                if data[pos:pos + n] == b:
+                    want.append(i)
+                    pos += n
+                    break
+        ids = tk.encode(data)
+        assert ids == want
+        assert tk.decode(ids) == data
+
+
 def test_cpp_mirror_builds_and_reports_errors(built_lib, tmp_path):
     """The C++ host mirror (include/rwkv_runtime.hpp + harness/decode_loop.cpp) compiles against the header and
     surfaces engine errors as exit code 1 (no GPU here) instead of aborting."""

@@ -226,3 +226,22 @@ def test_mirostat_ref_matches_a_literal_restatement():
         got_tok, got_surprise, _ = R.mirostat_ref(p, ms, u)
         assert got_tok == tok
         assert abs(got_surprise - float(np.log2(total) - np.log2(prob))) < 1e-6
+
+
+@pytest.mark.parametrize("name,quant", [("v5-small", (0, 0)), ("v6-small", (2, 1)), ("v7-small", (2, 2)), ("v6-tiny", (0, 0))])
+def test_lockstep_batch_form_agrees_with_the_per_token_restatement(name, quant):
+    """RwkvRefBatch (the multi-slot form the 32-slot GPU tests check against) == RwkvRef slot by slot: logits and state to
+    fp32 round-off, greedy ids identical."""
+    t = R.synth_named(name)
+    ref, rb = R.RwkvRef(t, *quant), R.RwkvRefBatch(t, *quant)
+    V = ref.info.num_vocab
+    ps = [[x % V for x in R.synth_prompt(s, 4 + 3 * s)] for s in range(5)]
+    states = rb.init_states(5)
+    lg = rb.prefill(ps, states)
+    ids, _ = rb.greedy_batch(np.argmax(lg, axis=1), 12, states)
+    for b in range(5):
+        s = ref.init_state()
+        want = ref.forward(ps[b], s)[-1]
+        assert np.abs(want - lg[b]).max() <= 5e-6 * max(1.0, float(np.abs(want).max()))
+        g, s2 = ref.greedy(ps[b], 13)
+        assert g[0] == int(np.argmax(lg[b])) and g[1:] == [int(x) for x in ids[:, b]]
