@@ -76,6 +76,17 @@ constexpr uint32_t kPrefabVersion = 1;
 struct PfEntryHead { uint32_t kind; int32_t fmt, rows, K; uint32_t counted, name_len; uint64_t n_elems, data_bytes, scale_bytes; };
 struct PfHeader { char magic[8]; uint32_t version, n_entries; rwkv_model_info info; int32_t quant_layers, quant_type; };
 struct PfEntry { PfEntryHead h; const uint8_t *data = nullptr, *scales = nullptr; };
+// the dimension rules every loaded model must satisfy (kernel tiling), whether the header comes from tensor shapes or a prefab
+static void validate_info(const rwkv_model_info &i) {
+    if (i.version != 5 && i.version != 6 && i.version != 7) throw RwkvError(RWKV_ERR_UNSUPPORTED, "unsupported model version");
+    if (i.num_layer <= 0 || i.num_layer > 4096 || i.num_emb <= 0 || i.num_hidden <= 0 || i.num_vocab <= 0 || i.num_head <= 0 ||
+        i.num_vocab > (1 << 24) || i.num_hidden > (1 << 20))
+        throw RwkvError(RWKV_ERR_FORMAT, "model dimensions out of range");
+    if (i.head_size != 64 || i.num_emb != i.num_head * 64) throw RwkvError(RWKV_ERR_UNSUPPORTED, "head size must be 64");
+    if (i.num_emb % 64 || i.num_hidden % 32 || i.num_vocab % 16)
+        throw RwkvError(RWKV_ERR_UNSUPPORTED, "dims must satisfy C%64==0, F%32==0, V%16==0");
+    if (i.num_emb > 8192) throw RwkvError(RWKV_ERR_UNSUPPORTED, "num_emb > 8192");
+}
 static bool prefab_sniff(const uint8_t *b, size_t n) { return b && n >= sizeof(PfHeader) && std::memcmp(b, kPrefabMagic, 8) == 0; }
 struct Prefab {
     PfHeader hdr{};
@@ -85,22 +96,40 @@ struct Prefab {
         if (!prefab_sniff(b, n)) throw RwkvError(RWKV_ERR_FORMAT, "not a prefab image");
         std::memcpy(&p.hdr, b, sizeof(PfHeader));
         if (p.hdr.version != kPrefabVersion) throw RwkvError(RWKV_ERR_UNSUPPORTED, "prefab version mismatch");
+        validate_info(p.hdr.info);
         size_t off = sizeof(PfHeader);
-        auto pad16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+        // every length comes from the file: compare against what is LEFT (len > n - off), never off + len (which can wrap)
+        auto take = [&](uint64_t len) -> const uint8_t * {
+            if (off > n || len > (uint64_t)(n - off)) throw RwkvError(RWKV_ERR_FORMAT, "prefab truncated");
+            const uint8_t *q = b + off;
+            const uint64_t padded = (len + 15) & ~(uint64_t)15;
+            off = padded > (uint64_t)(n - off) ? n : off + (size_t)padded;
+            return q;
+        };
         for (uint32_t i = 0; i < p.hdr.n_entries; ++i) {
             PfEntry e;
-            if (off + sizeof(PfEntryHead) > n) throw RwkvError(RWKV_ERR_FORMAT, "prefab truncated");
-            std::memcpy(&e.h, b + off, sizeof(PfEntryHead));
-            off += sizeof(PfEntryHead);
-            if (off + e.h.name_len > n) throw RwkvError(RWKV_ERR_FORMAT, "prefab truncated");
-            std::string name((const char *)b + off, e.h.name_len);
-            off = pad16(off + e.h.name_len);
-            if (off + e.h.data_bytes > n) throw RwkvError(RWKV_ERR_FORMAT, "prefab truncated");
-            e.data = b + off;
-            off = pad16(off + e.h.data_bytes);
-            if (off + e.h.scale_bytes > n) throw RwkvError(RWKV_ERR_FORMAT, "prefab truncated");
-            e.scales = e.h.scale_bytes ? b + off : nullptr;
-            off = pad16(off + e.h.scale_bytes);
+            const uint8_t *hp = take(sizeof(PfEntryHead));
+            std::memcpy(&e.h, hp, sizeof(PfEntryHead));
+            // the 16-byte padding applies after name / data / scales, not after the fixed head
+            off = (size_t)(hp - b) + sizeof(PfEntryHead);
+            if (e.h.name_len > 4096) throw RwkvError(RWKV_ERR_FORMAT, "prefab: entry name too long");
+            std::string name((const char *)take(e.h.name_len), e.h.name_len);
+            e.data = take(e.h.data_bytes);
+            e.scales = e.h.scale_bytes ? take(e.h.scale_bytes) : nullptr;
+            // payload sizes must be the ones save_prefab computes from the entry's own description
+            const uint64_t ne = e.h.n_elems;
+            if (e.h.kind == 0) { if (ne > (1ull << 40) || e.h.data_bytes != ne * 4 || e.h.scale_bytes) throw RwkvError(RWKV_ERR_FORMAT, "prefab: bad vector entry " + name); }
+            else if (e.h.kind == 1) { if (ne > (1ull << 40) || e.h.data_bytes != ne * 2 || e.h.scale_bytes) throw RwkvError(RWKV_ERR_FORMAT, "prefab: bad fp16 entry " + name); }
+            else if (e.h.kind == 2) {
+                const int64_t rows = e.h.rows, K = e.h.K;
+                bool ok = rows > 0 && K > 0 && rows % 16 == 0 && rows <= (1 << 24) && K <= (1 << 24);
+                uint64_t db = 0, sb = 0;
+                if (ok && e.h.fmt == W_F16) { ok = K % 32 == 0; db = (uint64_t)rows * K * 2; }
+                else if (ok && e.h.fmt == W_INT8) { ok = K % 256 == 0; db = (uint64_t)rows * K; sb = (uint64_t)rows * (K / 128) * 4; }
+                else if (ok && e.h.fmt == W_NF4) { ok = K % 256 == 0; db = (uint64_t)rows * K / 2; sb = (uint64_t)rows * (K / 64) * 2; }
+                else ok = false;
+                if (!ok || e.h.data_bytes != db || e.h.scale_bytes != sb) throw RwkvError(RWKV_ERR_FORMAT, "prefab: bad matrix entry " + name);
+            } else throw RwkvError(RWKV_ERR_FORMAT, "prefab: unknown entry kind");
             p.entries.emplace(std::move(name), e);
         }
         return p;
@@ -131,13 +160,16 @@ static rwkv_model_info detect_info(const SafeTensors &st) {
     i.num_layer = L;
     i.num_vocab = (int)emb.shape[0];
     i.num_emb = (int)emb.shape[1];
-    i.num_hidden = (int)st.get("blocks.0.ffn.key.weight").shape[0];
-    i.num_head = (int)(i.version == 7 ? st.get("blocks.0.att.r_k").shape[0] : st.get("blocks.0.att.time_first").shape[0]);
+    auto dim0 = [&](const char *name, size_t min_rank) -> int {
+        const StTensor &t = st.get(name);
+        if (t.shape.size() < min_rank || t.shape[0] <= 0 || t.shape[0] > (1 << 24)) throw RwkvError(RWKV_ERR_FORMAT, std::string(name) + ": unexpected shape");
+        return (int)t.shape[0];
+    };
+    if (emb.shape[0] <= 0 || emb.shape[0] > (1 << 24) || emb.shape[1] <= 0 || emb.shape[1] > (1 << 20)) throw RwkvError(RWKV_ERR_FORMAT, "emb.weight: unexpected shape");
+    i.num_hidden = dim0("blocks.0.ffn.key.weight", 2);
+    i.num_head = i.version == 7 ? dim0("blocks.0.att.r_k", 2) : dim0("blocks.0.att.time_first", 2);
     i.head_size = i.num_emb / std::max(1, i.num_head);
-    if (i.head_size != 64) throw RwkvError(RWKV_ERR_UNSUPPORTED, "head size must be 64");
-    if (i.num_emb % 64 || i.num_hidden % 32 || i.num_vocab % 16)
-        throw RwkvError(RWKV_ERR_UNSUPPORTED, "dims must satisfy C%64==0, F%32==0, V%16==0");
-    if (i.num_emb > 8192) throw RwkvError(RWKV_ERR_UNSUPPORTED, "num_emb > 8192");
+    validate_info(i);
     return i;
 }
 
@@ -452,9 +484,11 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
         if (t.dtype != "F16") throw RwkvError(RWKV_ERR_UNSUPPORTED, "tensor dtype must be F16 (convert_safetensors.py:64)");
         HIP_CHECK(hipMemcpyAsync(raw, t.data, t.nbytes, hipMemcpyHostToDevice, s_main));
     };
-    auto load_vec = [&](const std::string &name, int op = 0) -> const float * {
+    // `want` = the element count the kernels will read (0: unchecked): a short tensor must fail the load, not a kernel
+    auto load_vec = [&](const std::string &name, int op = 0, size_t want = 0) -> const float * {
         if (pf) {
             const PfEntry &e = prefab.get(name, 0);
+            if (want && e.h.n_elems != want) throw RwkvError(RWKV_ERR_FORMAT, name + ": unexpected size");
             float *v = dalloc<float>((size_t)e.h.n_elems);
             HIP_CHECK(hipMemcpy(v, e.data, e.h.n_elems * 4, hipMemcpyHostToDevice));
             vecs[name] = v; vec_meta[name] = {(size_t)e.h.n_elems, true};
@@ -462,6 +496,7 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
             return v;
         }
         const StTensor &t = st.get(name);
+        if (want && (size_t)t.numel() != want) throw RwkvError(RWKV_ERR_FORMAT, name + ": unexpected size");
         upload_raw(t);
         float *v = dalloc<float>((size_t)t.numel());
         launch_f16_to_f32(raw, v, t.numel(), op, s_main);
@@ -470,9 +505,10 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
         weight_bytes += (uint64_t)t.numel() * 2;
         return v;
     };
-    auto load_raw16 = [&](const std::string &name, bool count) -> const _Float16 * {
+    auto load_raw16 = [&](const std::string &name, bool count, size_t want = 0) -> const _Float16 * {
         if (pf) {
             const PfEntry &e = prefab.get(name, 1);
+            if (want && e.h.n_elems != want) throw RwkvError(RWKV_ERR_FORMAT, name + ": unexpected size");
             _Float16 *v = dalloc<_Float16>((size_t)e.h.n_elems);
             HIP_CHECK(hipMemcpy(v, e.data, e.h.n_elems * 2, hipMemcpyHostToDevice));
             raws[name] = v; raw_meta[name] = {(size_t)e.h.n_elems, count};
@@ -481,6 +517,7 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
         }
         const StTensor &t = st.get(name);
         if (t.dtype != "F16") throw RwkvError(RWKV_ERR_UNSUPPORTED, "tensor dtype must be F16");
+        if (want && (size_t)t.numel() != want) throw RwkvError(RWKV_ERR_FORMAT, name + ": unexpected size");
         _Float16 *v = dalloc<_Float16>((size_t)t.numel());
         HIP_CHECK(hipMemcpy(v, t.data, t.nbytes, hipMemcpyHostToDevice));
         raws[name] = v; raw_meta[name] = {(size_t)t.numel(), count};
@@ -488,10 +525,18 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
         return v;
     };
     // matrix [.., rows, K] (leading dims folded into `index`)
-    auto load_mat = [&](const std::string &name, int fmt, int index = -1, const std::string &key = "") -> const DMat * {
+    // want_rows / want_K: the shape the forward pass assumes (0: taken from the tensor, e.g. LoRA ranks); rows are checked
+    // after padding to whole 16-row strips
+    auto load_mat = [&](const std::string &name, int fmt, int index = -1, const std::string &key = "", int want_rows = 0, int want_K = 0) -> const DMat * {
+        auto check_shape = [&](int rows16, int K) {
+            if ((want_rows && rows16 != (want_rows + 15) / 16 * 16) || (want_K && K != want_K))
+                throw RwkvError(RWKV_ERR_FORMAT, name + ": unexpected matrix shape");
+        };
         if (pf) {
             const std::string &k = key.empty() ? name : key;
             const PfEntry &e = prefab.get(k, 2);
+            check_shape(e.h.rows, e.h.K);
+            if (e.h.fmt != fmt) throw RwkvError(RWKV_ERR_FORMAT, name + ": stored format differs from the image header's quantisation");
             DMat m;
             m.fmt = e.h.fmt; m.rows = e.h.rows; m.K = e.h.K; m.bytes = e.h.n_elems;
             void *p = dalloc<uint8_t>((size_t)e.h.data_bytes);
@@ -507,7 +552,15 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
         }
         const StTensor &t = st.get(name);
         if (t.shape.size() < 2) throw RwkvError(RWKV_ERR_FORMAT, name + ": expected a matrix");
+        if (t.shape.back() <= 0 || t.shape.back() > (1 << 24) || t.shape[t.shape.size() - 2] <= 0 || t.shape[t.shape.size() - 2] > (1 << 24))
+            throw RwkvError(RWKV_ERR_FORMAT, name + ": unexpected matrix shape");
         const int K = (int)t.shape.back(), rows = (int)t.shape[t.shape.size() - 2];
+        check_shape((rows + 15) / 16 * 16, K);
+        {
+            size_t lead = 1;
+            for (size_t i = 0; i + 2 < t.shape.size(); ++i) lead *= (size_t)t.shape[i];
+            if (index >= 0 ? (size_t)index >= lead : lead != 1) throw RwkvError(RWKV_ERR_FORMAT, name + ": unexpected leading dimensions");
+        }
         upload_raw(t);
         const _Float16 *src = raw + (index >= 0 ? (size_t)index * rows * K : 0);
         if (index < 0) {
@@ -562,12 +615,13 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
         return &it->second;
     };
 
-    emb = load_raw16("emb.weight", false);                    // embedding table: only B rows touched per step
-    ln0w = load_vec("blocks.0.ln0.weight");
-    ln0b = load_vec("blocks.0.ln0.bias");
-    lnow = load_vec("ln_out.weight");
-    lnob = load_vec("ln_out.bias");
-    head = load_mat("head.weight", W_F16);
+    const size_t nC = (size_t)C;
+    emb = load_raw16("emb.weight", false, (size_t)V * C);     // embedding table: only B rows touched per step
+    ln0w = load_vec("blocks.0.ln0.weight", 0, nC);
+    ln0b = load_vec("blocks.0.ln0.bias", 0, nC);
+    lnow = load_vec("ln_out.weight", 0, nC);
+    lnob = load_vec("ln_out.bias", 0, nC);
+    head = load_mat("head.weight", W_F16, -1, "", V, C);
     if (head->rows != V) throw RwkvError(RWKV_ERR_FORMAT, "head.weight rows != vocab");
 
     layers.resize(L);
@@ -577,55 +631,68 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
         const std::string p = "blocks." + std::to_string(l) + ".";
         const int qf = (quant_type != RWKV_QUANT_NONE && l < quant_layers) ? (quant_type == RWKV_QUANT_INT8 ? W_INT8 : W_NF4) : W_F16;
         auto qfmt = [&](const char *suffix) { return is_quant_target(info.version, suffix) ? qf : W_F16; };
-        w.ln1w = load_vec(p + "ln1.weight"); w.ln1b = load_vec(p + "ln1.bias");
-        w.ln2w = load_vec(p + "ln2.weight"); w.ln2b = load_vec(p + "ln2.bias");
-        w.lnxw = load_vec(p + "att.ln_x.weight"); w.lnxb = load_vec(p + "att.ln_x.bias");
-        w.Wr = load_mat(p + "att.receptance.weight", qfmt("att.receptance.weight"));
-        w.Wk = load_mat(p + "att.key.weight", qfmt("att.key.weight"));
-        w.Wv = load_mat(p + "att.value.weight", qfmt("att.value.weight"));
-        w.Wo = load_mat(p + "att.output.weight", qfmt("att.output.weight"));
-        w.Fk = load_mat(p + "ffn.key.weight", qfmt("ffn.key.weight"));
-        w.Fv = load_mat(p + "ffn.value.weight", qfmt("ffn.value.weight"));
+        // every vector is [C] (time_decay / time_first / r_k are [H, 64]); every matrix is checked against the shape the
+        // forward pass assumes, so a truncated or inconsistent checkpoint fails here with RWKV_ERR_FORMAT
+        w.ln1w = load_vec(p + "ln1.weight", 0, nC); w.ln1b = load_vec(p + "ln1.bias", 0, nC);
+        w.ln2w = load_vec(p + "ln2.weight", 0, nC); w.ln2b = load_vec(p + "ln2.bias", 0, nC);
+        w.lnxw = load_vec(p + "att.ln_x.weight", 0, nC); w.lnxb = load_vec(p + "att.ln_x.bias", 0, nC);
+        w.Wr = load_mat(p + "att.receptance.weight", qfmt("att.receptance.weight"), -1, "", C, C);
+        w.Wk = load_mat(p + "att.key.weight", qfmt("att.key.weight"), -1, "", C, C);
+        w.Wv = load_mat(p + "att.value.weight", qfmt("att.value.weight"), -1, "", C, C);
+        w.Wo = load_mat(p + "att.output.weight", qfmt("att.output.weight"), -1, "", C, C);
+        w.Fk = load_mat(p + "ffn.key.weight", qfmt("ffn.key.weight"), -1, "", F, C);
+        w.Fv = load_mat(p + "ffn.value.weight", qfmt("ffn.value.weight"), -1, "", C, F);
         if (info.version != 7) {
-            w.Wg = load_mat(p + "att.gate.weight", qfmt("att.gate.weight"));
-            w.Fr = load_mat(p + "ffn.receptance.weight", qfmt("ffn.receptance.weight"));
-            w.fmu[0] = load_vec(p + "ffn.time_mix_k");
-            w.fmu[1] = load_vec(p + "ffn.time_mix_r");
-            w.u = load_vec(p + "att.time_first");
+            w.Wg = load_mat(p + "att.gate.weight", qfmt("att.gate.weight"), -1, "", C, C);
+            w.Fr = load_mat(p + "ffn.receptance.weight", qfmt("ffn.receptance.weight"), -1, "", C, C);
+            w.fmu[0] = load_vec(p + "ffn.time_mix_k", 0, nC);
+            w.fmu[1] = load_vec(p + "ffn.time_mix_r", 0, nC);
+            w.u = load_vec(p + "att.time_first", 0, nC);
         }
         if (info.version == 5) {
             const char *n4[] = {"k", "v", "r", "g"};
-            for (int i = 0; i < 4; ++i) w.mu[i] = load_vec(p + "att.time_mix_" + n4[i]);
-            w.wdec = load_vec(p + "att.time_decay", 1);      // exp(-exp(decay)), static per channel
+            for (int i = 0; i < 4; ++i) w.mu[i] = load_vec(p + "att.time_mix_" + n4[i], 0, nC);
+            w.wdec = load_vec(p + "att.time_decay", 1, nC);  // exp(-exp(decay)), static per channel
         } else if (info.version == 6) {
             const char *n6[] = {"x", "w", "k", "v", "r", "g"};
-            for (int i = 0; i < 6; ++i) w.mu[i] = load_vec(p + "att.time_mix_" + n6[i]);
-            w.wdec = load_vec(p + "att.time_decay");
-            w.W1 = load_mat(p + "att.time_mix_w1", W_F16);
+            for (int i = 0; i < 6; ++i) w.mu[i] = load_vec(p + "att.time_mix_" + n6[i], 0, nC);
+            w.wdec = load_vec(p + "att.time_decay", 0, nC);
+            int dm_l;
             if (!pf) {
                 const StTensor &w2 = st.get(p + "att.time_mix_w2");
-                if (w2.shape.size() != 3 || w2.shape[0] != 5) throw RwkvError(RWKV_ERR_FORMAT, "time_mix_w2 must be [5,C,Dm]");
-                Dm = (int)w2.shape[2];
+                if (w2.shape.size() != 3 || w2.shape[0] != 5 || w2.shape[1] != C || w2.shape[2] <= 0 || w2.shape[2] > 4096)
+                    throw RwkvError(RWKV_ERR_FORMAT, "time_mix_w2 must be [5,C,Dm]");
+                dm_l = (int)w2.shape[2];
             } else {
-                Dm = prefab.get(p + "att.time_mix_w2#0", 2).h.K;
+                dm_l = prefab.get(p + "att.time_mix_w2#0", 2).h.K;
             }
-            for (int c = 0; c < 5; ++c) w.W2[c] = load_mat(p + "att.time_mix_w2", W_F16, c, p + "att.time_mix_w2#" + std::to_string(c));
-            w.D1 = load_mat(p + "att.time_decay_w1", W_F16);
+            if (l > 0 && dm_l != Dm) throw RwkvError(RWKV_ERR_FORMAT, "time_mix LoRA dim differs between layers");
+            Dm = dm_l;
+            w.W1 = load_mat(p + "att.time_mix_w1", W_F16, -1, "", 5 * Dm, C);
+            for (int c = 0; c < 5; ++c) w.W2[c] = load_mat(p + "att.time_mix_w2", W_F16, c, p + "att.time_mix_w2#" + std::to_string(c), C, Dm);
+            w.D1 = load_mat(p + "att.time_decay_w1", W_F16, -1, "", 0, C);
+            if (l > 0 && w.D1->rows != Dd) throw RwkvError(RWKV_ERR_FORMAT, "time_decay LoRA dim differs between layers");
             Dd = w.D1->rows;
             if (Dd > 128 || Dd % 4) throw RwkvError(RWKV_ERR_UNSUPPORTED, "time_decay LoRA dim must be <=128");
-            w.D2 = load_raw16(p + "att.time_decay_w2", true);
+            w.D2 = load_raw16(p + "att.time_decay_w2", true, (size_t)C * Dd);
         } else {
             const char *n7[] = {"r", "w", "k", "v", "a", "g"};
-            for (int i = 0; i < 6; ++i) w.mu[i] = load_vec(p + "att.x_" + n7[i]);
-            w.fmu[0] = load_vec(p + "ffn.x_k");
-            w.w0 = load_vec(p + "att.w0"); w.a0 = load_vec(p + "att.a0");
-            w.k_k = load_vec(p + "att.k_k"); w.k_a = load_vec(p + "att.k_a"); w.r_k = load_vec(p + "att.r_k");
-            w.w1 = load_mat(p + "att.w1", W_F16); w.w2 = load_mat(p + "att.w2", W_F16);
-            w.a1 = load_mat(p + "att.a1", W_F16); w.a2 = load_mat(p + "att.a2", W_F16);
-            w.g1 = load_mat(p + "att.g1", W_F16); w.g2 = load_mat(p + "att.g2", W_F16);
+            for (int i = 0; i < 6; ++i) w.mu[i] = load_vec(p + "att.x_" + n7[i], 0, nC);
+            w.fmu[0] = load_vec(p + "ffn.x_k", 0, nC);
+            w.w0 = load_vec(p + "att.w0", 0, nC); w.a0 = load_vec(p + "att.a0", 0, nC);
+            w.k_k = load_vec(p + "att.k_k", 0, nC); w.k_a = load_vec(p + "att.k_a", 0, nC); w.r_k = load_vec(p + "att.r_k", 0, nC);
+            // LoRA pairs: stage 1 is [D, C] with a free rank D, stage 2 must be [C, D] of the same rank
+            auto lora_pair = [&](const char *n1, const char *n2, const DMat *&m1, const DMat *&m2) {
+                m1 = load_mat(p + n1, W_F16, -1, "", 0, C);
+                m2 = load_mat(p + n2, W_F16, -1, "", C, 0);
+                if (m2->K > m1->rows || m2->K % 32) throw RwkvError(RWKV_ERR_FORMAT, p + n2 + ": LoRA rank mismatch");
+            };
+            lora_pair("att.w1", "att.w2", w.w1, w.w2);
+            lora_pair("att.a1", "att.a2", w.a1, w.a2);
+            lora_pair("att.g1", "att.g2", w.g1, w.g2);
             if (l > 0 || (pf ? prefab.has(p + "att.v0") : st.find(p + "att.v0") != nullptr)) {
-                w.v0 = load_vec(p + "att.v0");
-                w.v1 = load_mat(p + "att.v1", W_F16); w.v2 = load_mat(p + "att.v2", W_F16);
+                w.v0 = load_vec(p + "att.v0", 0, nC);
+                lora_pair("att.v1", "att.v2", w.v1, w.v2);
             }
             for (const DMat *m : {w.w1, w.a1, w.v1, w.g1}) if (m) Dl = std::max(Dl, m->rows);
         }

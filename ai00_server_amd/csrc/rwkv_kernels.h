@@ -33,6 +33,15 @@ struct DMat {
     uint64_t bytes = 0;             // payload + scales, for roofline accounting
 };
 
+// Soft dependency of a launch on its predecessor (rwkv_kernels.hip "Step-local activations and soft launch dependencies").
+// wait == nullptr: the launch is ordered by its stream alone; signal == nullptr: nobody polls this launch.
+struct DepLink {
+    const unsigned *wait = nullptr;  // completion counter of the predecessor launch
+    unsigned target = 0;             // = number of blocks of the predecessor
+    unsigned *signal = nullptr;      // this launch's own completion counter (every block adds 1 when its stores have drained)
+    unsigned *err = nullptr;         // set to 1 when a poll gives up
+};
+
 struct RowMeta {                    // device arrays, one entry per row of this step
     const int *token;               // token id
     const int *slot;                // state slot
@@ -104,6 +113,7 @@ struct GemmLaunch {
     int total_blocks;
     LnProArgs lnp;
     ShiftCommit commit;             // grid = total_blocks + 1 when commit.src is set
+    DepLink dep;
 };
 
 void gemm_variant(int T, bool hilo, int &NT, int &KSW);   // tile variant used for T rows
@@ -128,6 +138,7 @@ struct V6MixArgs {
     int ldh, T, C, Dm;
     LnProArgs lnp;                  // lnp.x_in set: LayerNorm + shift computed in the kernel (z, xx, dx unused)
     const float *mu_x;              // with lnp: z = xx + dx * mu_x
+    DepLink dep;
 };
 bool v6_mix_supported(int T, int C, int Dm);
 bool v6_mix_ln_supported(int T, int C, int Dm, bool hilo, int np);   // the LayerNorm-prologue form (lnp set)
@@ -152,6 +163,7 @@ struct LnShiftArgs {
     int ldh;
     float *xx_out, *dx_out;         // optional fp32 copies (V6 time-mix LoRA epilogue needs them)
     int C;
+    DepLink dep;
 };
 void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s);
 
@@ -161,6 +173,7 @@ struct EmbedArgs {
     const int *token;
     float *x;
     int C, V;
+    DepLink dep;
 };
 void launch_embed(const EmbedArgs &a, int T, hipStream_t s);
 
@@ -173,6 +186,7 @@ struct LnOutArgs {
     const int *out_rows;            // rows to emit (compacted)
     _Float16 *ohi, *olo;
     int ldh, C;
+    DepLink dep;
 };
 void launch_ln_out(const LnOutArgs &a, int n_out, hipStream_t s);
 
@@ -201,6 +215,7 @@ struct WkvArgs {
     const float *lnx_w, *lnx_b;
     _Float16 *yhi, *ylo;
     int ldh;
+    DepLink dep;
 };
 void launch_wkv(const WkvArgs &a, bool multi_row, hipStream_t s);   // multi_row: some sequence has > 1 row in this step
 

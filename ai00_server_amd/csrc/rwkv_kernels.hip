@@ -37,6 +37,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -76,6 +77,79 @@ __device__ __forceinline__ void store_operand4(_Float16 *__restrict__ hi, _Float
     split_hilo(o.w, a, b); h[3] = a; l[3] = b;
     *(f16x4 *)(hi + off) = h;
     if (lo) *(f16x4 *)(lo + off) = l;
+}
+
+// =====================================================================================
+// Step-local activations and soft launch dependencies (DepLink, rwkv_kernels.h).
+//
+// A decode step is a chain of ~260 dependent launches, each of which streams a few MB of weights that do NOT depend on
+// its predecessor.  The engine therefore runs consecutive launches on alternating HIP streams: launch i+1 starts while
+// launch i is still running, issues its weight / state loads, and only then waits — inside the kernel — for launch i's
+// completion counter (one relaxed agent-scope poll by one lane, `dep_wait`).  Launch boundaries (≈4 us each on this part
+// for a dependent pair) turn into a ≈1 us flag hop, and the weight stream of launch i+1 overlaps the tail of launch i.
+//
+// Visibility without fences (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": valid
+// form `sc1` stores AND `sc1` loads both sides): every buffer a launch of the step writes and a later launch of the SAME
+// step reads is written with write-through `sc1` stores and read with `sc1` loads (L1 bypassed; per-XCD L2s need no
+// write-back / invalidate); every storing wave drains `vmcnt(0)` before the block's single counter increment.
+// Weights, constants and the recurrent state (written in one step, read in the next, i.e. across a real graph boundary)
+// keep plain / non-temporal accesses.  The accessors below are the ONLY way activations are touched in decode-path kernels.
+// =====================================================================================
+typedef __amdgpu_buffer_rsrc_t act_t;                              // buffer descriptor of one activation array (4 SGPRs)
+constexpr int ACT_SC1 = 16;                                       // gfx950 cache-policy bit 4 = sc1 (agent scope)
+__device__ __forceinline__ act_t act_buf(const void *p) {         // p must be wave-uniform (kernel argument arithmetic)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float4 act_ld4(act_t b, long fidx) {   // 4 floats at float index fidx (16-byte aligned)
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(b, (unsigned)(fidx * 4), 0, ACT_SC1));
+}
+__device__ __forceinline__ float act_ld1(act_t b, long fidx) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, (unsigned)(fidx * 4), 0, ACT_SC1));
+}
+__device__ __forceinline__ f16x8 act_ldh8(act_t b, long hidx) {   // 8 halfs at half index hidx (16-byte aligned)
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(b, (unsigned)(hidx * 2), 0, ACT_SC1));
+}
+__device__ __forceinline__ void act_st4(act_t b, long fidx, float4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b, (unsigned)(fidx * 4), 0, ACT_SC1);
+}
+__device__ __forceinline__ void act_st1(act_t b, long fidx, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(u32, v), b, (unsigned)(fidx * 4), 0, ACT_SC1);
+}
+__device__ __forceinline__ void act_sth4(act_t b, long hidx, f16x4 v) {   // 4 halfs (8 bytes)
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), b, (unsigned)(hidx * 2), 0, ACT_SC1);
+}
+// operand emit (hi[, lo] f16 pair of four fp32 values) into an activation operand
+__device__ __forceinline__ void act_store_operand4(act_t hi, act_t lo, bool has_lo, long off, float4 o) {
+    f16x4 h, l;
+    _Float16 a, b;
+    split_hilo(o.x, a, b); h[0] = a; l[0] = b;
+    split_hilo(o.y, a, b); h[1] = a; l[1] = b;
+    split_hilo(o.z, a, b); h[2] = a; l[2] = b;
+    split_hilo(o.w, a, b); h[3] = a; l[3] = b;
+    act_sth4(hi, off, h);
+    if (has_lo) act_sth4(lo, off, l);
+}
+
+constexpr unsigned DEP_SPIN_LIMIT = 1u << 22;                      // ~0.5 s of polling: a step never takes that long
+// All threads of the block call this at one uniform point, AFTER issuing every load that does not depend on the
+// predecessor.  One lane polls; the barrier releases the block.  A poll that gives up sets *err (the host fails the call).
+__device__ __forceinline__ void dep_wait(const DepLink &d) {
+    if (d.wait == nullptr) return;
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(d.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < d.target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > DEP_SPIN_LIMIT) { __hip_atomic_store(d.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+}
+// All threads call this after their last activation store: drain the write-through stores, then ONE increment per block.
+__device__ __forceinline__ void dep_signal(const DepLink &d) {
+    if (d.signal == nullptr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(d.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Cross-lane sums on the DPP path (v_add_f32 with a dpp source modifier, a few cycles each) instead of `__shfl_xor`,
@@ -283,6 +357,7 @@ __device__ __forceinline__ void ln_prologue_load(const LnProArgs &a, int T, floa
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int C = a.C, ldl = C + LNP_PAD;
     int (&prev)[LNP_MAX_T] = k.prev;
+    const act_t bx = act_buf(a.x_in), bP = act_buf(a.P), bsx = act_buf(a.sx), bxo = act_buf(a.x_out);
     // ---- pass 1, row by row (registers: one row's slabs in flight): residual sum -> LDS, state -> LDS, partial sums
 #pragma unroll
     for (int t = 0; t < LNP_MAX_T; ++t) {
@@ -294,11 +369,11 @@ __device__ __forceinline__ void ln_prologue_load(const LnProArgs &a, int T, floa
             for (int i = 0; i < PTN; ++i) {
                 const int c = (tid + i * nth) * 4;
                 if (c < C) {
-                    v[i] = lnp_ld4(a.x_in + (long)t * C + c);
+                    v[i] = act_ld4(bx, (long)t * C + c);
 #pragma unroll
                     for (int j = 0; j < LNP_MAX_NP; ++j)       // branch-free: slabs beyond np re-read slab 0 and are dropped below
-                        pp[j][i] = lnp_ld4(a.P + (j < a.np ? j : 0) * a.pstride + (long)t * C + c);
-                    sxv[i] = lnp_ld4(a.sx + (long)slot * a.sx_slot_stride + c);
+                        pp[j][i] = act_ld4(bP, (j < a.np ? j : 0) * a.pstride + (long)t * C + c);
+                    sxv[i] = act_ld4(bsx, (long)slot * a.sx_slot_stride + c);
                 }
             }
             float sum = 0.f;
@@ -312,7 +387,7 @@ __device__ __forceinline__ void ln_prologue_load(const LnProArgs &a, int T, floa
                         v[i].x += on ? pp[j][i].x : 0.f; v[i].y += on ? pp[j][i].y : 0.f;
                         v[i].z += on ? pp[j][i].z : 0.f; v[i].w += on ? pp[j][i].w : 0.f;
                     }
-                    if (publish) *(float4 *)(a.x_out + (long)t * C + c) = v[i];
+                    if (publish) act_st4(bxo, (long)t * C + c, v[i]);
                     *(float4 *)(xx_l + t * ldl + c) = v[i];
                     *(float4 *)(pv_l + t * ldl + c) = sxv[i];
                     sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -332,6 +407,7 @@ __device__ __forceinline__ void ln_prologue_finish(const LnProArgs &a, int T, co
     const int tid = threadIdx.x, nth = blockDim.x, nwv = nth >> 6, lane = tid & 63, wave = tid >> 6;
     const int C = a.C, ldl = C + LNP_PAD;
     const int (&prev)[LNP_MAX_T] = k.prev;
+    const act_t bxxo = act_buf(a.xx_out);
     float4 wv[PTN], bv[PTN], muv[PTN];                           // L2-hot parameters: in flight across the first barrier
 #pragma unroll
     for (int i = 0; i < PTN; ++i) {
@@ -380,7 +456,7 @@ __device__ __forceinline__ void ln_prologue_finish(const LnProArgs &a, int T, co
                     o.z = (v.z - mean[t]) * rstd * wv[i].z + bv[i].z;
                     o.w = (v.w - mean[t]) * rstd * wv[i].w + bv[i].w;
                     *(float4 *)(xx_l + t * ldl + c) = o;
-                    if (publish) *(float4 *)(a.xx_out + (long)t * C + c) = o;
+                    if (publish) act_st4(bxxo, (long)t * C + c, o);
                 }
             }
         }
@@ -426,9 +502,9 @@ __device__ __forceinline__ void shift_commit(const ShiftCommit &c) {
     for (int t = 0; t < c.T; ++t) {
         const int last = c.rm.last[t];
         if (last < 0) continue;
-        const float *src = c.src + (long)last * c.C;
+        const act_t src = act_buf(c.src);
         float *dst = c.sx + (long)c.rm.slot[t] * c.sx_slot_stride;
-        for (int i = threadIdx.x * 4; i < c.C; i += blockDim.x * 4) *(float4 *)(dst + i) = *(const float4 *)(src + i);
+        for (int i = threadIdx.x * 4; i < c.C; i += blockDim.x * 4) *(float4 *)(dst + i) = act_ld4(src, (long)last * c.C + i);
     }
 }
 
@@ -468,7 +544,48 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
         }
     };
 
+    // activation arrays of this problem (write-through / L1-bypassing accessors, see "Step-local activations")
+    const act_t bxh = act_buf(P.xhi), bxl = act_buf(P.xlo);
+    const act_t bo32 = act_buf(P.out_f32 ? P.out_f32 + (long)kb * P.partial_stride : nullptr);
+    const act_t boh = act_buf(P.out_hi), bol = act_buf(P.out_lo), bm0 = act_buf(P.m0), bm1 = act_buf(P.m1);
+
+    // rounds a wave holds in registers at once (gemm_max_rounds)
+    constexpr int MAXR = NT == 4 ? 2 : (FMT == W_F16 ? 2 : ((NT == 2 || HILO) ? 3 : 4));
+    WRound<FMT> cur, nxt, w[SHOT ? MAXR : 1];
+    // streamed (not single-shot) quantised weights: a ring of RD rounds in flight per wave.  With only cur/nxt
+    // (one round ahead) a wave's K slice is a serial chain of memory latencies — 6 rounds x ~0.9 us at T = 1
+    // (scripts/trace_gemm.py); fp16 rounds are twice the registers and stay at one round ahead.
+    constexpr int RD = (!SHOT && FMT != W_F16) ? ((NT >= 2 || HILO || LNP) ? 2 : 4) : 1;
+    WRound<FMT> ring[RD];
+    // weights of one K slice of this wave: everything (single shot), the first RD rounds (ring) or the first round
+    auto issue_w = [&](int k0, int nsub, int nround, bool ringed) {
+        if constexpr (SHOT) {
+            // single shot: every weight tile of this wave is in flight before the first MFMA (host: spb * SUB <= MAXR)
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+                const int s = r / SUB, sub = r % SUB;
+                if (s < nstrip && sub < nsub) load_round<FMT, TAIL>(w[r], P, strip0 + s, k0 + sub * RK, kend, true, lane);
+            }
+        } else if (ringed) {
+#pragma unroll
+            for (int j = 0; j < RD; ++j)
+                if (j < nround) load_round<FMT, TAIL>(ring[j], P, strip0 + j / SUB, k0 + (j % SUB) * RK, kend, true, lane);
+        } else {
+            load_round<FMT, TAIL>(cur, P, strip0, k0, kend, true, lane);
+        }
+    };
+
     TRACE_PT(0);
+    // The weights of the wave's first slice do not depend on the previous launch: they are issued BEFORE the wait on its
+    // completion counter (dep_wait), so the stream of this launch overlaps the tail of its predecessor.
+    bool prefetched = false;
+    if (wave < nw && wave < nslice) {
+        const int k0 = kbeg + wave * KW;
+        const int nsub = TAIL ? SUB : min(SUB, (kend - k0) / RK);
+        issue_w(k0, nsub, nstrip * nsub, RD > 1 && nsub == SUB);
+        prefetched = true;
+    }
+    dep_wait(L.dep);
     for (int t0 = 0; t0 < L.T; t0 += NT * 16) {
         for (int sl = wave; sl < nslice && wave < nw; sl += nw) {
             const int k0 = kbeg + sl * KW;
@@ -478,16 +595,6 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
             TRACE_PT(6);
             // X slice of this wave -> B fragments: one contiguous 1 KiB tile per (n-tile, k-step), see opd_off
             f16x8 xb[NT][KSW], xl[HILO ? NT : 1][HILO ? KSW : 1];
-            // X first, weights after: the X fragments are L2 hits and complete first, so (in-order vmcnt) the MFMAs of round
-            // r only wait for rounds <= r while later rounds are still streaming in from HBM.  (Weights-first was measured
-            // and is slower: issuing is throttled by the CU's memory pipeline either way, and X then lands last.)
-            constexpr int MAXR = NT == 4 ? 2 : (FMT == W_F16 ? 2 : ((NT == 2 || HILO) ? 3 : 4));   // rounds a wave holds in registers at once (gemm_max_rounds)
-            WRound<FMT> cur, nxt, w[SHOT ? MAXR : 1];
-            // streamed (not single-shot) quantised weights: a ring of RD rounds in flight per wave.  With only cur/nxt
-            // (one round ahead) a wave's K slice is a serial chain of memory latencies — 6 rounds x ~0.9 us at T = 1
-            // (scripts/trace_gemm.py); fp16 rounds are twice the registers and stay at one round ahead.
-            constexpr int RD = (!SHOT && FMT != W_F16) ? ((NT >= 2 || HILO || LNP) ? 2 : 4) : 1;
-            WRound<FMT> ring[RD];
             const bool ringed = RD > 1 && nsub == SUB;
             auto load_x = [&]() {
 #pragma unroll
@@ -497,8 +604,6 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                     const int tile = min((t0 >> 4) + nt, (L.T - 1) >> 4);
                     const int tl = min(lane & 15, L.T - 1 - tile * 16);
                     const long xo = ((long)tile * (P.ldx >> 5) + (k0 >> 5)) * 512 + ((lane >> 4) * 16 + tl) * 8;
-                    const _Float16 *ph = P.xhi + xo;
-                    const _Float16 *pl = HILO ? P.xlo + xo : nullptr;
 #pragma unroll
                     for (int sub = 0; sub < SUB; ++sub) {
                         if (TAIL || sub < nsub) {                      // one uniform branch per 256-k round
@@ -506,8 +611,8 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                             for (int k8 = 0; k8 < RS; ++k8) {
                                 const int ks = sub * RS + k8;
                                 const bool in = !TAIL || (k0 + ks * 32 < kend);
-                                xb[nt][ks] = in ? *(const f16x8 *)(ph + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                                if constexpr (HILO) xl[nt][ks] = in ? *(const f16x8 *)(pl + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                                xb[nt][ks] = in ? act_ldh8(bxh, xo + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                                if constexpr (HILO) xl[nt][ks] = in ? act_ldh8(bxl, xo + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                             }
                         } else {
 #pragma unroll
@@ -519,25 +624,9 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                     }
                 }
             };
-            auto issue_w = [&]() {
-                if constexpr (SHOT) {
-                    // single shot: every weight tile of this wave is in flight before the first MFMA (host: spb * SUB <= MAXR)
-#pragma unroll
-                    for (int r = 0; r < MAXR; ++r) {
-                        const int s = r / SUB, sub = r % SUB;
-                        if (s < nstrip && sub < nsub) load_round<FMT, TAIL>(w[r], P, strip0 + s, k0 + sub * RK, kend, true, lane);
-                    }
-                } else if (ringed) {
-#pragma unroll
-                    for (int j = 0; j < RD; ++j)
-                        if (j < nround) load_round<FMT, TAIL>(ring[j], P, strip0 + j / SUB, k0 + (j % SUB) * RK, kend, true, lane);
-                } else {
-                    load_round<FMT, TAIL>(cur, P, strip0, k0, kend, true, lane);
-                }
-            };
             if constexpr (LNP) {
-                // LayerNorm prologue launch: row loads, then this wave's weights (holding both in flight at once does not
-                // fit the register file), then the reductions; the B fragments come from the prologue's LDS image.
+                // LayerNorm prologue launch: this wave's weights are already in flight (issued before the dependency wait);
+                // row loads, reductions; the B fragments come from the prologue's LDS image.
                 // One slice per wave, one 16-token tile (host checks).
                 float *xx_l = (float *)(smem + (size_t)L.lds_items * NT * 64 * 16);
                 const int ldl = L.lnp.C + LNP_PAD;
@@ -545,7 +634,6 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                 _Float16 *op_l = (_Float16 *)(lred + 64);
                 LnCarry carry;
                 ln_prologue_load(L.lnp, L.T, xx_l, pv_l, lred, blockIdx.x == 0, carry);
-                issue_w();                                     // the weights fly while the rows are reduced and normalised
                 ln_prologue_finish<HILO>(L.lnp, L.T, P.lnp_mu, xx_l, pv_l, op_l, lred, blockIdx.x == 0, carry);
                 const int tl = min(lane & 15, L.T - 1);
                 const _Float16 *oph = op_l + lnp_op_off(L.T, k0 + (lane >> 4) * 8, tl);
@@ -557,8 +645,9 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                 }
             } else {
                 load_x();
-                issue_w();
+                if (!prefetched) issue_w(k0, nsub, nround, ringed);
             }
+            prefetched = false;
 #ifdef RWKV_TRACE
             TRACE_PT(1);
 #if RWKV_TRACE >= 2
@@ -646,27 +735,22 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                     float x = v4[r];
                     if (P.bias) x += P.bias[row0 + r];
                     x = apply_act(P.act, x);
-                    if (P.post == POST_MUL) x *= P.m0[(long)t * P.ldm + row0 + r];
-                    else if (P.post == POST_MIX)
-                        x = P.m0[(long)t * P.ldm + row0 + r] + P.m1[(long)t * P.ldm + row0 + r] * x;
                     v[r] = x;
                 }
-                if (P.out_f32) {
-                    float *o = P.out_f32 + (long)kb * P.partial_stride + (long)t * P.ldo + row0;
-                    *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
+                if (P.post == POST_MUL) {
+                    const float4 m = act_ld4(bm0, (long)t * P.ldm + row0);
+                    v[0] *= m.x; v[1] *= m.y; v[2] *= m.z; v[3] *= m.w;
+                } else if (P.post == POST_MIX) {
+                    const float4 m = act_ld4(bm0, (long)t * P.ldm + row0), n = act_ld4(bm1, (long)t * P.ldm + row0);
+                    v[0] = m.x + n.x * v[0]; v[1] = m.y + n.y * v[1]; v[2] = m.z + n.z * v[2]; v[3] = m.w + n.w * v[3];
                 }
-                if (P.out_hi) {
-                    f16x4 h, l;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { _Float16 a, b; split_hilo(v[r], a, b); h[r] = a; l[r] = b; }
-                    const long oo = opd_off(t, row0, P.ldh);
-                    *(f16x4 *)(P.out_hi + oo) = h;
-                    if (P.out_lo) *(f16x4 *)(P.out_lo + oo) = l;
-                }
+                if (P.out_f32) act_st4(bo32, (long)t * P.ldo + row0, make_float4(v[0], v[1], v[2], v[3]));
+                if (P.out_hi) act_store_operand4(boh, bol, P.out_lo != nullptr, opd_off(t, row0, P.ldh), make_float4(v[0], v[1], v[2], v[3]));
             }
         }
         if (t0 + NT * 16 < L.T) __syncthreads();
     }
+    dep_signal(L.dep);
     TRACE_PT(4);
 }
 
@@ -674,7 +758,9 @@ template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, bool LNP>
 __global__ __launch_bounds__(((KSW == 16 || NT == 4) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES) * 64) void gemm_kernel(const GemmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x >= L.total_blocks) {                      // the extra block of a launch that carries a commit
+        dep_wait(L.dep);                                          // every block of the prologue launch has read the old state
         shift_commit(L.commit);
+        dep_signal(L.dep);
         return;
     }
     int pi = 0;
@@ -763,6 +849,24 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
 #pragma unroll
     for (int ks = 0; ks < DS / 2; ++ks) w2t[ks] = ((const u32x4 *)a.W2[c])[((long)strip_c * (DS / 2) + ks) * 64 + lane];
     const float4 mu = *(const float4 *)(a.mu[c] + row0);
+    // phase-1 weights of the first batch of k-steps: W1 is a constant too, so its tiles are also in flight before the wait
+    const u32x4 *w1 = (const u32x4 *)a.W1;
+    constexpr int KB = DS == 2 ? ((HILO && NT == 2) ? 5 : 10) : 4;                                          // k-steps per batch: all loads of a batch in flight at once
+    u32x4 wt[KB][DS];
+    auto load_w1 = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            if (k0 + j < kst) {                                    // wave-uniform
+                const int kt = wave * kst + k0 + j;
+#pragma unroll
+                for (int d = 0; d < DS; ++d) wt[j][d] = w1[((long)(c * DS + d) * KT1 + kt) * 64 + lane];
+            }
+        }
+    };
+    load_w1(0);
+    dep_wait(a.dep);                                              // everything above is independent of the previous launch
+    const act_t bxx = act_buf(a.xx), bdx = act_buf(a.dx), bzh = act_buf(a.zhi), bzl = act_buf(a.zlo);
+    const act_t boh = act_buf(a.ohi[c]), bol = act_buf(a.olo[c]);
     // LNP (single-token steps): LayerNorm + token shift are redone here by every block (ln_prologue_*): z arrives in LDS in
     // fragment order, xx and dx for the epilogue come from the prologue's LDS rows
     float *xx_l = (float *)(m_lo + NT * 16 * mstride);
@@ -788,8 +892,8 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
             int t = nt * 16 + (lane & 15);
             t = t < T ? t : T - 1;
-            xxv[nt] = *(const float4 *)(a.xx + (long)t * C + row0);
-            dxv[nt] = *(const float4 *)(a.dx + (long)t * C + row0);
+            xxv[nt] = act_ld4(bxx, (long)t * C + row0);
+            dxv[nt] = act_ld4(bdx, (long)t * C + row0);
         }
     }
     // ---- phase 1: partial m_c over this wave's K slice
@@ -798,11 +902,9 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     for (int d = 0; d < DS; ++d)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[d][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const u32x4 *w1 = (const u32x4 *)a.W1;
-    constexpr int KB = DS == 2 ? ((HILO && NT == 2) ? 5 : 10) : 4;                                          // k-steps per batch: all loads of a batch in flight at once
     for (int k0 = 0; k0 < kst; k0 += KB) {
         f16x8 zb[KB][NT], zl[HILO ? KB : 1][HILO ? NT : 1];
-        u32x4 wt[KB][DS];
+        if (k0 > 0) load_w1(k0);
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             if (k0 + j < kst) {                                    // wave-uniform
@@ -816,12 +918,10 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
                         if constexpr (HILO) zl[j][nt] = *(const f16x8 *)(z_l + (size_t)T * C + lnp_op_off(T, kt * 32 + (lane >> 4) * 8, tl));
                     } else {
                         const long zo = ((long)tile * (a.ldz >> 5) + kt) * 512 + ((lane >> 4) * 16 + tl) * 8;
-                        zb[j][nt] = *(const f16x8 *)(a.zhi + zo);
-                        if constexpr (HILO) zl[j][nt] = *(const f16x8 *)(a.zlo + zo);
+                        zb[j][nt] = act_ldh8(bzh, zo);
+                        if constexpr (HILO) zl[j][nt] = act_ldh8(bzl, zo);
                     }
                 }
-#pragma unroll
-                for (int d = 0; d < DS; ++d) wt[j][d] = w1[((long)(c * DS + d) * KT1 + kt) * 64 + lane];
             }
         }
 #pragma unroll
@@ -885,10 +985,11 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
                 r.y = xx.y + dx.y * (mu.y + o[nt][1]);
                 r.z = xx.z + dx.z * (mu.z + o[nt][2]);
                 r.w = xx.w + dx.w * (mu.w + o[nt][3]);
-                store_operand4(a.ohi[c], a.olo[c], opd_off(t, row0, a.ldh), r);
+                act_store_operand4(boh, bol, a.olo[c] != nullptr, opd_off(t, row0, a.ldh), r);
             }
         }
     }
+    dep_signal(a.dep);
     TRACE_K(0, 4);
 }
 
@@ -1268,14 +1369,14 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *(const float4 *)
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 template <int PT>
-__device__ __forceinline__ void row_load_sum(const float *__restrict__ x_in, const float *__restrict__ P, int np, long pstride,
+__device__ __forceinline__ void row_load_sum(act_t x_in, act_t P, int np, long pstride,
                                              int row, int C, float4 (&v)[PT]) {
     constexpr int MAXNP = 8;                                       // all loads in flight at once, summed in fixed order
     float4 pp[MAXNP][PT];
-    ROW_FOR(i, c) v[i] = ld4(x_in + (long)row * C + c);
+    ROW_FOR(i, c) v[i] = act_ld4(x_in, (long)row * C + c);
 #pragma unroll
     for (int j = 0; j < MAXNP; ++j) {
-        if (j < np) { ROW_FOR(i, c) pp[j][i] = ld4(P + j * pstride + (long)row * C + c); }
+        if (j < np) { ROW_FOR(i, c) pp[j][i] = act_ld4(P, j * pstride + (long)row * C + c); }
     }
 #pragma unroll
     for (int j = 0; j < MAXNP; ++j) {
@@ -1328,11 +1429,14 @@ __global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
     const int slot = a.rm.slot[t], prev = a.rm.prev[t], last = a.rm.last[t];
     float *__restrict__ sx = a.sx + (long)slot * a.sx_slot_stride;
     float4 xv[PT], pv[PT];
-    row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, t, C, xv);
-    if (prev >= 0) row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, prev, C, pv);
-    else { ROW_FOR(i, c) pv[i] = ld4(sx + c); }
+    // the token-shift state was written by the previous STEP (a real graph boundary): it is fetched before the wait too
+    if (prev < 0) { ROW_FOR(i, c) pv[i] = ld4(sx + c); }
+    dep_wait(a.dep);
+    const act_t bx = act_buf(a.x_in), bP = act_buf(a.P), bxo = act_buf(a.x_out), bxx = act_buf(a.xx_out), bdx = act_buf(a.dx_out);
+    row_load_sum<PT>(bx, bP, a.np, a.pstride, t, C, xv);
+    if (prev >= 0) row_load_sum<PT>(bx, bP, a.np, a.pstride, prev, C, pv);
     TRACE_K(2, 1);
-    if (a.x_out) { ROW_FOR(i, c) *(float4 *)(a.x_out + (long)t * C + c) = xv[i]; }
+    if (a.x_out) { ROW_FOR(i, c) act_st4(bxo, (long)t * C + c, xv[i]); }
     row_layernorm<PT>(xv, C, wv, bv, red);
     TRACE_K(2, 2);
     if (prev >= 0) row_layernorm<PT>(pv, C, wv, bv, red);
@@ -1341,20 +1445,20 @@ __global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
             ROW_FOR(i, c) *(float4 *)(sx + c) = xv[i];
         } else {
             float4 lv[PT];
-            row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, last, C, lv);
+            row_load_sum<PT>(bx, bP, a.np, a.pstride, last, C, lv);
             row_layernorm<PT>(lv, C, wv, bv, red);
             ROW_FOR(i, c) *(float4 *)(sx + c) = lv[i];
         }
     }
     float4 dxv[PT];
     ROW_FOR(i, c) dxv[i] = make_float4(pv[i].x - xv[i].x, pv[i].y - xv[i].y, pv[i].z - xv[i].z, pv[i].w - xv[i].w);
-    if (a.xx_out) { ROW_FOR(i, c) *(float4 *)(a.xx_out + (long)t * C + c) = xv[i]; }
-    if (a.dx_out) { ROW_FOR(i, c) *(float4 *)(a.dx_out + (long)t * C + c) = dxv[i]; }
+    if (a.xx_out) { ROW_FOR(i, c) act_st4(bxx, (long)t * C + c, xv[i]); }
+    if (a.dx_out) { ROW_FOR(i, c) act_st4(bdx, (long)t * C + c, dxv[i]); }
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
         if (m < a.nmix) {
-            _Float16 *__restrict__ oh = a.ohi[m];
-            _Float16 *__restrict__ ol = a.olo[m];
+            const act_t oh = act_buf(a.ohi[m]), ol = act_buf(a.olo[m]);
+            const bool has_lo = a.olo[m] != nullptr;
             float4 muv[PT];
             if (m == 0) { ROW_FOR(i, c) muv[i] = mu0[i]; }
             else if (m == 1) { ROW_FOR(i, c) muv[i] = mu1[i]; }
@@ -1372,10 +1476,11 @@ __global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
                     o.z = xv[i].z + dxv[i].z * muv[i].z;
                     o.w = xv[i].w + dxv[i].w * muv[i].w;
                 }
-                store_operand4(oh, ol, opd_off(t, c, a.ldh), o);
+                act_store_operand4(oh, ol, has_lo, opd_off(t, c, a.ldh), o);
             }
         }
     }
+    dep_signal(a.dep);
     TRACE_K(2, 3);
 }
 #define ROW_DISPATCH(KERN, C_, GRID, ...)                                                          \
@@ -1402,7 +1507,10 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
         v[i] = make_float4((float)e[0], (float)e[1], (float)e[2], (float)e[3]);
     }
     row_layernorm<PT>(v, C, wv, bv, red);
-    ROW_FOR(i, c) *(float4 *)(a.x + (long)t * C + c) = v[i];
+    dep_wait(a.dep);                                               // the previous launch may still read the residual buffer
+    const act_t bx = act_buf(a.x);
+    ROW_FOR(i, c) act_st4(bx, (long)t * C + c, v[i]);
+    dep_signal(a.dep);
 }
 void launch_embed(const EmbedArgs &a, int T, hipStream_t s) { ROW_DISPATCH(embed_kernel, a.C, T, a); }
 
@@ -1414,9 +1522,12 @@ __global__ __launch_bounds__(256) void ln_out_kernel(const LnOutArgs a) {
     ROW_FOR(i, c) { wv[i] = ld4(a.lnw + c); bv[i] = ld4(a.lnb + c); }
     const int t = a.out_rows[o];
     float4 v[PT];
-    row_load_sum<PT>(a.x_in, a.P, a.np, a.pstride, t, C, v);
+    dep_wait(a.dep);
+    row_load_sum<PT>(act_buf(a.x_in), act_buf(a.P), a.np, a.pstride, t, C, v);
     row_layernorm<PT>(v, C, wv, bv, red);
-    ROW_FOR(i, c) store_operand4(a.ohi, a.olo, opd_off(o, c, a.ldh), v[i]);
+    const act_t oh = act_buf(a.ohi), ol = act_buf(a.olo);
+    ROW_FOR(i, c) act_store_operand4(oh, ol, a.olo != nullptr, opd_off(o, c, a.ldh), v[i]);
+    dep_signal(a.dep);
 }
 void launch_ln_out(const LnOutArgs &a, int n_out, hipStream_t s) { ROW_DISPATCH(ln_out_kernel, a.C, n_out, a); }
 
@@ -1461,6 +1572,11 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
     const int ch = tid >> 2, part = tid & 3;                 // v6 decay LoRA: 4 threads per channel
     const int per = a.Dd >> 2;
     const float decay0 = a.version == 6 ? a.wdec_or_decay[cb + ch] : 0.f;
+    // state, parameters: in flight; now the projections of the previous launch
+    dep_wait(a.dep);
+    const act_t br = act_buf(a.r), bk = act_buf(a.k), bv = act_buf(a.v), bg = act_buf(a.g), btd = act_buf(a.td);
+    const act_t ba7 = act_buf(a.a7), bw7 = act_buf(a.w7), bvg7 = act_buf(a.vg7), bvf = act_buf(a.v_first);
+    const act_t byh = act_buf(a.yhi), byl = act_buf(a.ylo);
 
     for (int it = 0; it < nrow; ++it) {
         const int t = row0 + it;
@@ -1469,19 +1585,19 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
         float dsum = 0.f;
         // ---- issue every global load of this token before the first barrier
         if (tid < 64) {
-            r = a.r[rb + tid]; k = a.k[rb + tid]; v = a.v[rb + tid]; gt = a.g[rb + tid];
+            r = act_ld1(br, rb + tid); k = act_ld1(bk, rb + tid); v = act_ld1(bv, rb + tid); gt = act_ld1(bg, rb + tid);
             if (a.version == 7) {
-                av = a.a7[rb + tid]; w7 = a.w7[rb + tid];
-                if (a.layer != 0) { vg = a.vg7[rb + tid]; vf = a.v_first[rb + tid]; }
+                av = act_ld1(ba7, rb + tid); w7 = act_ld1(bw7, rb + tid);
+                if (a.layer != 0) { vg = act_ld1(bvg7, rb + tid); vf = act_ld1(bvf, rb + tid); }
             }
         }
         if (a.version == 6) {
             // decay LoRA stage 2: d_c = time_decay_c + sum_d D2[c][d] td[d];  w = exp(-exp(d))
             const _Float16 *d2 = a.D2 + (long)(cb + ch) * a.Dd + part * per;
-            const float *tdp = a.td + (long)t * a.Dd + part * per;
+            const long tdo = (long)t * a.Dd + part * per;
             for (int d = 0; d < per; d += 8) {
                 const f16x8 wv = *(const f16x8 *)(d2 + d);
-                const float4 t0v = *(const float4 *)(tdp + d), t1v = *(const float4 *)(tdp + d + 4);
+                const float4 t0v = act_ld4(btd, tdo + d), t1v = act_ld4(btd, tdo + d + 4);
                 dsum += (float)wv[0] * t0v.x + (float)wv[1] * t0v.y + (float)wv[2] * t0v.z + (float)wv[3] * t0v.w +
                         (float)wv[4] * t1v.x + (float)wv[5] * t1v.y + (float)wv[6] * t1v.z + (float)wv[7] * t1v.w;
             }
@@ -1496,7 +1612,7 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
                 const float ss = wave_sum(kk * kk);        // tid<64 == wave 0: L2 norm over the head
                 kk = kk / fmaxf(sqrtf(ss), 1e-12f);
                 k = k * (1.0f + (av - 1.0f) * ka_p);
-                if (a.layer == 0) a.v_first[rb + tid] = v;
+                if (a.layer == 0) act_st1(bvf, rb + tid, v);
                 else v = v + (vf - v) * vg;
                 sh_kk[tid] = -kk;                          // -kappa
                 sh_ka[tid] = kk * av;                      // kappa * a
@@ -1560,14 +1676,21 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
             y *= gt;
             _Float16 hh, ll;
             split_hilo(y, hh, ll);
-            const long yo = opd_off(t, cb + tid, a.ldh);
-            a.yhi[yo] = hh;
-            if (a.ylo) a.ylo[yo] = ll;
+            // 2-byte write-through stores would each be a fabric write: lanes pair up, the even lane stores both halves (4 B)
+            const unsigned hb = __builtin_bit_cast(unsigned short, hh), lb = __builtin_bit_cast(unsigned short, ll);
+            const unsigned hn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hb, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+            const unsigned ln2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lb, 0xB1, 0xf, 0xf, true);
+            if ((tid & 1) == 0) {
+                const long yo = opd_off(t, cb + tid, a.ldh);     // channels tid, tid+1 are adjacent halfs of one 16-byte piece
+                __builtin_amdgcn_raw_buffer_store_b32(hb | (hn << 16), byh, (unsigned)(yo * 2), 0, ACT_SC1);
+                if (a.ylo) __builtin_amdgcn_raw_buffer_store_b32(lb | (ln2 << 16), byl, (unsigned)(yo * 2), 0, ACT_SC1);
+            }
         }
     }
     TRACE_K(1, 4);
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, T[aa]), (f32x4 *)(st + (aa * 16 + ig) * 64 + jg * 4));
+    dep_signal(a.dep);
     TRACE_K(1, 5);
 }
 
@@ -1605,9 +1728,14 @@ __device__ __forceinline__ float wkv_decay_dot(const f16x8 (&d2r)[DD / 8], const
 template <int VER, int DD>
 __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
     __shared__ __attribute__((aligned(16))) float s_r[WKV_CH][64], s_k[WKV_CH][64], s_v[WKV_CH][64], s_w[WKV_CH][64];
-    __shared__ __attribute__((aligned(16))) float s_kk[WKV_CH][64], s_ka[WKV_CH][64], s_o[WKV_CH][64];
+    // kappa rows ([0]) and kappa*a rows ([1]) of V7 in ONE array: V6 reuses the pair as the chunk's td rows [WKV_CH][Dd], which
+    // for Dd = 128 (7B) needs both halves back to back — two separate arrays are not guaranteed to be adjacent in LDS
+    __shared__ __attribute__((aligned(16))) float s_kka[2][WKV_CH][64], s_o[WKV_CH][64];
     __shared__ __attribute__((aligned(16))) float s_u[64];
-    float *s_td = &s_kk[0][0];                           // V6: td rows of the chunk [WKV_CH][Dd] (s_kk + s_ka are V7-only)
+    float (&s_kk)[WKV_CH][64] = s_kka[0];
+    float (&s_ka)[WKV_CH][64] = s_kka[1];
+    static_assert(DD <= 128, "td rows of a chunk must fit s_kka");
+    float *s_td = &s_kka[0][0][0];                       // V6: td rows of the chunk [WKV_CH][Dd]
     const int seq = blockIdx.x, h = blockIdx.y;
     const int tid = threadIdx.x, ig = tid >> 4, jg = tid & 15, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

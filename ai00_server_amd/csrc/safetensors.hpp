@@ -76,6 +76,15 @@ class SafeTensors {
                 t.nbytes = (size_t)(o1 - o0);
                 size_t es = t.dtype == "F32" ? 4 : (t.dtype == "F16" || t.dtype == "BF16") ? 2 : 0;
                 if (es == 0) throw std::runtime_error("safetensors: unsupported dtype " + t.dtype);
+                {   // dims come from the file: non-negative, and their product must not wrap before it is compared
+                    uint64_t prod = 1;
+                    for (auto d : t.shape) {
+                        if (d < 0 || (d != 0 && prod > (uint64_t)1 << 46) || (uint64_t)d > ((uint64_t)1 << 46))
+                            throw std::runtime_error("safetensors: bad shape for '" + name + "'");
+                        prod *= (uint64_t)d;
+                        if (prod > ((uint64_t)1 << 46)) throw std::runtime_error("safetensors: bad shape for '" + name + "'");
+                    }
+                }
                 if ((size_t)t.numel() * es != t.nbytes)
                     throw std::runtime_error("safetensors: size mismatch for '" + name + "'");
                 st.tensors.emplace(std::move(name), std::move(t));

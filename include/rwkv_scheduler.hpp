@@ -37,13 +37,13 @@ struct CachedItem {                              // run.rs:201-223
 
 class PrefixCache {                              // `Trie<Tokens, CachedItem>` keyed by whole token sequences
    public:
-    explicit PrefixCache(size_t max_cached = 64) : max_cached_(max_cached) {}
+    explicit PrefixCache(size_t max_cached = 256) : max_cached_(max_cached) {}      // MAX_CACHE_ITEMS, run.rs:41
     struct Checkout { size_t prefix_len = 0; std::vector<float> state, output; bool hit = false; };
     // longest cached key that is a prefix of `tokens` (run.rs:447-455); refreshes the item's stamp (CachedItem::update)
     Checkout checkout(const Tokens &tokens, uint64_t now) {
         Checkout c;
-        const Node *n = &root_;
-        const Node *best = nullptr;
+        Node *n = &root_;
+        Node *best = nullptr;
         size_t best_len = 0;
         for (size_t i = 0; i < tokens.size(); ++i) {
             auto it = n->next.find(tokens[i]);
@@ -52,38 +52,70 @@ class PrefixCache {                              // `Trie<Tokens, CachedItem>` k
             if (n->item) { best = n; best_len = i + 1; }
         }
         if (best) {
-            best->item->stamp = now;
+            touch(best, now);
             c.prefix_len = best_len; c.state = best->item->state; c.output = best->item->output; c.hit = true;
         }
         return c;
+    }
+    bool contains(const Tokens &tokens) const {                                     // `cache.contains_key`, run.rs:795
+        const Node *n = &root_;
+        for (uint32_t t : tokens) {
+            auto it = n->next.find(t);
+            if (it == n->next.end()) return false;
+            n = it->second.get();
+        }
+        return n != &root_ && n->item != nullptr;
     }
     void insert(const Tokens &tokens, std::vector<float> state, std::vector<float> output, uint64_t now) {
         if (tokens.empty()) return;
         Node *n = &root_;
         for (uint32_t t : tokens) {
             auto &slot = n->next[t];
-            if (!slot) slot.reset(new Node());
+            if (!slot) { slot.reset(new Node()); slot->parent = n; slot->tok = t; }
             n = slot.get();
         }
-        if (!n->item) { n->item.reset(new CachedItem()); ++count_; }
-        n->item->state = std::move(state); n->item->output = std::move(output); n->item->stamp = now;
-        while (count_ > max_cached_) evict_oldest();
+        if (!n->item) { n->item.reset(new CachedItem()); ++count_; n->item->stamp = now; n->age = by_age_.emplace(now, n); }
+        n->item->state = std::move(state); n->item->output = std::move(output);
+        touch(n, now);
+        while (count_ > max_cached_) evict_oldest();                                // `Cache::maintain`, run.rs:237-257
     }
     size_t size() const { return count_; }
+    size_t nodes() const { return count_nodes(&root_) - 1; }                        // trie nodes alive (tests: eviction prunes)
 
    private:
-    struct Node { std::map<uint32_t, std::unique_ptr<Node>> next; std::unique_ptr<CachedItem> item; };
-    static void oldest(Node *n, Node *&arg, uint64_t &stamp) {
-        if (n->item && n->item->stamp < stamp) { stamp = n->item->stamp; arg = n; }
-        for (auto &kv : n->next) oldest(kv.second.get(), arg, stamp);
+    struct Node {
+        std::map<uint32_t, std::unique_ptr<Node>> next;
+        std::unique_ptr<CachedItem> item;
+        Node *parent = nullptr;
+        uint32_t tok = 0;
+        std::multimap<uint64_t, Node *>::iterator age;                              // valid while `item` is set
+    };
+    static size_t count_nodes(const Node *n) {
+        size_t c = 1;
+        for (auto &kv : n->next) c += count_nodes(kv.second.get());
+        return c;
     }
+    void touch(Node *n, uint64_t now) {
+        by_age_.erase(n->age);
+        n->item->stamp = now;
+        n->age = by_age_.emplace(now, n);
+    }
+    // the oldest item goes, and with it every trie node that now leads nowhere: the cache of a long-running server holds at most
+    // `max_cached` items AND at most the nodes on their key paths (an item-only eviction would leak one node per token ever cached)
     void evict_oldest() {
-        Node *arg = nullptr;
-        uint64_t stamp = ~0ull;
-        oldest(&root_, arg, stamp);
-        if (arg) { arg->item.reset(); --count_; }
+        if (by_age_.empty()) return;
+        Node *n = by_age_.begin()->second;
+        by_age_.erase(by_age_.begin());
+        n->item.reset();
+        --count_;
+        while (n != &root_ && !n->item && n->next.empty()) {
+            Node *parent = n->parent;
+            parent->next.erase(n->tok);                                             // destroys n
+            n = parent;
+        }
     }
     Node root_;
+    std::multimap<uint64_t, Node *> by_age_;                                       // stamp -> node: eviction is O(log n), not a trie walk
     size_t count_ = 0, max_cached_;
 };
 
@@ -115,9 +147,12 @@ class Scheduler {
         std::vector<float> output;               // logits after the last consumed token (empty until one exists)
         RnnOption option = RnnOption::Last;
         std::vector<std::vector<float>> rows;    // Full: one entry per emitted row
+        size_t prompt_len = 0;                   // tokens of the request as queued (the "prompt", run.rs:794)
+        bool cache_prompt = false;               // CachedPrompt::Future: cache the state when the prompt has been consumed
     };
 
-    explicit Scheduler(Engine &e, size_t max_cached = 64) : e_(e), slots_(e.max_batch), reqs_(e.max_batch), cache_(max_cached) {}
+    static constexpr size_t kMinPromptCacheTokens = 32;                          // MIN_PROMPT_CACHE_TOKENS, run.rs:40
+    explicit Scheduler(Engine &e, size_t max_cached = 256) : e_(e), slots_(e.max_batch), reqs_(e.max_batch), cache_(max_cached) {}
 
     // run.rs:488-626.  On Success / Fault `batch` is the slot now Busy with the request.
     SlotResult queue(Tokens tokens, int &batch, RnnOption option = RnnOption::Last) {
@@ -143,9 +178,9 @@ class Scheduler {
         batch = best.batch;
         // check the state out of the cache (longest cached prefix, else the initial state) and load it into the slot.
         // (The reference does this for all three choices, Continue included: run.rs:548-626.)
+        // A request that is cached whole starts with an empty suffix and the cached output row: the process loop samples from
+        // it without touching the engine (`(0, Some(output)) => output`, run.rs:809-811).
         PrefixCache::Checkout co = cache_.checkout(tokens, clock_);
-        if (co.hit && co.prefix_len == tokens.size())     // the whole request is cached: replay its last token so that the
-            co = cache_.checkout(Tokens(tokens.begin(), tokens.end() - 1), clock_);   // output row comes from the engine
         const size_t len = co.hit ? co.prefix_len : 0;
         if (co.hit) e_.state.load(co.state, batch);
         else e_.state.load(e_.state.init(), batch);
@@ -154,6 +189,10 @@ class Scheduler {
         r.suffix.assign(tokens.begin() + (long)len, tokens.end());
         r.output = co.hit ? co.output : std::vector<float>();
         r.option = option;
+        r.prompt_len = tokens.size();
+        // run.rs:794-803: prompts longer than MIN_PROMPT_CACHE_TOKENS that are not cached yet get a cache entry as soon as
+        // they have been read in (so a second request with the same long prompt skips its prefill even while this one decodes)
+        r.cache_prompt = tokens.size() > kMinPromptCacheTokens && !cache_.contains(tokens);
         reqs_[batch] = std::move(r);
         const bool back = best.kind == SlotChoice::Back;
         slots_[batch].kind = SlotKind::Busy;
@@ -192,6 +231,10 @@ class Scheduler {
                 std::vector<float> lg(out[b].begin() + (long)(row * V), out[b].begin() + (long)((row + 1) * V));
                 if (r.option == RnnOption::Full) r.rows.push_back(lg);
                 r.output = std::move(lg);
+            }
+            if (r.cache_prompt && r.suffix.empty() && r.prefix.size() == r.prompt_len && !r.output.empty()) {   // run.rs:829-838
+                cache_.insert(r.prefix, e_.state.back((int)b), r.output, ++clock_);
+                r.cache_prompt = false;
             }
         }
         return riders;

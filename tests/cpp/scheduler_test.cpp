@@ -99,12 +99,12 @@ int main() {
         CHECK(e.calls - calls0 == 1);                                    // only the 3 new tokens were fed
         CHECK(s.request(b2).output == want);
         s.finish(b2);
-        // the whole request cached: one token is replayed, same answer
+        // the whole request cached: nothing is fed, the cached output row is the answer (run.rs:809-811)
         int b3 = -1;
+        const int calls1 = e.calls;
         CHECK(s.queue(full, b3) != SlotResult::Failure);
-        CHECK(s.request(b3).suffix.size() == 1 || s.request(b3).suffix.size() == 3);
-        while (s.pending()) s.step();
-        CHECK(s.request(b3).output == want);
+        CHECK(s.request(b3).suffix.empty() && s.request(b3).prefix == full && !s.pending());
+        CHECK(s.request(b3).output == want && e.calls == calls1);
         s.finish(b3);
     }
     // --- continuous batching: a request queued while another is mid-flight rides the very next step
@@ -133,6 +133,42 @@ int main() {
         (void)c.checkout({1, 7}, 3);                                     // refreshes {1}
         c.insert({3}, {3.f}, {3.f}, 4);                                  // evicts {2}
         CHECK(c.size() == 2 && c.checkout({2}, 5).hit == false && c.checkout({1}, 6).hit && c.checkout({3}, 7).hit);
+    }
+    // --- eviction prunes the trie: after thousands of long keys through a 4-item cache only the live key paths remain
+    {
+        PrefixCache c(4);
+        for (uint32_t i = 0; i < 2000; ++i) {
+            Tokens k(100, i + 1);                                        // 100 tokens per key, disjoint paths
+            k.back() = 7;
+            c.insert(k, {1.f}, {1.f}, i + 1);
+        }
+        CHECK(c.size() == 4 && c.nodes() == 4 * 100);
+        Tokens shared(50, 9u), a = shared, b = shared;
+        a.push_back(1); b.push_back(2);
+        c.insert(a, {1.f}, {1.f}, 5000); c.insert(b, {1.f}, {1.f}, 5001);
+        c.insert({3}, {1.f}, {1.f}, 5002); c.insert({4}, {1.f}, {1.f}, 5003);   // pushes the four old keys out
+        CHECK(c.size() == 4 && c.nodes() == 50 + 2 + 2);                 // the shared stem is kept once
+        c.insert({5}, {1.f}, {1.f}, 5004);                               // evicts `a`: its leaf goes, the stem stays for `b`
+        CHECK(!c.contains(a) && c.contains(b) && c.nodes() == 50 + 1 + 3);
+    }
+    // --- prompts longer than MIN_PROMPT_CACHE_TOKENS (32) are cached when they have been read in (run.rs:794-838), short ones
+    //     only at finish; a second request with the same long prompt skips its prefill while the first one still decodes
+    {
+        FakeEngine e(2, 16);
+        Scheduler<FakeEngine> s(e);
+        Tokens longp(40, 5u), shortp(8, 6u);
+        int a = -1, b = -1;
+        CHECK(s.queue(longp, a) == SlotResult::Success);
+        CHECK(s.queue(shortp, b) == SlotResult::Success);
+        while (s.pending()) s.step();
+        CHECK(s.cache().size() == 1 && s.cache().contains(longp) && !s.cache().contains(shortp));
+        s.push(a, 9);                                                    // a keeps decoding
+        s.step();
+        s.finish(b);
+        CHECK(s.cache().size() == 2);
+        int c2 = -1;
+        CHECK(s.queue(longp, c2) != SlotResult::Failure && c2 == b);
+        CHECK(s.request(c2).prefix.size() == 40 && s.request(c2).suffix.empty() && !s.request(c2).output.empty());   // no prefill at all
     }
     std::printf("scheduler_test: ok\n");
     return 0;
