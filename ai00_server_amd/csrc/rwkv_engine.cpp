@@ -216,6 +216,7 @@ struct LayerW {
 };
 
 struct StepPlan {
+    bool dense = false;             // slots 0..T-1 active with one token each, every row emitted: row index == slot index
     int T = 0, n_seq = 0, n_out = 0;
     std::vector<int> token, slot, prev, last, seq_slot, seq_begin, seq_len, out_rows;
     std::vector<int> slot_consumed, slot_out_begin, slot_out_rows;   // per slot
@@ -363,7 +364,7 @@ struct rwkv_engine {
     float *lnp_xx_att = nullptr, *lnp_xx_ffn = nullptr;   // normalised rows published by an LN-prologue launch (for the commit)
     void plan_step(const rwkv_slot_input *in, StepPlan &pl);
     void upload_plan(const StepPlan &pl);
-    void run_layers(int T, int n_seq, int n_out, const int *d_token);
+    void run_layers(int T, int n_seq, int n_out, const int *d_token, bool dense);
     void infer(const rwkv_slot_input *in, rwkv_slot_output *out);
     void run_plan(const StepPlan &pl);
     void infer_sample(const rwkv_slot_input *in, const rwkv_sample_params *sp, uint32_t *out_tokens, float *out_probs,
@@ -944,18 +945,22 @@ void rwkv_engine::plan_step(const rwkv_slot_input *in, StepPlan &pl) {
             pl.slot.push_back(b);
             pl.prev.push_back(i == 0 ? -1 : begin + i - 1);
             pl.last.push_back(i == 0 ? begin + n - 1 : -1);
-            if (in[b].option == RWKV_OPTION_FULL || (exhausted && i == n - 1)) pl.out_rows.push_back(begin + i);
+            if (in[b].option == RWKV_OPTION_FULL || (in[b].option == RWKV_OPTION_LAST && exhausted && i == n - 1)) pl.out_rows.push_back(begin + i);
         }
         pl.slot_out_rows[b] = (int)pl.out_rows.size() - pl.slot_out_begin[b];
     }
     pl.T = (int)pl.token.size();
     pl.n_seq = (int)pl.seq_slot.size();
     pl.n_out = (int)pl.out_rows.size();
+    static const int no_dense = std::getenv("RWKV_NO_DENSE") ? std::atoi(std::getenv("RWKV_NO_DENSE")) : 0;   // A/B switch
+    pl.dense = !no_dense && pl.T > 0 && pl.n_seq == pl.T && pl.n_out == pl.T;
+    for (int i = 0; i < pl.n_seq && pl.dense; ++i) pl.dense = pl.seq_slot[i] == i;
 }
 
 // meta layout in d_meta: token[chunk] slot[chunk] prev[chunk] last[chunk] out_rows[chunk] seq_slot[B] seq_begin[B] seq_len[B]
 RowMeta rwkv_engine::meta_ptrs(int) const {
     RowMeta rm;
+    rm.dense = 0;
     rm.token = d_meta;
     rm.slot = d_meta + chunk;
     rm.prev = d_meta + 2 * chunk;
@@ -979,10 +984,11 @@ void rwkv_engine::upload_plan(const StepPlan &pl) {
 // ------------------------------------------------------------------------------------------------
 // the forward pass: enqueue every kernel of one step on s_main
 // ------------------------------------------------------------------------------------------------
-void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token) {
+void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bool dense) {
     const int C = info.num_emb, V = info.num_vocab, H = info.num_head, L = info.num_layer;
     RowMeta rm = meta_ptrs(T);
     rm.token = d_token;
+    rm.dense = dense ? 1 : 0;
     const int *seq_slot = d_meta + 5 * chunk, *seq_begin = seq_slot + max_batch, *seq_len = seq_begin + max_batch;
     const int *out_rows = d_meta + 4 * chunk;
 
@@ -1098,7 +1104,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token) {
         {
             WkvArgs k{};
             k.version = info.version; k.H = H; k.C = C; k.n_seq = n_seq;
-            k.seq_slot = seq_slot; k.seq_begin = seq_begin; k.seq_len = seq_len;
+            k.seq_slot = seq_slot; k.seq_begin = seq_begin; k.seq_len = seq_len; k.dense = dense ? 1 : 0;
             k.state = wkv + (long)l * H * 4096; k.slot_stride = wkv_slot_stride;
             k.r = fr; k.k = fk; k.v = fv; k.g = fg;
             k.wdec_or_decay = w.wdec; k.u = w.u; k.td = ftd; k.D2 = w.D2; k.Dd = Dd;
@@ -1149,7 +1155,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token) {
         }
     }
     if (n_out > 0) {
-        LnOutArgs o{cur, P, np, pstride, lnow, lnob, out_rows, opO.hi, opO.lo, C, C};
+        LnOutArgs o{cur, P, np, pstride, lnow, lnob, dense ? nullptr : out_rows, opO.hi, opO.lo, C, C};
         launch(FAM_ROW, [&] { launch_ln_out(o, n_out, s_main); });
         std::vector<ProbSpec> ps(1);
         ps[0].W = head; ps[0].x = opO; ps[0].out = logits; ps[0].ldo = V;
@@ -1162,21 +1168,21 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token) {
 // upload the row metadata and enqueue the step (graph replay when this shape was seen before)
 void rwkv_engine::run_plan(const StepPlan &pl) {
     upload_plan(pl);
-    const uint64_t key = ((uint64_t)pl.T << 40) | ((uint64_t)pl.n_seq << 20) | (uint64_t)pl.n_out;
+    const uint64_t key = ((uint64_t)pl.dense << 63) | ((uint64_t)pl.T << 40) | ((uint64_t)pl.n_seq << 20) | (uint64_t)pl.n_out;
     if (use_graphs && !profiling) {
         auto it = graphs.find(key);
         // a shape is captured the SECOND time it shows up: decode-shaped steps repeat at once, while the one-off shapes of
         // prefill tails would pay capture + instantiation (milliseconds) for a single replay and churn the cache
         if (it == graphs.end() && graph_seen.insert(key).second) {
             if (graph_seen.size() > 4096) graph_seen.clear();
-            run_layers(pl.T, pl.n_seq, pl.n_out, d_meta);
+            run_layers(pl.T, pl.n_seq, pl.n_out, d_meta, pl.dense);
             return;
         }
         if (it == graphs.end()) {
             hipGraph_t g = nullptr;
             HIP_CHECK(hipStreamBeginCapture(s_main, hipStreamCaptureModeThreadLocal));
             try {
-                run_layers(pl.T, pl.n_seq, pl.n_out, d_meta);
+                run_layers(pl.T, pl.n_seq, pl.n_out, d_meta, pl.dense);
             } catch (...) {
                 (void)hipStreamEndCapture(s_main, &g);
                 if (g) (void)hipGraphDestroy(g);
@@ -1194,7 +1200,7 @@ void rwkv_engine::run_plan(const StepPlan &pl) {
         }
         HIP_CHECK(hipGraphLaunch(it->second.exec, s_main));
     } else {
-        run_layers(pl.T, pl.n_seq, pl.n_out, d_meta);
+        run_layers(pl.T, pl.n_seq, pl.n_out, d_meta, pl.dense);
     }
 }
 
@@ -1266,7 +1272,7 @@ void rwkv_engine::infer(const rwkv_slot_input *in, rwkv_slot_output *out) {
         out[b].n_rows = 0;
         out[b].n_consumed = 0;
         if (in[b].n_tokens && !in[b].tokens) throw RwkvError(RWKV_ERR_INVALID, "slot has n_tokens>0 but tokens==NULL");
-        if (in[b].option != RWKV_OPTION_LAST && in[b].option != RWKV_OPTION_FULL)
+        if (in[b].option != RWKV_OPTION_LAST && in[b].option != RWKV_OPTION_FULL && in[b].option != RWKV_OPTION_NONE)
             throw RwkvError(RWKV_ERR_INVALID, "bad RnnOption");
     }
     StepPlan pl;
@@ -1277,15 +1283,35 @@ void rwkv_engine::infer(const rwkv_slot_input *in, rwkv_slot_output *out) {
             throw RwkvError(RWKV_ERR_INVALID, "logits buffer too small for slot " + std::to_string(b));
     run_plan(pl);
     const int V = info.num_vocab;
-    if (pl.n_out > 0)
-        HIP_CHECK(hipMemcpyAsync(logits_host, logits, (size_t)pl.n_out * V * 4, hipMemcpyDeviceToHost, s_main));
-    HIP_CHECK(hipStreamSynchronize(s_main));
+    // Logits go straight into the caller's buffers when those are pinned host memory (rwkv_host_alloc, or anything registered
+    // with the HIP runtime): destinations that are contiguous in output-row order are merged, so a caller that hands one pinned
+    // block for all slots gets ONE device-to-host copy and no host-side memcpy.  Pageable destinations take the staged path.
+    struct Seg { float *dst; size_t row0, rows; };
+    std::vector<Seg> segs;
     for (int b = 0; b < max_batch; ++b) {
         out[b].n_consumed = (size_t)pl.slot_consumed[b];
         out[b].n_rows = (size_t)pl.slot_out_rows[b];
-        if (pl.slot_out_rows[b] > 0)
-            std::memcpy(out[b].logits, logits_host + (size_t)pl.slot_out_begin[b] * V, (size_t)pl.slot_out_rows[b] * V * 4);
+        if (pl.slot_out_rows[b] == 0) continue;
+        const size_t r0 = (size_t)pl.slot_out_begin[b], n = (size_t)pl.slot_out_rows[b];
+        if (!segs.empty() && segs.back().dst + segs.back().rows * V == out[b].logits && segs.back().row0 + segs.back().rows == r0) segs.back().rows += n;
+        else segs.push_back(Seg{out[b].logits, r0, n});
     }
+    bool direct = !segs.empty();
+    for (const Seg &g : segs) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, g.dst) != hipSuccess) { (void)hipGetLastError(); direct = false; break; }
+        if (at.type != hipMemoryTypeHost) { direct = false; break; }
+    }
+    if (direct) {
+        for (const Seg &g : segs)
+            HIP_CHECK(hipMemcpyAsync(g.dst, logits + g.row0 * V, g.rows * V * 4, hipMemcpyDeviceToHost, s_main));
+        HIP_CHECK(hipStreamSynchronize(s_main));
+        return;
+    }
+    if (pl.n_out > 0)
+        HIP_CHECK(hipMemcpyAsync(logits_host, logits, (size_t)pl.n_out * V * 4, hipMemcpyDeviceToHost, s_main));
+    HIP_CHECK(hipStreamSynchronize(s_main));
+    for (const Seg &g : segs) std::memcpy(g.dst, logits_host + g.row0 * V, g.rows * V * 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1294,6 +1320,7 @@ void rwkv_engine::infer(const rwkv_slot_input *in, rwkv_slot_output *out) {
 extern "C" {
 
 const char *rwkv_last_error(void) { return g_err.c_str(); }
+void rwkv_set_last_error(const char *msg) { g_err = msg ? msg : ""; }   // internal: the tokenizer TU reports through the same slot
 int32_t rwkv_abi_version(void) { return RWKV_ABI_VERSION; }
 
 int32_t rwkv_device_count(void) {
@@ -1365,6 +1392,16 @@ rwkv_status rwkv_engine_info(const rwkv_engine *e, rwkv_model_info *out) {
 int32_t rwkv_engine_device(const rwkv_engine *e) { return e ? e->device : -1; }
 int32_t rwkv_engine_max_batch(const rwkv_engine *e) { return e ? e->max_batch : 0; }
 uint64_t rwkv_engine_weight_bytes(const rwkv_engine *e) { return e ? e->weight_bytes : 0; }
+
+rwkv_status rwkv_host_alloc(size_t bytes, void **out) {
+    return guard([&] {
+        if (!out || bytes == 0) throw RwkvError(RWKV_ERR_INVALID, "bad arguments");
+        void *p = nullptr;
+        HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        *out = p;
+    });
+}
+void rwkv_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 rwkv_status rwkv_infer(rwkv_engine *e, const rwkv_slot_input *in, rwkv_slot_output *out) {
     return guard([&] {
@@ -1575,7 +1612,11 @@ rwkv_status rwkv_decode_greedy(rwkv_engine *e, int32_t n_slots, const uint32_t *
         e->plan_step(in.data(), pl);
         e->upload_plan(pl);
         const size_t need = (size_t)n_steps * n_slots;
-        if (need > e->hist_cap) {
+        if (need > e->hist_cap) {                                  // grow: the old buffer goes back (dalloc only frees at destroy)
+            if (e->d_hist) {
+                e->allocs.erase(std::remove(e->allocs.begin(), e->allocs.end(), (void *)e->d_hist), e->allocs.end());
+                (void)hipFree(e->d_hist);
+            }
             e->d_hist = e->dalloc<int>(need);
             e->hist_cap = need;
         }
@@ -1586,7 +1627,7 @@ rwkv_status rwkv_decode_greedy(rwkv_engine *e, int32_t n_slots, const uint32_t *
         hipGraphExec_t exec = nullptr;
         HIP_CHECK(hipStreamBeginCapture(e->s_main, hipStreamCaptureModeThreadLocal));
         try {
-            e->run_layers(pl.T, pl.n_seq, pl.n_out, e->d_tok_feedback);
+            e->run_layers(pl.T, pl.n_seq, pl.n_out, e->d_tok_feedback, pl.dense);
             launch_argmax(e->logits, n_slots, e->info.num_vocab, e->d_tok_feedback, e->d_amax_v, e->d_amax_i, e->s_main);
         } catch (...) {
             (void)hipStreamEndCapture(e->s_main, &g);

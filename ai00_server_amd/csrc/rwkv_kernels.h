@@ -33,20 +33,13 @@ struct DMat {
     uint64_t bytes = 0;             // payload + scales, for roofline accounting
 };
 
-// Soft dependency of a launch on its predecessor (rwkv_kernels.hip "Step-local activations and soft launch dependencies").
-// wait == nullptr: the launch is ordered by its stream alone; signal == nullptr: nobody polls this launch.
-struct DepLink {
-    const unsigned *wait = nullptr;  // completion counter of the predecessor launch
-    unsigned target = 0;             // = number of blocks of the predecessor
-    unsigned *signal = nullptr;      // this launch's own completion counter (every block adds 1 when its stores have drained)
-    unsigned *err = nullptr;         // set to 1 when a poll gives up
-};
-
 struct RowMeta {                    // device arrays, one entry per row of this step
     const int *token;               // token id
     const int *slot;                // state slot
     const int *prev;                // previous row of the same slot in this step, or -1 (-> state)
     const int *last;                // for first rows: last row of the slot in this step; else -1
+    int dense;                      // 1: dense decode step — row t belongs to slot t, one row per slot (prev = -1, last = t):
+                                    //    the kernels derive slot / prev / last from the row index instead of loading them
 };
 
 // LayerNorm + token-shift PROLOGUE of a GEMM-like kernel (tiny decode steps, T <= LNP_MAX_T): every block redoes the
@@ -113,7 +106,6 @@ struct GemmLaunch {
     int total_blocks;
     LnProArgs lnp;
     ShiftCommit commit;             // grid = total_blocks + 1 when commit.src is set
-    DepLink dep;
 };
 
 void gemm_variant(int T, bool hilo, int &NT, int &KSW);   // tile variant used for T rows
@@ -138,7 +130,6 @@ struct V6MixArgs {
     int ldh, T, C, Dm;
     LnProArgs lnp;                  // lnp.x_in set: LayerNorm + shift computed in the kernel (z, xx, dx unused)
     const float *mu_x;              // with lnp: z = xx + dx * mu_x
-    DepLink dep;
 };
 bool v6_mix_supported(int T, int C, int Dm);
 bool v6_mix_ln_supported(int T, int C, int Dm, bool hilo, int np);   // the LayerNorm-prologue form (lnp set)
@@ -163,7 +154,6 @@ struct LnShiftArgs {
     int ldh;
     float *xx_out, *dx_out;         // optional fp32 copies (V6 time-mix LoRA epilogue needs them)
     int C;
-    DepLink dep;
 };
 void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s);
 
@@ -173,7 +163,6 @@ struct EmbedArgs {
     const int *token;
     float *x;
     int C, V;
-    DepLink dep;
 };
 void launch_embed(const EmbedArgs &a, int T, hipStream_t s);
 
@@ -186,7 +175,6 @@ struct LnOutArgs {
     const int *out_rows;            // rows to emit (compacted)
     _Float16 *ohi, *olo;
     int ldh, C;
-    DepLink dep;
 };
 void launch_ln_out(const LnOutArgs &a, int n_out, hipStream_t s);
 
@@ -197,6 +185,7 @@ struct WkvArgs {
     const int *seq_slot;            // [n_seq]
     const int *seq_begin;           // [n_seq] first row
     const int *seq_len;             // [n_seq]
+    int dense;                      // 1: sequence i = slot i = row i, one row each (seq_* are not read)
     float *state;                   // internal WKV state of this layer: state + slot*slot_stride + h*4096
     long slot_stride;
     const float *r, *k, *v;         // [T][C]
@@ -215,7 +204,6 @@ struct WkvArgs {
     const float *lnx_w, *lnx_b;
     _Float16 *yhi, *ylo;
     int ldh;
-    DepLink dep;
 };
 void launch_wkv(const WkvArgs &a, bool multi_row, hipStream_t s);   // multi_row: some sequence has > 1 row in this step
 

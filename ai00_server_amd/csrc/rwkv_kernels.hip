@@ -80,23 +80,17 @@ __device__ __forceinline__ void store_operand4(_Float16 *__restrict__ hi, _Float
 }
 
 // =====================================================================================
-// Step-local activations and soft launch dependencies (DepLink, rwkv_kernels.h).
-//
-// A decode step is a chain of ~260 dependent launches, each of which streams a few MB of weights that do NOT depend on
-// its predecessor.  The engine therefore runs consecutive launches on alternating HIP streams: launch i+1 starts while
-// launch i is still running, issues its weight / state loads, and only then waits — inside the kernel — for launch i's
-// completion counter (one relaxed agent-scope poll by one lane, `dep_wait`).  Launch boundaries (≈4 us each on this part
-// for a dependent pair) turn into a ≈1 us flag hop, and the weight stream of launch i+1 overlaps the tail of launch i.
-//
-// Visibility without fences (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": valid
-// form `sc1` stores AND `sc1` loads both sides): every buffer a launch of the step writes and a later launch of the SAME
-// step reads is written with write-through `sc1` stores and read with `sc1` loads (L1 bypassed; per-XCD L2s need no
-// write-back / invalidate); every storing wave drains `vmcnt(0)` before the block's single counter increment.
-// Weights, constants and the recurrent state (written in one step, read in the next, i.e. across a real graph boundary)
-// keep plain / non-temporal accesses.  The accessors below are the ONLY way activations are touched in decode-path kernels.
+// Activation accessors.  Everything a kernel of the step hands to a later kernel (residual rows, fp32 projections, f16
+// operands) is addressed through a buffer descriptor (4 SGPRs per array) + a 32-bit byte offset per lane: half the address
+// VGPRs of 64-bit global pointers in kernels whose register budget is spent on weight tiles and X fragments, and one place
+// to set the cache policy of hand-over data.  Policy 0 = default (L1 + L2).  A write-through / L1-bypassing policy (sc1 on
+// both sides) with in-kernel completion counters was built to overlap consecutive launches on two streams and measured:
+// the polling of a few hundred waiting workgroups on one counter costs more than the launch boundary it replaces
+// (scripts/chain_bench.hip: 10.8-30 us per dependent phase against 6.2 us for plain graph launches), so launches stay
+// stream-ordered.
 // =====================================================================================
 typedef __amdgpu_buffer_rsrc_t act_t;                              // buffer descriptor of one activation array (4 SGPRs)
-constexpr int ACT_SC1 = 16;                                       // gfx950 cache-policy bit 4 = sc1 (agent scope)
+constexpr int ACT_SC1 = 0;                                        // cache policy of activation accesses (0: default; 16 would be sc1)
 __device__ __forceinline__ act_t act_buf(const void *p) {         // p must be wave-uniform (kernel argument arithmetic)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, -1, 0x00020000);
 }
@@ -128,28 +122,6 @@ __device__ __forceinline__ void act_store_operand4(act_t hi, act_t lo, bool has_
     split_hilo(o.w, a, b); h[3] = a; l[3] = b;
     act_sth4(hi, off, h);
     if (has_lo) act_sth4(lo, off, l);
-}
-
-constexpr unsigned DEP_SPIN_LIMIT = 1u << 22;                      // ~0.5 s of polling: a step never takes that long
-// All threads of the block call this at one uniform point, AFTER issuing every load that does not depend on the
-// predecessor.  One lane polls; the barrier releases the block.  A poll that gives up sets *err (the host fails the call).
-__device__ __forceinline__ void dep_wait(const DepLink &d) {
-    if (d.wait == nullptr) return;
-    if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(d.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < d.target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > DEP_SPIN_LIMIT) { __hip_atomic_store(d.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-    }
-    __syncthreads();
-}
-// All threads call this after their last activation store: drain the write-through stores, then ONE increment per block.
-__device__ __forceinline__ void dep_signal(const DepLink &d) {
-    if (d.signal == nullptr) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(d.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Cross-lane sums on the DPP path (v_add_f32 with a dpp source modifier, a few cycles each) instead of `__shfl_xor`,
@@ -362,8 +334,8 @@ __device__ __forceinline__ void ln_prologue_load(const LnProArgs &a, int T, floa
 #pragma unroll
     for (int t = 0; t < LNP_MAX_T; ++t) {
         if (t < T) {
-            const int slot = a.rm.slot[t];
-            prev[t] = a.rm.prev[t];
+            const int slot = a.rm.dense ? t : a.rm.slot[t];
+            prev[t] = a.rm.dense ? -1 : a.rm.prev[t];
             float4 v[PTN], sxv[PTN], pp[LNP_MAX_NP][PTN];
 #pragma unroll
             for (int i = 0; i < PTN; ++i) {
@@ -500,10 +472,10 @@ size_t lnp_lds_bytes(int T, int C, bool hilo) { return (size_t)(2 * T * (C + LNP
 // token-shift state commit of the previous launch's prologue (one extra block)
 __device__ __forceinline__ void shift_commit(const ShiftCommit &c) {
     for (int t = 0; t < c.T; ++t) {
-        const int last = c.rm.last[t];
+        const int last = c.rm.dense ? t : c.rm.last[t];
         if (last < 0) continue;
         const act_t src = act_buf(c.src);
-        float *dst = c.sx + (long)c.rm.slot[t] * c.sx_slot_stride;
+        float *dst = c.sx + (long)(c.rm.dense ? t : c.rm.slot[t]) * c.sx_slot_stride;
         for (int i = threadIdx.x * 4; i < c.C; i += blockDim.x * 4) *(float4 *)(dst + i) = act_ld4(src, (long)last * c.C + i);
     }
 }
@@ -576,16 +548,6 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
     };
 
     TRACE_PT(0);
-    // The weights of the wave's first slice do not depend on the previous launch: they are issued BEFORE the wait on its
-    // completion counter (dep_wait), so the stream of this launch overlaps the tail of its predecessor.
-    bool prefetched = false;
-    if (wave < nw && wave < nslice) {
-        const int k0 = kbeg + wave * KW;
-        const int nsub = TAIL ? SUB : min(SUB, (kend - k0) / RK);
-        issue_w(k0, nsub, nstrip * nsub, RD > 1 && nsub == SUB);
-        prefetched = true;
-    }
-    dep_wait(L.dep);
     for (int t0 = 0; t0 < L.T; t0 += NT * 16) {
         for (int sl = wave; sl < nslice && wave < nw; sl += nw) {
             const int k0 = kbeg + sl * KW;
@@ -596,6 +558,9 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
             // X slice of this wave -> B fragments: one contiguous 1 KiB tile per (n-tile, k-step), see opd_off
             f16x8 xb[NT][KSW], xl[HILO ? NT : 1][HILO ? KSW : 1];
             const bool ringed = RD > 1 && nsub == SUB;
+            // X first, weights after: the X fragments are L2 hits and complete first, so (in-order vmcnt) the MFMAs of round
+            // r only wait for rounds <= r while later rounds are still streaming in from HBM.  (Weights-first was measured
+            // and is slower: issuing is throttled by the CU's memory pipeline either way, and X then lands last.)
             auto load_x = [&]() {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -625,8 +590,8 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                 }
             };
             if constexpr (LNP) {
-                // LayerNorm prologue launch: this wave's weights are already in flight (issued before the dependency wait);
-                // row loads, reductions; the B fragments come from the prologue's LDS image.
+                // LayerNorm prologue launch: row loads, then this wave's weights (holding both in flight at once does not
+                // fit the register file), then the reductions; the B fragments come from the prologue's LDS image.
                 // One slice per wave, one 16-token tile (host checks).
                 float *xx_l = (float *)(smem + (size_t)L.lds_items * NT * 64 * 16);
                 const int ldl = L.lnp.C + LNP_PAD;
@@ -634,6 +599,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                 _Float16 *op_l = (_Float16 *)(lred + 64);
                 LnCarry carry;
                 ln_prologue_load(L.lnp, L.T, xx_l, pv_l, lred, blockIdx.x == 0, carry);
+                issue_w(k0, nsub, nround, ringed);             // the weights fly while the rows are reduced and normalised
                 ln_prologue_finish<HILO>(L.lnp, L.T, P.lnp_mu, xx_l, pv_l, op_l, lred, blockIdx.x == 0, carry);
                 const int tl = min(lane & 15, L.T - 1);
                 const _Float16 *oph = op_l + lnp_op_off(L.T, k0 + (lane >> 4) * 8, tl);
@@ -645,9 +611,8 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                 }
             } else {
                 load_x();
-                if (!prefetched) issue_w(k0, nsub, nround, ringed);
+                issue_w(k0, nsub, nround, ringed);
             }
-            prefetched = false;
 #ifdef RWKV_TRACE
             TRACE_PT(1);
 #if RWKV_TRACE >= 2
@@ -750,7 +715,6 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
         }
         if (t0 + NT * 16 < L.T) __syncthreads();
     }
-    dep_signal(L.dep);
     TRACE_PT(4);
 }
 
@@ -758,9 +722,7 @@ template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, bool LNP>
 __global__ __launch_bounds__(((KSW == 16 || NT == 4) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES) * 64) void gemm_kernel(const GemmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x >= L.total_blocks) {                      // the extra block of a launch that carries a commit
-        dep_wait(L.dep);                                          // every block of the prologue launch has read the old state
         shift_commit(L.commit);
-        dep_signal(L.dep);
         return;
     }
     int pi = 0;
@@ -849,22 +811,6 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
 #pragma unroll
     for (int ks = 0; ks < DS / 2; ++ks) w2t[ks] = ((const u32x4 *)a.W2[c])[((long)strip_c * (DS / 2) + ks) * 64 + lane];
     const float4 mu = *(const float4 *)(a.mu[c] + row0);
-    // phase-1 weights of the first batch of k-steps: W1 is a constant too, so its tiles are also in flight before the wait
-    const u32x4 *w1 = (const u32x4 *)a.W1;
-    constexpr int KB = DS == 2 ? ((HILO && NT == 2) ? 5 : 10) : 4;                                          // k-steps per batch: all loads of a batch in flight at once
-    u32x4 wt[KB][DS];
-    auto load_w1 = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            if (k0 + j < kst) {                                    // wave-uniform
-                const int kt = wave * kst + k0 + j;
-#pragma unroll
-                for (int d = 0; d < DS; ++d) wt[j][d] = w1[((long)(c * DS + d) * KT1 + kt) * 64 + lane];
-            }
-        }
-    };
-    load_w1(0);
-    dep_wait(a.dep);                                              // everything above is independent of the previous launch
     const act_t bxx = act_buf(a.xx), bdx = act_buf(a.dx), bzh = act_buf(a.zhi), bzl = act_buf(a.zlo);
     const act_t boh = act_buf(a.ohi[c]), bol = act_buf(a.olo[c]);
     // LNP (single-token steps): LayerNorm + token shift are redone here by every block (ln_prologue_*): z arrives in LDS in
@@ -902,9 +848,11 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     for (int d = 0; d < DS; ++d)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[d][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const u32x4 *w1 = (const u32x4 *)a.W1;
+    constexpr int KB = DS == 2 ? ((HILO && NT == 2) ? 5 : 10) : 4;                                          // k-steps per batch: all loads of a batch in flight at once
     for (int k0 = 0; k0 < kst; k0 += KB) {
         f16x8 zb[KB][NT], zl[HILO ? KB : 1][HILO ? NT : 1];
-        if (k0 > 0) load_w1(k0);
+        u32x4 wt[KB][DS];
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             if (k0 + j < kst) {                                    // wave-uniform
@@ -922,6 +870,8 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
                         if constexpr (HILO) zl[j][nt] = act_ldh8(bzl, zo);
                     }
                 }
+#pragma unroll
+                for (int d = 0; d < DS; ++d) wt[j][d] = w1[((long)(c * DS + d) * KT1 + kt) * 64 + lane];
             }
         }
 #pragma unroll
@@ -989,7 +939,6 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
             }
         }
     }
-    dep_signal(a.dep);
     TRACE_K(0, 4);
 }
 
@@ -1426,12 +1375,11 @@ __global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
     ROW_FOR(i, c) { wv[i] = ld4(a.lnw + c); bv[i] = ld4(a.lnb + c); }
     if (a.nmix > 0) { ROW_FOR(i, c) mu0[i] = ld4(a.mu[0] + c); }
     if (a.nmix > 1) { ROW_FOR(i, c) mu1[i] = ld4(a.mu[1] + c); }
-    const int slot = a.rm.slot[t], prev = a.rm.prev[t], last = a.rm.last[t];
+    // dense decode step (row t = slot t, one row per slot): no metadata round trip in front of the state load
+    const int slot = a.rm.dense ? t : a.rm.slot[t], prev = a.rm.dense ? -1 : a.rm.prev[t], last = a.rm.dense ? t : a.rm.last[t];
     float *__restrict__ sx = a.sx + (long)slot * a.sx_slot_stride;
     float4 xv[PT], pv[PT];
-    // the token-shift state was written by the previous STEP (a real graph boundary): it is fetched before the wait too
     if (prev < 0) { ROW_FOR(i, c) pv[i] = ld4(sx + c); }
-    dep_wait(a.dep);
     const act_t bx = act_buf(a.x_in), bP = act_buf(a.P), bxo = act_buf(a.x_out), bxx = act_buf(a.xx_out), bdx = act_buf(a.dx_out);
     row_load_sum<PT>(bx, bP, a.np, a.pstride, t, C, xv);
     if (prev >= 0) row_load_sum<PT>(bx, bP, a.np, a.pstride, prev, C, pv);
@@ -1480,7 +1428,6 @@ __global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
             }
         }
     }
-    dep_signal(a.dep);
     TRACE_K(2, 3);
 }
 #define ROW_DISPATCH(KERN, C_, GRID, ...)                                                          \
@@ -1507,10 +1454,8 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
         v[i] = make_float4((float)e[0], (float)e[1], (float)e[2], (float)e[3]);
     }
     row_layernorm<PT>(v, C, wv, bv, red);
-    dep_wait(a.dep);                                               // the previous launch may still read the residual buffer
     const act_t bx = act_buf(a.x);
     ROW_FOR(i, c) act_st4(bx, (long)t * C + c, v[i]);
-    dep_signal(a.dep);
 }
 void launch_embed(const EmbedArgs &a, int T, hipStream_t s) { ROW_DISPATCH(embed_kernel, a.C, T, a); }
 
@@ -1520,14 +1465,12 @@ __global__ __launch_bounds__(256) void ln_out_kernel(const LnOutArgs a) {
     const int o = blockIdx.x, C = a.C;
     float4 wv[PT], bv[PT];
     ROW_FOR(i, c) { wv[i] = ld4(a.lnw + c); bv[i] = ld4(a.lnb + c); }
-    const int t = a.out_rows[o];
+    const int t = a.out_rows ? a.out_rows[o] : o;               // null: every row is emitted in order (dense decode step)
     float4 v[PT];
-    dep_wait(a.dep);
     row_load_sum<PT>(act_buf(a.x_in), act_buf(a.P), a.np, a.pstride, t, C, v);
     row_layernorm<PT>(v, C, wv, bv, red);
     const act_t oh = act_buf(a.ohi), ol = act_buf(a.olo);
     ROW_FOR(i, c) act_store_operand4(oh, ol, a.olo != nullptr, opd_off(o, c, a.ldh), v[i]);
-    dep_signal(a.dep);
 }
 void launch_ln_out(const LnOutArgs &a, int n_out, hipStream_t s) { ROW_DISPATCH(ln_out_kernel, a.C, n_out, a); }
 
@@ -1550,7 +1493,7 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
     const int seq = blockIdx.x, h = blockIdx.y;
     const int tid = threadIdx.x, ig = tid >> 4, jg = tid & 15;
     TRACE_K(1, 0);
-    const int slot = a.seq_slot[seq], row0 = a.seq_begin[seq], nrow = a.seq_len[seq];
+    const int slot = a.dense ? seq : a.seq_slot[seq], row0 = a.dense ? seq : a.seq_begin[seq], nrow = a.dense ? 1 : a.seq_len[seq];
     const int C = a.C, cb = h * 64;
     float *st = a.state + (long)slot * a.slot_stride + (long)h * 4096;
 
@@ -1572,8 +1515,6 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
     const int ch = tid >> 2, part = tid & 3;                 // v6 decay LoRA: 4 threads per channel
     const int per = a.Dd >> 2;
     const float decay0 = a.version == 6 ? a.wdec_or_decay[cb + ch] : 0.f;
-    // state, parameters: in flight; now the projections of the previous launch
-    dep_wait(a.dep);
     const act_t br = act_buf(a.r), bk = act_buf(a.k), bv = act_buf(a.v), bg = act_buf(a.g), btd = act_buf(a.td);
     const act_t ba7 = act_buf(a.a7), bw7 = act_buf(a.w7), bvg7 = act_buf(a.vg7), bvf = act_buf(a.v_first);
     const act_t byh = act_buf(a.yhi), byl = act_buf(a.ylo);
@@ -1676,7 +1617,7 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
             y *= gt;
             _Float16 hh, ll;
             split_hilo(y, hh, ll);
-            // 2-byte write-through stores would each be a fabric write: lanes pair up, the even lane stores both halves (4 B)
+            // lanes pair up, the even lane stores both halves (one 4-byte store per pair instead of two 2-byte stores)
             const unsigned hb = __builtin_bit_cast(unsigned short, hh), lb = __builtin_bit_cast(unsigned short, ll);
             const unsigned hn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hb, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
             const unsigned ln2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lb, 0xB1, 0xf, 0xf, true);
@@ -1690,7 +1631,6 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
     TRACE_K(1, 4);
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, T[aa]), (f32x4 *)(st + (aa * 16 + ig) * 64 + jg * 4));
-    dep_signal(a.dep);
     TRACE_K(1, 5);
 }
 
@@ -2066,7 +2006,9 @@ __device__ __forceinline__ float block_reduce_1024(float v, float *red, bool is_
 // (exact while that fits NC = 8192, i.e. max_surprise < 13; beyond, the tail below 2^-13 is cut), no temperature,
 // draw u * sum against the running sum; `out_prob` carries the token surprise log2(sum) - log2(p) the host needs for
 // its update of max_surprise.
-template <int NC, bool MIRO>
+// FULL: V == 65536 exactly (the World vocabulary padded): no bound predicates at all — with them hipcc keeps 64 exec masks
+// alive across the kernel (spilled to VGPR lanes) and wraps every load in its own branch.
+template <int NC, bool MIRO, bool FULL>
 __global__ __launch_bounds__(NUC_THREADS) void nucleus_kernel(const float *logits, int V, const SampleRow *sp, int *out_tok,
                                                                float *out_prob) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nuc_smem[];
@@ -2084,13 +2026,14 @@ __global__ __launch_bounds__(NUC_THREADS) void nucleus_kernel(const float *logit
 #pragma unroll
     for (int j = 0; j < NUC_EPT; ++j) {
         const int i = j * NUC_THREADS + tid;
-        p[j] = i < V ? x[i] : -INFINITY;
+        const float xv = x[FULL ? i : (i < V ? i : V - 1)];      // clamped, not predicated: the 64 loads are issued back to back
+        p[j] = (FULL || i < V) ? xv : -INFINITY;
         m = fmaxf(m, p[j]);
     }
     m = block_reduce_1024(m, red, true);
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < NUC_EPT; ++j) { p[j] = (j * NUC_THREADS + tid) < V ? expf(p[j] - m) : 0.f; s += p[j]; }
+    for (int j = 0; j < NUC_EPT; ++j) { p[j] = expf(p[j] - m); s += p[j]; }            // out of range: exp(-inf) = 0
     s = block_reduce_1024(s, red, false);
 #pragma unroll
     for (int j = 0; j < NUC_EPT; ++j) p[j] = p[j] / s;
@@ -2115,8 +2058,16 @@ __global__ __launch_bounds__(NUC_THREADS) void nucleus_kernel(const float *logit
         return expf(x[id] - m) / s;
     };
     const float cut = typical ? P.tau : P.top_p;
-    // ---- radix select of the k-th largest key (positive floats / complemented keys: bit patterns are order-preserving)
-    int k = P.top_k < 1 ? 1 : (P.top_k > 256 ? 256 : P.top_k);
+    // ---- the k-th largest key (positive floats / complemented keys: bit patterns are order-preserving).
+    // A histogram radix select is the textbook choice and was the first version: all 65 536 keys of a row share a handful of
+    // exponent bytes, so its LDS atomics serialise on a few bins (137 us per launch).  Instead: a search over the key bits,
+    // two bits per step; a step counts, per thread over its 64 registers, the keys >= each of three trial thresholds and sums
+    // the three counts over the block (DPP wave sums, one barrier).  16 steps, no atomics, deterministic.
+    if (!MIRO && P.top_k < 1) {                                     // `.take(0)`: nothing kept, find_or_first -> None -> token 0 (nucleus.rs:78-101)
+        if (tid == 0) { out_tok[row] = 0; if (out_prob) out_prob[row] = 0.f; }
+        return;
+    }
+    int k = P.top_k > 256 ? 256 : P.top_k;
     if (MIRO) {
         float c = 0.f;
 #pragma unroll
@@ -2125,42 +2076,88 @@ __global__ __launch_bounds__(NUC_THREADS) void nucleus_kernel(const float *logit
         if (k > NC) k = NC;
     }
     if (k > V) k = V;
-    if (tid == 0) { sel[0] = 0u; sel[1] = (unsigned)k; sel[2] = 0u; }
-    unsigned prefix = 0u, mask = 0u;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        if (tid < 256) hist[tid] = 0u;
+    float *cnt = (float *)hist;                                     // [2][16 waves][4] per-wave partial counts, double-buffered
+    // per-wave counts arrive as wave-uniform integers: a count is s_bcnt1 of the compare mask (v_cmp -> SALU), no cross-lane sum.
+    // Written as asm: left to itself hipcc batches the 192 compares of a step and spills their masks to VGPR lanes (17 k lines).
+    // (compare, count and accumulate in one statement: with the count as an asm OUTPUT hipcc still parks every count in a lane)
+    auto wcount3 = [](int &c1, int &c2, int &c3, unsigned key, unsigned t1, unsigned t2, unsigned t3) {   // c_i += #lanes(key >= t_i)
+        asm volatile("v_cmp_le_u32 vcc, %3, %6\n\ts_bcnt1_i32_b64 vcc_lo, vcc\n\ts_add_i32 %0, %0, vcc_lo\n\t"
+                     "v_cmp_le_u32 vcc, %4, %6\n\ts_bcnt1_i32_b64 vcc_lo, vcc\n\ts_add_i32 %1, %1, vcc_lo\n\t"
+                     "v_cmp_le_u32 vcc, %5, %6\n\ts_bcnt1_i32_b64 vcc_lo, vcc\n\ts_add_i32 %2, %2, vcc_lo"
+                     : "+s"(c1), "+s"(c2), "+s"(c3) : "s"(t1), "s"(t2), "s"(t3), "v"(key) : "vcc", "scc");
+    };
+    auto count3 = [&](int buf, float c1, float c2, float c3, float &s1, float &s2, float &s3) {
+        float *cb = cnt + buf * 64;
+        if ((tid & 63) == 0) { cb[(tid >> 6) * 4 + 0] = c1; cb[(tid >> 6) * 4 + 1] = c2; cb[(tid >> 6) * 4 + 2] = c3; }
         __syncthreads();
+        s1 = s2 = s3 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NUC_THREADS / 64; ++w) { s1 += cb[w * 4 + 0]; s2 += cb[w * 4 + 1]; s3 += cb[w * 4 + 2]; }
+    };
+    unsigned thr = 0u;                                              // invariant: count(key >= thr) >= k
+#pragma unroll 1
+    for (int step = 0; step < 16; ++step) {
+        const int lo = 30 - 2 * step;
+        const unsigned tu = __builtin_amdgcn_readfirstlane(thr);    // block-uniform by construction; make it an SGPR
+        const unsigned t1 = tu | (1u << lo), t2 = tu | (2u << lo), t3 = tu | (3u << lo);
+        int c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
         for (int j = 0; j < NUC_EPT; ++j) {
-            const unsigned key = __float_as_uint(p[j]);
-            if ((j * NUC_THREADS + tid) < V && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            const unsigned key = __float_as_uint(p[j]);             // elements beyond V hold 0 and never count (thresholds > 0)
+            wcount3(c1, c2, c3, key, t1, t2, t3);
         }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned need = sel[1], cum = 0u;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (cum + hist[b] >= need) break;
-                cum += hist[b];
-            }
-            sel[0] = prefix | ((unsigned)b << shift);
-            sel[1] = need - cum;
-        }
-        __syncthreads();
-        prefix = sel[0];
-        mask |= 255u << shift;
+        float s1, s2, s3;
+        count3(step & 1, (float)c1, (float)c2, (float)c3, s1, s2, s3);   // sums <= 65536: exact in fp32
+        thr = s3 >= (float)k ? t3 : (s2 >= (float)k ? t2 : (s1 >= (float)k ? t1 : thr));
     }
-    const unsigned thr = prefix;                                    // bits of the k-th largest probability
-    // ---- gather everything >= thr (ties included; zero-probability ties are skipped), sort, keep k
+    // thr = bits of the k-th largest key (0 when fewer than k keys are non-zero).  Candidates: every key > thr, and of the keys
+    // == thr the lowest ids (ties order lower id first, as the oracle's restatement does: the reference sorts with an unstable
+    // radix sort, nucleus.rs:76, so its tie order is not defined).  If more keys tie at thr than the candidate buffer holds,
+    // a second search of the same kind over the id picks the id bound, so the set never depends on thread timing.
+    float n_ge, n_gt, n_dummy;
+    {
+        const unsigned tu = __builtin_amdgcn_readfirstlane(thr);
+        const unsigned tge = tu < 1u ? 1u : tu, tgt = tu + 1u;     // key >= thr and non-zero; key > thr  (thr < 2^32 - 1: a key of all ones is never the k-th... guarded below)
+        int cge = 0, cgt = 0, cxx = 0;
+#pragma unroll
+        for (int j = 0; j < NUC_EPT; ++j) wcount3(cge, cgt, cxx, __float_as_uint(p[j]), tge, tgt, tgt);
+        if (tu == 0xFFFFFFFFu) cgt = 0;                             // tgt wrapped to 0: nothing is greater than all ones
+        count3(0, (float)cge, (float)cgt, 0.f, n_ge, n_gt, n_dummy);
+    }
+    unsigned id_bound = 0xFFFFFFFFu;                                // keys == thr are admitted while id <= id_bound
+    if (n_ge > (float)NC) {
+        const float need = (float)k - n_gt;                         // >= 1 ties needed; there are more than NC - n_gt of them
+        unsigned lim = 0u;                                          // the largest t with count(key == thr, id < t) < need
+#pragma unroll 1
+        for (int step = 0; step < 9; ++step) {                      // 18 bits, two per step (ids < 2^16)
+            const int lo = 16 - 2 * step;
+            const unsigned lu = __builtin_amdgcn_readfirstlane(lim);
+            const unsigned t1 = lu | (1u << lo), t2 = lu | (2u << lo), t3 = lu | (3u << lo);
+            int c1 = 0, c2 = 0, c3 = 0;                             // counts of ties with id < t (monotone in t)
+#pragma unroll
+            for (int j = 0; j < NUC_EPT; ++j) {
+                const unsigned id = (unsigned)(j * NUC_THREADS + tid);
+                // a tie counts when id < t, i.e. NOT (id >= t): fold the tie test into the compared value (non-ties compare as 2^32-1)
+                const unsigned idv = (__float_as_uint(p[j]) == thr) ? id : 0xFFFFFFFFu;   // out-of-range elements hold key 0 != thr
+                wcount3(c1, c2, c3, idv, t1, t2, t3);                // counts of NOT (id < t); flipped below
+            }
+            c1 = NUC_EPT * 64 - c1; c2 = NUC_EPT * 64 - c2; c3 = NUC_EPT * 64 - c3;
+            float s1, s2, s3;
+            count3((step + 1) & 1, (float)c1, (float)c2, (float)c3, s1, s2, s3);
+            // keep the LARGEST lim whose count is still < need: then lim is the last id bound that is one short
+            lim = s3 < need ? t3 : (s2 < need ? t2 : (s1 < need ? t1 : lim));
+        }
+        id_bound = lim;                                             // then id `lim` is a tie and the ties with id <= lim are exactly `need`
+    }
+    if (tid == 0) sel[2] = 0u;
     for (int i = tid; i < NC; i += NUC_THREADS) cand[i] = 0ull;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NUC_EPT; ++j) {
         const int i = j * NUC_THREADS + tid;
         const unsigned key = __float_as_uint(p[j]);
-        if (i < V && key >= thr && key != 0u) {
-            const unsigned slot = atomicAdd(&sel[2], 1u);
+        if (key != 0u && (key > thr || (key == thr && (unsigned)i <= id_bound))) {   // out-of-range elements hold key 0
+            const unsigned slot = atomicAdd(&sel[2], 1u);           // slot order is arbitrary, the SET is not; sorted below
             if (slot < NC) cand[slot] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
         }
     }
@@ -2220,11 +2217,16 @@ void launch_nucleus(const float *logits, int n_rows, int V, const SampleRow *sp,
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_done[dev & 15]) {
-        (void)hipFuncSetAttribute((const void *)nucleus_kernel<NC2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NC2 * 12);
+        (void)hipFuncSetAttribute((const void *)nucleus_kernel<NC2, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NC2 * 12);
+        (void)hipFuncSetAttribute((const void *)nucleus_kernel<NC2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NC2 * 12);
         attr_done[dev & 15] = true;
     }
-    if (any_nucleus_typical) hipLaunchKernelGGL((nucleus_kernel<NC0, false>), dim3(n_rows), dim3(NUC_THREADS), NC0 * 12, s, logits, V, sp, out_tok, out_prob);
-    if (any_mirostat) hipLaunchKernelGGL((nucleus_kernel<NC2, true>), dim3(n_rows), dim3(NUC_THREADS), NC2 * 12, s, logits, V, sp, out_tok, out_prob);
+    const bool full = V == NUC_EPT * NUC_THREADS;
+#define NUC_LAUNCH(nc, miro) do { if (full) hipLaunchKernelGGL((nucleus_kernel<nc, miro, true>), dim3(n_rows), dim3(NUC_THREADS), nc * 12, s, logits, V, sp, out_tok, out_prob); \
+                                  else hipLaunchKernelGGL((nucleus_kernel<nc, miro, false>), dim3(n_rows), dim3(NUC_THREADS), nc * 12, s, logits, V, sp, out_tok, out_prob); } while (0)
+    if (any_nucleus_typical) NUC_LAUNCH(NC0, false);
+    if (any_mirostat) NUC_LAUNCH(NC2, true);
+#undef NUC_LAUNCH
 }
 
 // =====================================================================================

@@ -3,6 +3,7 @@
 // crates/ai00-core/src/lib.rs:375, run.rs:157-168,856 and sampler/bnf.rs:14-27.
 // Vocab JSON (assets/tokenizer/rwkv_vocab_v20230424.json, produced by convert_tokenizer.py:22-32):
 //   { "<id>": "string" | [byte, byte, ...], ... }   ids 1..65529, id 0 reserved (EOS, run.rs:855).
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -14,25 +15,55 @@
 
 namespace {
 
+// Byte trie in two forms.  While the vocabulary is read, nodes keep a small unsorted child list; `freeze()` then lays the
+// trie out as flat arrays — per node a token id and a [begin, end) range into byte-sorted edge arrays, plus a 256-entry
+// table for the root (the only wide node).  The World vocabulary (65 529 tokens, ~116 k nodes) takes ~2 MB this way; a
+// node of 256 int32 children, the first version, took 120 MB per tokenizer handle.
 struct Tok {
     std::vector<std::string> id2bytes;            // index = token id
     std::vector<uint8_t> present;
-    struct Node { int32_t next[256]; int32_t token; };
-    std::vector<Node> trie;
+    struct Build { std::vector<std::pair<uint8_t, int32_t>> kids; int32_t token = -1; };
+    std::vector<Build> build;                     // emptied by freeze()
+    std::vector<int32_t> tok, ebeg;               // per node: token id (-1: none), first edge; ebeg has one extra entry
+    std::vector<uint8_t> ebyte;                   // per edge, sorted by byte within a node
+    std::vector<int32_t> enode;
+    int32_t root[256];
 
-    int new_node() {
-        trie.emplace_back();
-        std::memset(trie.back().next, 0xff, sizeof(trie.back().next));
-        trie.back().token = -1;
-        return (int)trie.size() - 1;
-    }
+    int new_node() { build.emplace_back(); return (int)build.size() - 1; }
     void insert(const std::string &b, int id) {
         int n = 0;
         for (unsigned char c : b) {
-            if (trie[n].next[c] < 0) { int m = new_node(); trie[n].next[c] = m; }
-            n = trie[n].next[c];
+            int m = -1;
+            for (auto &k : build[n].kids) if (k.first == c) { m = k.second; break; }
+            if (m < 0) { m = new_node(); build[n].kids.emplace_back((uint8_t)c, m); }
+            n = m;
         }
-        trie[n].token = id;
+        build[n].token = id;
+    }
+    void freeze() {
+        const size_t N = build.size();
+        tok.resize(N); ebeg.resize(N + 1);
+        size_t ne = 0;
+        for (auto &b : build) ne += b.kids.size();
+        ebyte.reserve(ne); enode.reserve(ne);
+        for (size_t n = 0; n < N; ++n) {
+            auto &k = build[n].kids;
+            std::sort(k.begin(), k.end());
+            tok[n] = build[n].token;
+            ebeg[n] = (int32_t)ebyte.size();
+            for (auto &e : k) { ebyte.push_back(e.first); enode.push_back(e.second); }
+        }
+        ebeg[N] = (int32_t)ebyte.size();
+        std::memset(root, 0xff, sizeof(root));
+        if (N) for (auto &e : build[0].kids) root[e.first] = e.second;
+        std::vector<Build>().swap(build);
+    }
+    int child(int n, uint8_t c) const {
+        if (n == 0) return root[c];
+        int lo = ebeg[n], hi = ebeg[n + 1];
+        while (hi - lo > 4) { const int mid = (lo + hi) >> 1; if (ebyte[mid] <= c) lo = mid; else hi = mid; }
+        for (; lo < hi; ++lo) if (ebyte[lo] == c) return enode[lo];
+        return -1;
     }
 };
 
@@ -100,7 +131,8 @@ struct P {
 
 struct rwkv_tokenizer { Tok t; };
 
-static thread_local std::string g_tok_err;
+// failures are reported through the library's one error slot (rwkv_last_error, rwkv_engine.cpp)
+extern "C" void rwkv_set_last_error(const char *msg);
 
 extern "C" {
 
@@ -147,10 +179,11 @@ rwkv_status rwkv_tokenizer_create(const char *json, size_t len, rwkv_tokenizer *
                 break;
             }
         }
+        t.freeze();
         *out = tk.release();
         return RWKV_OK;
     } catch (const std::exception &e) {
-        g_tok_err = e.what();
+        rwkv_set_last_error(e.what());
         return RWKV_ERR_FORMAT;
     }
 }
@@ -158,18 +191,21 @@ rwkv_status rwkv_tokenizer_create(const char *json, size_t len, rwkv_tokenizer *
 void rwkv_tokenizer_destroy(rwkv_tokenizer *t) { delete t; }
 
 int64_t rwkv_tokenizer_encode(const rwkv_tokenizer *tk, const uint8_t *text, size_t len, uint32_t *out, size_t cap) {
-    if (!tk || (!text && len)) return RWKV_ERR_INVALID;
+    if (!tk || (!text && len)) { rwkv_set_last_error("tokenizer: null argument"); return RWKV_ERR_INVALID; }
     const Tok &t = tk->t;
     size_t i = 0, n = 0;
     while (i < len) {
         int node = 0, best = -1;
         size_t best_len = 0;
         for (size_t j = i; j < len; ++j) {
-            node = t.trie[node].next[text[j]];
+            node = t.child(node, text[j]);
             if (node < 0) break;
-            if (t.trie[node].token >= 0) { best = t.trie[node].token; best_len = j - i + 1; }
+            if (t.tok[node] >= 0) { best = t.tok[node]; best_len = j - i + 1; }
         }
-        if (best < 0) return RWKV_ERR_INVALID;        // TokenizerError::NoMatchingTokenFound
+        if (best < 0) {                               // TokenizerError::NoMatchingTokenFound
+            rwkv_set_last_error(("tokenizer: no token matches the input at byte " + std::to_string(i)).c_str());
+            return RWKV_ERR_INVALID;
+        }
         if (out && n < cap) out[n] = (uint32_t)best;
         ++n;
         i += best_len;
@@ -180,7 +216,7 @@ int64_t rwkv_tokenizer_encode(const rwkv_tokenizer *tk, const uint8_t *text, siz
 int64_t rwkv_tokenizer_token_bytes(const rwkv_tokenizer *tk, uint32_t token, uint8_t *out, size_t cap) {
     if (!tk) return RWKV_ERR_INVALID;
     const Tok &t = tk->t;
-    if (token >= t.id2bytes.size() || !t.present[token]) return RWKV_ERR_INVALID;
+    if (token >= t.id2bytes.size() || !t.present[token]) { rwkv_set_last_error("tokenizer: token id out of range"); return RWKV_ERR_INVALID; }
     const std::string &b = t.id2bytes[token];
     if (out) std::memcpy(out, b.data(), b.size() < cap ? b.size() : cap);
     return (int64_t)b.size();
@@ -191,7 +227,10 @@ int64_t rwkv_tokenizer_decode(const rwkv_tokenizer *tk, const uint32_t *tokens, 
     const Tok &t = tk->t;
     size_t w = 0;
     for (size_t i = 0; i < n; ++i) {
-        if (tokens[i] >= t.id2bytes.size() || !t.present[tokens[i]]) return RWKV_ERR_INVALID;   // TokenizerError::OutOfRange
+        if (tokens[i] >= t.id2bytes.size() || !t.present[tokens[i]]) {                            // TokenizerError::OutOfRange
+            rwkv_set_last_error(("tokenizer: token id " + std::to_string(tokens[i]) + " is not in the vocabulary").c_str());
+            return RWKV_ERR_INVALID;
+        }
         const std::string &b = t.id2bytes[tokens[i]];
         for (unsigned char c : b) {
             if (out && w < cap) out[w] = c;

@@ -18,6 +18,7 @@ from __future__ import annotations
 import ctypes as C
 import enum
 import os
+import time
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -78,6 +79,8 @@ ABI_SYMBOLS = {
     "rwkv_engine_max_batch": (C.c_int32, [C.c_void_p]),
     "rwkv_engine_weight_bytes": (C.c_uint64, [C.c_void_p]),
     "rwkv_infer": (C.c_int32, [C.c_void_p, C.POINTER(_SlotInC), C.POINTER(_SlotOutC)]),
+    "rwkv_host_alloc": (C.c_int32, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rwkv_host_free": (None, [C.c_void_p]),
     "rwkv_infer_sample": (C.c_int32, [C.c_void_p, C.POINTER(_SlotInC), C.POINTER(_SampleC), C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_size_t)]),
     "rwkv_plan_chunk": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]),
@@ -161,6 +164,7 @@ class Precision(enum.IntEnum):   # reload.rs:89-94
 class RnnOption(enum.IntEnum):   # run.rs:716, 819
     Last = 0
     Full = 1
+    NoOutput = 2                 # extension (RWKV_OPTION_NONE): state-only jobs such as `/embeddings`; no logits row is produced
 
 
 @dataclass
@@ -340,13 +344,23 @@ class Runtime:
         V = self.info.num_vocab
         self._ins = (_SlotInC * max_batch)()
         self._outs = (_SlotOutC * max_batch)()
-        self._logit_rows = [1] * max_batch
-        self._logits = [np.empty((1, V), np.float32) for _ in range(max_batch)]
+        # logits land in ONE pinned block (rwkv_host_alloc): the slots of a call get consecutive pieces of it in slot order, which
+        # the engine copies device-to-host in one go; calls that need more rows than the block holds fall back to numpy buffers
+        self._arena_rows = token_chunk_size + max_batch
+        ap = C.c_void_p()
+        _check(l.rwkv_host_alloc(self._arena_rows * V * 4, C.byref(ap)))
+        self._arena_ptr = ap
+        self._arena = np.ctypeslib.as_array(C.cast(ap, C.POINTER(C.c_float)), shape=(self._arena_rows, V))
+        self._views = [None] * max_batch
 
     def close(self):
         if self._h:
             lib().rwkv_engine_destroy(self._h)
             self._h = None
+            self._arena = None
+            self._views = []
+            lib().rwkv_host_free(self._arena_ptr)
+            self._arena_ptr = None
 
     def __del__(self):
         try:
@@ -372,23 +386,29 @@ class Runtime:
             raise RwkvError(-1, f"RnnInput must have max_batch={self.max_batch} entries")
         V = self.info.num_vocab
         keep = []
+        needs = [0 if not len(ib.tokens) or ib.option == RnnOption.NoOutput else
+                 (1 if ib.option == RnnOption.Last else min(len(ib.tokens), self.token_chunk_size)) for ib in inp.batches]
+        pinned = sum(needs) <= self._arena_rows
+        row = 0
         for b, ib in enumerate(inp.batches):
             toks = np.asarray(ib.tokens, dtype=np.uint32)
             keep.append(toks)
-            need = 1 if ib.option == RnnOption.Last else max(1, min(len(ib.tokens), self.token_chunk_size))
-            if self._logit_rows[b] < need:
-                self._logits[b] = np.empty((need, V), np.float32)
-                self._logit_rows[b] = need
+            if pinned:
+                view = self._arena[row:row + needs[b]]
+                row += needs[b]
+            else:
+                view = np.empty((max(1, needs[b]), V), np.float32)
+            self._views[b] = view
             self._ins[b] = _SlotInC(toks.ctypes.data_as(C.POINTER(C.c_uint32)) if toks.size else None, toks.size,
                                     int(ib.option), 0)
-            self._outs[b] = _SlotOutC(self._logits[b].ctypes.data_as(C.POINTER(C.c_float)), self._logit_rows[b], 0, 0)
+            self._outs[b] = _SlotOutC(view.ctypes.data_as(C.POINTER(C.c_float)) if needs[b] else None, needs[b], 0, 0)
         return keep
 
     def _collect(self, inp: RnnInput):
         outs = []
         for b, ib in enumerate(inp.batches):
             o = self._outs[b]
-            outs.append(self._logits[b][:o.n_rows].copy())        # RnnOutputBatch: [n_rows, V]; empty if n_rows == 0
+            outs.append(self._views[b][:o.n_rows].copy())         # RnnOutputBatch: [n_rows, V]; empty if n_rows == 0
             ib.tokens = list(ib.tokens[o.n_consumed:])
         return inp, outs
 
@@ -435,6 +455,51 @@ class Runtime:
             ib.tokens = list(ib.tokens[consumed[b]:])
             out.append((int(toks_o[b]), float(probs_o[b])) if emitted[b] else None)
         return inp, out
+
+    # ---- measurement loops (bench.py): the same ABI calls with every per-step Python object hoisted out, so that the rate is
+    # the library's, not the interpreter's
+    def serve_loop_logits(self, first_tokens, n_steps: int) -> float:
+        """`n_steps` single-token steps of `len(first_tokens)` slots through rwkv_infer with the logits of every slot copied to
+        the (pinned) host block each step, as run.rs:809-832 receives them; returns seconds.  The token fed is the slot's first
+        token every step: the arg-max over 65 536 floats per slot on the host is the sampler's cost, not the transport's."""
+        B = len(first_tokens)
+        toks = np.asarray(first_tokens, dtype=np.uint32).copy()
+        for b in range(self.max_batch):
+            self._ins[b] = _SlotInC(C.cast(toks.ctypes.data + 4 * b, C.POINTER(C.c_uint32)) if b < B else None, 1 if b < B else 0, 0, 0)
+            self._outs[b] = _SlotOutC(self._arena[b:b + 1].ctypes.data_as(C.POINTER(C.c_float)) if b < B else None, 1 if b < B else 0, 0, 0)
+        l, h, ins, outs = lib(), self._h, self._ins, self._outs
+        _check(l.rwkv_infer(h, ins, outs))
+        t = time.perf_counter()
+        for _ in range(n_steps):
+            rc = l.rwkv_infer(h, ins, outs)
+            if rc:
+                _check(rc)
+        return time.perf_counter() - t
+
+    def serve_loop_sample(self, first_tokens, n_steps: int, top_p=0.5, top_k=128, temperature=1.0, seed=0) -> float:
+        """The same loop through rwkv_infer_sample (nucleus defaults of the reference, sampler/nucleus.rs:25-35): 8 bytes per slot
+        come back instead of 256 KiB, and the token the device picked is fed to the next step.  Returns seconds."""
+        B = len(first_tokens)
+        toks = np.asarray(first_tokens, dtype=np.uint32).copy()
+        u = np.random.default_rng(seed).random((n_steps + 1, self.max_batch))
+        ins, sps = (_SlotInC * self.max_batch)(), (_SampleC * self.max_batch)()
+        for b in range(self.max_batch):
+            ins[b] = _SlotInC(C.cast(toks.ctypes.data + 4 * b, C.POINTER(C.c_uint32)) if b < B else None, 1 if b < B else 0, 0, 0)
+            sps[b] = _SampleC(top_p, top_k, temperature, 0.0, None, None, 0, 0, 0.0)
+        toks_o, probs_o = (C.c_uint32 * self.max_batch)(), (C.c_float * self.max_batch)()
+        emitted, consumed = (C.c_uint8 * self.max_batch)(), (C.c_size_t * self.max_batch)()
+        out_view = np.ctypeslib.as_array(toks_o)
+        l, h = lib(), self._h
+        _check(l.rwkv_infer_sample(h, ins, sps, toks_o, probs_o, emitted, consumed))
+        t = time.perf_counter()
+        for s_ in range(n_steps):
+            for b in range(B):
+                sps[b].uniform = u[s_, b]
+            rc = l.rwkv_infer_sample(h, ins, sps, toks_o, probs_o, emitted, consumed)
+            if rc:
+                _check(rc)
+            toks[:B] = out_view[:B]
+        return time.perf_counter() - t
 
     def profile_infer(self, inp: RnnInput):
         keep = self._prepare(inp)

@@ -184,35 +184,18 @@ def main():
                 sweep[str(nb)] = {"tokens_per_s": nb * args.steps / d2, "ms_per_step": d2 * 1e3 / args.steps,
                                   "frac_of_peak": abn["per_step"] * (args.steps / d2) / HBM_PEAK}
 
-    # PCIe-inclusive rate through rwkv_infer (logits D2H every token, as run.rs:809-832 does) — never `value`
+    # PCIe-inclusive rate through rwkv_infer (logits of every slot D2H every token, as run.rs:809-832 receives them) — never
+    # `value`.  Tight loops (runtime.serve_loop_*): one ABI call per step, nothing else on the host.
     pcie = None
     if rank == 0 and world == 1 and not args.decode_only:
-        nst = max(5, min(30, args.steps))
-        inp_tok = [int(x) for x in first]
-        t = time.perf_counter()
-        for _ in range(nst):
-            inp = rt.RnnInput([rt.RnnInputBatch([inp_tok[b]] if b < B else [], rt.RnnOption.Last)
-                               for b in range(eng.max_batch)])
-            _, outs = eng.infer(inp)
-        pcie = B * nst / (time.perf_counter() - t)
+        nst = max(5, min(40, args.steps))
+        pcie = B * nst / eng.serve_loop_logits(first, nst)
 
     # serving path with the on-device sampling front-end (rwkv_infer_sample: nucleus defaults, 8 bytes/slot over PCIe)
     sampled = None
     if rank == 0 and world == 1 and V <= 65536 and not args.decode_only:
-        from ai00_server_amd.harness import NucleusSampler
-        smp = [NucleusSampler() for _ in range(eng.max_batch)]
-        rng = np.random.default_rng(0)
-        cur = [int(x) for x in first]
-        nst = max(5, min(30, args.steps))
-        t = time.perf_counter()
-        for _ in range(nst):
-            inp = rt.RnnInput([rt.RnnInputBatch([cur[b]] if b < B else []) for b in range(eng.max_batch)])
-            _, outs = eng.infer_sample(inp, [smp[b] if b < B else None for b in range(eng.max_batch)],
-                                       [float(u) for u in rng.random(eng.max_batch)])
-            for b in range(B):
-                cur[b] = outs[b][0]
-                smp[b].update(cur[b])
-        sampled = B * nst / (time.perf_counter() - t)
+        nst = max(5, min(40, args.steps))
+        sampled = B * nst / eng.serve_loop_sample(first, nst)
 
     # second half of BASELINE's metric: embeddings/s = documents prefilled (256 tokens each, one per slot) and read
     # back as one layer's WKV rows (rwkv_state_back_layer) per second, same engine, rank 0 only
@@ -226,7 +209,7 @@ def main():
             for b in range(B):
                 eng.state.load(zero, b)
             t = time.perf_counter()
-            inp = rt.RnnInput([rt.RnnInputBatch(list(docs[b]) if b < B else [], rt.RnnOption.Last)
+            inp = rt.RnnInput([rt.RnnInputBatch(list(docs[b]) if b < B else [], rt.RnnOption.NoOutput)   # state-only: no head GEMM, no logits
                                for b in range(eng.max_batch)])
             while inp.num_token() > 0:
                 inp, _ = eng.infer(inp)

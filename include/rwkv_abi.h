@@ -101,7 +101,10 @@ int32_t rwkv_engine_max_batch(const rwkv_engine *e);
 uint64_t rwkv_engine_weight_bytes(const rwkv_engine *e);
 
 /* ---- `runtime.infer(RnnInput) -> (RnnInput, RnnOutput)` run.rs:1134-1156 ------------------ */
-enum { RWKV_OPTION_LAST = 0, RWKV_OPTION_FULL = 1 };            /* RnnOption, run.rs:716,819 */
+enum { RWKV_OPTION_LAST = 0, RWKV_OPTION_FULL = 1,              /* RnnOption, run.rs:716,819 */
+       RWKV_OPTION_NONE = 2 };   /* extension: consume the tokens, emit no row (state-only jobs: the documented `/embeddings`
+                                  * route, docs/doc-api/openai.md:376-437, reads back a state slice and never looks at logits);
+                                  * a step in which no slot emits skips the final LayerNorm, the head GEMM and the logits copy */
 typedef struct rwkv_slot_input {   /* RnnInputBatch::new(tokens, option) run.rs:1128 */
     const uint32_t *tokens;        /* remaining tokens of this slot (may be NULL if n_tokens==0) */
     size_t n_tokens;
@@ -120,6 +123,14 @@ typedef struct rwkv_slot_output {  /* RnnOutputBatch, run.rs:1146-1155 */
  * Last: one row when the slot's tokens are exhausted by this call.  Full: one row per token
  * consumed.  State of each touched slot is updated in place on the device. */
 rwkv_status rwkv_infer(rwkv_engine *e, const rwkv_slot_input *in, rwkv_slot_output *out);
+
+/* Pinned host memory for the `logits` buffers of rwkv_infer (the `TensorCpu<f32>` outputs of run.rs:1146-1155 are read back
+ * through mapped staging buffers in web-rwkv; this is the equivalent on the HIP side).  When every destination of a call is
+ * pinned, rows are copied device-to-host straight into it (destinations contiguous in slot order become one copy: hand the
+ * slots consecutive pieces of one block); pageable buffers still work and take a staged copy.  Any thread; free with
+ * rwkv_host_free. */
+rwkv_status rwkv_host_alloc(size_t bytes, void **out);
+void rwkv_host_free(void *p);
 
 /* The chunk policy of rwkv_infer as a pure host function (no device needed): how many of each slot's pending tokens one
  * call consumes — water-filling of `token_chunk_size`, so decode slots are never starved by a long prefill

@@ -1,0 +1,163 @@
+// rwkv_router.hpp — request-level sharding over N independent engines of one process (one engine per GPU): SURVEY §8 row (e).
+//
+// The path shards by REQUEST: a slot owns its recurrent state, weights are read-only, nothing is exchanged between
+// replicas (the reference itself is single-GPU: docs/doc-guide/FAQ.md:14-16; `run.rs:1121-1130` builds each batch from
+// independent slots).  So there is no collective and no RCCL here — only a routing decision on the host:
+//
+//   1. the replica whose prefix cache holds the LONGEST prefix of the request's tokens (the cache of `run.rs:443-485` is
+//      per replica, because a cached state can only be checked out into a slot of the engine that produced its layout and
+//      sits in that replica's host memory) — ties and misses fall through to
+//   2. the replica with the fewest busy slots (then the lowest index), skipping replicas that are full.
+//
+// Threading follows the reference's contract per engine (two long-lived caller threads: `infer` and `softmax`,
+// run.rs:1072-1190): every replica is driven by its OWN thread (`Replica::run`), which is the only thread that touches that
+// engine's scheduler; `submit` only appends to the replica's inbox under its mutex.  Header-only, no HIP: `Engine` is what
+// rwkv::Scheduler needs (include/rwkv_scheduler.hpp), so the CPU test runs it over fake engines.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+#include "rwkv_scheduler.hpp"
+
+namespace rwkv {
+
+struct RoutedRequest {
+    Tokens tokens;                                // the prompt (run.rs:489-492: empty => [0])
+    int max_new = 0;                              // greedy tokens to generate after the prompt (0: prefill only)
+    std::function<uint32_t(const std::vector<float> &)> sample;   // logits -> token; default arg-max (Nucleus top_k = 1)
+    // filled in by the replica thread
+    Tokens generated;
+    std::vector<float> last_output;
+    int replica = -1;
+    bool done = false;
+};
+
+template <class Engine>
+class ReplicaRouter {
+   public:
+    explicit ReplicaRouter(std::vector<Engine *> engines, size_t max_cached = 256) {
+        for (Engine *e : engines) reps_.emplace_back(new Replica(*e, max_cached));
+        for (auto &r : reps_) r->thread = std::thread([p = r.get()] { p->run(); });
+    }
+    ~ReplicaRouter() {
+        for (auto &r : reps_) { { std::lock_guard<std::mutex> g(r->mu); r->stop = true; } r->cv.notify_all(); }
+        for (auto &r : reps_) if (r->thread.joinable()) r->thread.join();
+    }
+    size_t size() const { return reps_.size(); }
+
+    // Routing decision for `tokens` (exposed for tests): {replica, matched prefix length}.
+    std::pair<int, size_t> route(const Tokens &tokens) {
+        int best = -1;
+        size_t best_len = 0;
+        for (size_t i = 0; i < reps_.size(); ++i) {                      // 1. prefix affinity
+            std::lock_guard<std::mutex> g(reps_[i]->mu);
+            if (reps_[i]->load() >= reps_[i]->capacity) continue;
+            const size_t len = reps_[i]->sched.cache().match_len(tokens);
+            if (len > best_len) { best_len = len; best = (int)i; }
+        }
+        if (best >= 0) return {best, best_len};
+        int least = -1, least_busy = 0;
+        for (size_t i = 0; i < reps_.size(); ++i) {                      // 2. least busy
+            std::lock_guard<std::mutex> g(reps_[i]->mu);
+            const int busy = reps_[i]->load();
+            if (busy >= reps_[i]->capacity) continue;
+            if (least < 0 || busy < least_busy) { least = (int)i; least_busy = busy; }
+        }
+        return {least, 0};
+    }
+
+    // Hand a request to a replica; returns the replica index, or -1 when every replica is full (the caller queues it, as the
+    // reference's `enqueue` task does with `SlotResult::Failure`, run.rs:1030-1062).  `req` must outlive its completion.
+    int submit(RoutedRequest *req) {
+        const auto where = route(req->tokens);
+        if (where.first < 0) return -1;
+        Replica &r = *reps_[(size_t)where.first];
+        {
+            std::lock_guard<std::mutex> g(r.mu);
+            req->replica = where.first;
+            r.inbox.push_back(req);
+            ++r.inflight;
+        }
+        r.cv.notify_all();
+        return where.first;
+    }
+    // Block until every submitted request has completed.
+    void drain() {
+        for (auto &r : reps_) {
+            std::unique_lock<std::mutex> g(r->mu);
+            r->idle_cv.wait(g, [&] { return r->inflight == 0; });
+        }
+    }
+    int busy(int replica) { std::lock_guard<std::mutex> g(reps_[(size_t)replica]->mu); return reps_[(size_t)replica]->load(); }
+    uint64_t steps(int replica) const { return reps_[(size_t)replica]->steps.load(); }
+
+   private:
+    struct Replica {
+        Scheduler<Engine> sched;
+        int capacity;
+        std::mutex mu;
+        std::condition_variable cv, idle_cv;
+        std::deque<RoutedRequest *> inbox;
+        int inflight = 0;                         // submitted and not yet completed (inbox + slots)
+        bool stop = false;
+        std::atomic<uint64_t> steps{0};
+        std::thread thread;
+        Replica(Engine &e, size_t max_cached) : sched(e, max_cached), capacity(e.max_batch) {}
+        int load() const { return inflight; }
+
+        // The replica's `infer` thread: admit what is in the inbox (slot choice + cache checkout, Scheduler::queue), run one
+        // device step over every slot with tokens pending, sample the slots whose prompt / token has been consumed.
+        void run() {
+            std::vector<RoutedRequest *> owner((size_t)capacity, nullptr);
+            for (;;) {
+                std::deque<RoutedRequest *> fresh;
+                {
+                    std::unique_lock<std::mutex> g(mu);
+                    cv.wait(g, [&] { return stop || !inbox.empty() || active(owner); });
+                    if (stop && inbox.empty() && !active(owner)) return;
+                    fresh.swap(inbox);
+                }
+                for (RoutedRequest *rq : fresh) {
+                    int b = -1;
+                    if (sched.queue(rq->tokens, b) == SlotResult::Failure) {     // cannot happen while inflight <= capacity
+                        std::lock_guard<std::mutex> g(mu);
+                        inbox.push_front(rq);
+                        continue;
+                    }
+                    owner[(size_t)b] = rq;
+                }
+                if (sched.pending()) { sched.step(); ++steps; }
+                for (int b = 0; b < capacity; ++b) {
+                    RoutedRequest *rq = owner[(size_t)b];
+                    if (!rq) continue;
+                    auto &r = sched.request(b);
+                    if (!r.suffix.empty() || r.output.empty()) continue;           // still reading tokens in
+                    if ((int)rq->generated.size() < rq->max_new) {
+                        const uint32_t t = rq->sample ? rq->sample(r.output)
+                                                      : (uint32_t)(std::max_element(r.output.begin(), r.output.end()) - r.output.begin());
+                        rq->generated.push_back(t);
+                        sched.push(b, t);
+                        continue;
+                    }
+                    rq->last_output = r.output;
+                    sched.finish(b);
+                    owner[(size_t)b] = nullptr;
+                    {
+                        std::lock_guard<std::mutex> g(mu);
+                        rq->done = true;
+                        --inflight;
+                    }
+                    idle_cv.notify_all();
+                }
+            }
+        }
+        static bool active(const std::vector<RoutedRequest *> &o) { for (auto *p : o) if (p) return true; return false; }
+    };
+    std::vector<std::unique_ptr<Replica>> reps_;
+};
+
+}  // namespace rwkv

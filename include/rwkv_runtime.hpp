@@ -22,7 +22,7 @@ struct Error : std::runtime_error {
 };
 inline void check(rwkv_status s) { if (s != RWKV_OK) throw Error(s); }
 
-enum class RnnOption : int32_t { Last = RWKV_OPTION_LAST, Full = RWKV_OPTION_FULL };
+enum class RnnOption : int32_t { Last = RWKV_OPTION_LAST, Full = RWKV_OPTION_FULL, None = RWKV_OPTION_NONE };
 enum class Quant : int32_t { None = RWKV_QUANT_NONE, Int8 = RWKV_QUANT_INT8, NF4 = RWKV_QUANT_NF4 };
 enum class Precision : int32_t { Fp16 = RWKV_PRECISION_FP16, Fp32 = RWKV_PRECISION_FP32 };
 using ModelInfo = rwkv_model_info;
@@ -68,9 +68,10 @@ class State {
 
 class Runtime {
    public:
-    Runtime(rwkv_engine *e) : e_(e, rwkv_engine_destroy), state(e) {
+    explicit Runtime(rwkv_engine *e, int chunk = 128) : e_(e, rwkv_engine_destroy), state(e) {
         check(rwkv_engine_info(e, &info));
         max_batch = rwkv_engine_max_batch(e);
+        token_chunk_size = chunk > 0 ? chunk : 128;
     }
     // runtime.infer(input) -> output; `input` is consumed in place (tokens drained by n_consumed)
     std::vector<RnnOutputBatch> infer(RnnInput &input) {
@@ -80,10 +81,13 @@ class Runtime {
         std::vector<RnnOutputBatch> bufs(max_batch);
         for (int b = 0; b < max_batch; ++b) {
             auto &ib = input.batches[b];
-            const size_t rows = ib.option == RnnOption::Full ? std::max<size_t>(1, ib.tokens.size()) : 1;
+            // one call emits at most token_chunk_size rows for a slot however long its pending token list is (an 8k-token Full
+            // request must not allocate 8k x V floats per call); slots without tokens and state-only slots need no buffer
+            const size_t rows = ib.tokens.empty() || ib.option == RnnOption::None ? 0
+                               : ib.option == RnnOption::Full ? std::min(ib.tokens.size(), (size_t)token_chunk_size) : 1;
             bufs[b].resize(rows * (size_t)info.num_vocab);
             in[b] = rwkv_slot_input{ib.tokens.data(), ib.tokens.size(), (int32_t)ib.option, 0};
-            out[b] = rwkv_slot_output{bufs[b].data(), rows, 0, 0};
+            out[b] = rwkv_slot_output{rows ? bufs[b].data() : nullptr, rows, 0, 0};
         }
         check(rwkv_infer(e_.get(), in.data(), out.data()));
         for (int b = 0; b < max_batch; ++b) {
@@ -96,6 +100,7 @@ class Runtime {
     rwkv_engine *raw() const { return e_.get(); }
     ModelInfo info{};
     int max_batch = 0;
+    int token_chunk_size = 128;                  // tokens one infer call consumes at most (bounds the rows of a Full request)
    private:
     std::shared_ptr<rwkv_engine> e_;
    public:
@@ -112,7 +117,7 @@ class ModelBuilder {
         d_.lora = lora_.empty() ? nullptr : lora_.data(); d_.n_lora = lora_.size();
         rwkv_engine *e = nullptr;
         check(rwkv_engine_create(&d_, &e));
-        return Runtime(e);
+        return Runtime(e, token_chunk_size);
     }
    private:
     rwkv_load_desc d_{};
@@ -120,6 +125,8 @@ class ModelBuilder {
 };
 
 inline std::vector<std::vector<float>> softmax(Runtime &rt, const std::vector<std::vector<float>> &rows) {
+    for (const auto &r : rows)                    // rwkv_softmax reads num_vocab floats per row: a short row would be read out of bounds
+        if (r.size() != (size_t)rt.info.num_vocab) throw std::invalid_argument("softmax: every row must hold num_vocab values");
     std::vector<std::vector<float>> out(rows.size());
     std::vector<const float *> pi(rows.size());
     std::vector<float *> po(rows.size());

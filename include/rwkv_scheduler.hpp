@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <vector>
 
@@ -41,6 +42,7 @@ class PrefixCache {                              // `Trie<Tokens, CachedItem>` k
     struct Checkout { size_t prefix_len = 0; std::vector<float> state, output; bool hit = false; };
     // longest cached key that is a prefix of `tokens` (run.rs:447-455); refreshes the item's stamp (CachedItem::update)
     Checkout checkout(const Tokens &tokens, uint64_t now) {
+        std::lock_guard<std::mutex> g(mu_);
         Checkout c;
         Node *n = &root_;
         Node *best = nullptr;
@@ -57,7 +59,21 @@ class PrefixCache {                              // `Trie<Tokens, CachedItem>` k
         }
         return c;
     }
+    // length of the longest cached key that is a prefix of `tokens`, without touching stamps (the router's affinity probe)
+    size_t match_len(const Tokens &tokens) const {
+        std::lock_guard<std::mutex> g(mu_);
+        const Node *n = &root_;
+        size_t best = 0;
+        for (size_t i = 0; i < tokens.size(); ++i) {
+            auto it = n->next.find(tokens[i]);
+            if (it == n->next.end()) break;
+            n = it->second.get();
+            if (n->item) best = i + 1;
+        }
+        return best;
+    }
     bool contains(const Tokens &tokens) const {                                     // `cache.contains_key`, run.rs:795
+        std::lock_guard<std::mutex> g(mu_);
         const Node *n = &root_;
         for (uint32_t t : tokens) {
             auto it = n->next.find(t);
@@ -68,6 +84,7 @@ class PrefixCache {                              // `Trie<Tokens, CachedItem>` k
     }
     void insert(const Tokens &tokens, std::vector<float> state, std::vector<float> output, uint64_t now) {
         if (tokens.empty()) return;
+        std::lock_guard<std::mutex> g(mu_);
         Node *n = &root_;
         for (uint32_t t : tokens) {
             auto &slot = n->next[t];
@@ -79,8 +96,8 @@ class PrefixCache {                              // `Trie<Tokens, CachedItem>` k
         touch(n, now);
         while (count_ > max_cached_) evict_oldest();                                // `Cache::maintain`, run.rs:237-257
     }
-    size_t size() const { return count_; }
-    size_t nodes() const { return count_nodes(&root_) - 1; }                        // trie nodes alive (tests: eviction prunes)
+    size_t size() const { std::lock_guard<std::mutex> g(mu_); return count_; }
+    size_t nodes() const { std::lock_guard<std::mutex> g(mu_); return count_nodes(&root_) - 1; }   // trie nodes alive (tests: eviction prunes)
 
    private:
     struct Node {
@@ -114,6 +131,9 @@ class PrefixCache {                              // `Trie<Tokens, CachedItem>` k
             n = parent;
         }
     }
+    // one engine's scheduler owns the cache, but the router thread probes it (match_len) while that replica's thread inserts:
+    // every public method takes the lock (the critical sections are a trie walk plus, for checkout, one state copy)
+    mutable std::mutex mu_;
     Node root_;
     std::multimap<uint64_t, Node *> by_age_;                                       // stamp -> node: eviction is O(log n), not a trie walk
     size_t count_ = 0, max_cached_;

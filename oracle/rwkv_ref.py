@@ -844,11 +844,16 @@ def algorithmic_bytes(info: ModelInfo, tensors_shapes: dict[str, tuple], quant_l
 # --------------------------------------------------------------------------------------
 def nucleus_ref(probs: np.ndarray, top_p: float, top_k: int, temperature: float, u: float):
     """`NucleusSampler::sample` (nucleus.rs:69-101) with the random draw `u` made explicit.
-    Sort descending (ties: lower id first), take top_k, keep while the cumulative sum BEFORE the element is <= top_p
-    (the first is always kept), p^(1/T), renormalise, first element with u <= cumulative, else the FIRST element
-    (`find_or_first`).  Returns (token, margin) where margin is the distance of the decisive comparison."""
+    Sort descending, take top_k, keep while the cumulative sum BEFORE the element is <= top_p (the first is always kept),
+    p^(1/T), renormalise, first element with u <= cumulative, else the FIRST element (`find_or_first`); `top_k = 0` keeps
+    nothing and the `unwrap_or_default` at nucleus.rs:101 yields token 0.  Ties: the reference sorts with `voracious_sort`
+    (nucleus.rs:76), an UNSTABLE radix sort, so the order of equal probabilities is not defined by the reference; this
+    restatement (and the device kernel) fix it as lower id first.
+    Returns (token, margin) where margin is the distance of the decisive comparison."""
     p = probs.astype(np.float32)
-    order = np.lexsort((np.arange(p.size), -p))[:max(1, top_k)]
+    if top_k < 1:
+        return 0, 1.0
+    order = np.lexsort((np.arange(p.size), -p))[:top_k]
     kept, cum = [], np.float32(0.0)
     for i in order:
         if cum > np.float32(top_p):
@@ -883,7 +888,9 @@ def typical_ref(probs: np.ndarray, tau: float, top_k: int, temperature: float, u
         h = np.float32(h + np.float32(a * b))
     h = np.float32(h + np.float32(h_shift))
     key = np.abs(y - h).astype(np.float32)
-    order = np.lexsort((ids, key))[:max(1, top_k)]
+    if top_k < 1:
+        return 0, 1.0                                                   # `.take(0)` -> `unwrap_or_default` (typical.rs:87, 117)
+    order = np.lexsort((ids, key))[:top_k]
     kept, cum = [], np.float32(0.0)
     for o in order:
         if cum > np.float32(tau):

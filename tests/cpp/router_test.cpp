@@ -1,0 +1,88 @@
+// CPU test of include/rwkv_router.hpp over fake engines (no GPU, no HIP): prefix affinity, least-busy placement, full
+// replicas skipped, per-replica threads, results identical to a single-engine run.
+#include <cassert>
+#include <cstdio>
+
+#include "../../include/rwkv_router.hpp"
+#include "fake_engine.hpp"
+
+#define CHECK(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+static rwkv::Tokens greedy_alone(const rwkv::Tokens &prompt, int n_new) {
+    FakeEngine e(1, 1000);
+    std::vector<FakeEngine *> es{&e};
+    rwkv::ReplicaRouter<FakeEngine> r(es);
+    rwkv::RoutedRequest q;
+    q.tokens = prompt; q.max_new = n_new;
+    assert(r.submit(&q) == 0);
+    r.drain();
+    return q.generated;
+}
+
+int main() {
+    using namespace rwkv;
+    // --- 8 replicas x 4 slots, 64 requests: every request completes, answers equal the single-engine answers, load spreads
+    {
+        std::vector<std::unique_ptr<FakeEngine>> engines;
+        std::vector<FakeEngine *> es;
+        for (int i = 0; i < 8; ++i) { engines.emplace_back(new FakeEngine(4, 3)); es.push_back(engines.back().get()); }
+        ReplicaRouter<FakeEngine> router(es);
+        std::vector<RoutedRequest> reqs(64);
+        for (int i = 0; i < 64; ++i) {
+            reqs[(size_t)i].tokens = Tokens{(uint32_t)(i % 7 + 1), (uint32_t)(i % 5 + 2), (uint32_t)(i + 3)};
+            reqs[(size_t)i].max_new = 5 + i % 3;
+        }
+        size_t next = 0;
+        while (next < reqs.size()) {                                     // `enqueue`: retry while every replica is full
+            if (router.submit(&reqs[next]) >= 0) ++next;
+            else std::this_thread::yield();
+        }
+        router.drain();
+        int used = 0;
+        for (int r = 0; r < 8; ++r) used += router.steps(r) > 0;
+        CHECK(used == 8);                                                // least-busy placement reaches every replica
+        for (auto &q : reqs) {
+            CHECK(q.done && q.replica >= 0 && (int)q.generated.size() == q.max_new);
+            CHECK(q.generated == greedy_alone(q.tokens, q.max_new));
+        }
+    }
+    // --- prefix affinity: a follow-up that extends a finished request goes to the replica that cached it, even if that
+    //     replica is busier than the others, and continues from the cached state
+    {
+        FakeEngine e0(4, 100), e1(4, 100), e2(4, 100);
+        std::vector<FakeEngine *> es{&e0, &e1, &e2};
+        ReplicaRouter<FakeEngine> router(es);
+        RoutedRequest a, b, c;
+        a.tokens = {9, 8, 7, 6}; a.max_new = 3;
+        b.tokens = {1, 2}; b.max_new = 2;
+        CHECK(router.submit(&a) == 0);                                   // all idle: lowest index
+        CHECK(router.submit(&b) == 1);                                   // replica 0 has one in flight: least busy is 1
+        router.drain();
+        Tokens follow = a.tokens;
+        follow.insert(follow.end(), a.generated.begin(), a.generated.end());       // what replica 0 cached at finish: prompt + every fed token
+        follow.push_back(42);
+        RoutedRequest hold;                                              // make replica 0 the busiest
+        hold.tokens = {5, 5, 5}; hold.max_new = 200;
+        CHECK(router.submit(&hold) == 0);
+        const auto where = router.route(follow);
+        CHECK(where.first == 0 && where.second == follow.size() - 1);
+        c.tokens = follow; c.max_new = 4;
+        const int calls0 = e0.calls;
+        CHECK(router.submit(&c) == 0);
+        router.drain();
+        CHECK(c.done && c.generated == greedy_alone(follow, 4));
+        CHECK(e0.calls > calls0);
+    }
+    // --- a full replica is skipped; with every replica full submit() reports -1
+    {
+        FakeEngine e0(1, 100), e1(1, 100);
+        std::vector<FakeEngine *> es{&e0, &e1};
+        RoutedRequest a, b, c;                                           // declared before the router: they outlive its threads
+        a.tokens = {1}; a.max_new = 100000; b.tokens = {2}; b.max_new = 100000; c.tokens = {3}; c.max_new = 1;
+        ReplicaRouter<FakeEngine> router(es);
+        CHECK(router.submit(&a) == 0 && router.submit(&b) == 1);
+        CHECK(router.submit(&c) == -1);
+    }   // the router's destructor stops the replica threads with requests still running
+    std::printf("router_test: ok\n");
+    return 0;
+}

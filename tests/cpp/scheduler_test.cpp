@@ -6,45 +6,9 @@
 
 #include "../../include/rwkv_scheduler.hpp"
 
+#include "fake_engine.hpp"
+
 namespace {
-struct FakeState {
-    std::vector<std::vector<float>> slots;
-    std::vector<float> init() const { return {1.0f, 0.0f}; }
-    void load(const std::vector<float> &t, int b) { slots.at((size_t)b) = t; }
-    std::vector<float> back(int b) { return slots.at((size_t)b); }
-};
-// state = (hash, count); a token updates hash = fmod(hash * 31 + tok + 1, 65521); logits[i] = fmod(hash + 7 i, 13)
-struct FakeEngine {
-    int max_batch;
-    rwkv::ModelInfo info{};
-    FakeState state;
-    int chunk;            // tokens a slot may consume per infer call (like token_chunk_size / active slots)
-    int calls = 0;
-    std::vector<int> riders;
-    FakeEngine(int B, int chunk_) : max_batch(B), chunk(chunk_) { info.num_vocab = 8; state.slots.assign((size_t)B, state.init()); }
-    std::vector<rwkv::RnnOutputBatch> infer(rwkv::RnnInput &in) {
-        ++calls;
-        int n = 0;
-        std::vector<rwkv::RnnOutputBatch> out((size_t)max_batch);
-        for (int b = 0; b < max_batch; ++b) {
-            auto &t = in.batches[(size_t)b].tokens;
-            if (t.empty()) continue;
-            ++n;
-            const size_t take = std::min<size_t>(t.size(), (size_t)chunk);
-            for (size_t i = 0; i < take; ++i) {
-                auto &s = state.slots[(size_t)b];
-                s[0] = std::fmod(s[0] * 31.0f + (float)t[i] + 1.0f, 65521.0f);
-                s[1] += 1.0f;
-                const bool last = i + 1 == t.size();
-                if (in.batches[(size_t)b].option == rwkv::RnnOption::Full || last)
-                    for (int v = 0; v < 8; ++v) out[(size_t)b].push_back(std::fmod(s[0] + 7.0f * v, 13.0f));
-            }
-            t.erase(t.begin(), t.begin() + (long)take);
-        }
-        riders.push_back(n);
-        return out;
-    }
-};
 std::vector<float> run_alone(const rwkv::Tokens &toks) {
     FakeEngine e(1, 1000);
     rwkv::Scheduler<FakeEngine> s(e);

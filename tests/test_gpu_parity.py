@@ -430,6 +430,71 @@ def test_on_device_nucleus_sampling_matches_reference_sampler():
     eng.close()
 
 
+def test_on_device_sampling_full_vocabulary_ties_and_top_k_zero():
+    """The V = 65536 instantiation of the sampling kernel (no bound predicates), on a one-layer model whose head holds 8000
+    copies of the arg-max row: an 8001-way tie at the top of the distribution, more than the candidate buffer holds, so the
+    candidate set has to come from the id-bound search (lowest ids first, as the oracle's restatement orders ties — the
+    reference's own tie order is undefined, its sort is unstable, nucleus.rs:76).  Also `top_k = 0` (nothing kept ->
+    `unwrap_or_default` -> token 0, nucleus.rs:78-101) and a plain row without ties."""
+    from ai00_server_amd.harness import NucleusSampler
+    tens = R.synth_checkpoint(6, 1, 128, 448, 65536, seed=5)
+    p = [int(x) for x in R.synth_prompt(90, 5)]
+    base = R.RwkvRef(tens).forward(p, R.RwkvRef(tens).init_state())[-1]
+    a = int(np.argmax(base))
+    tens["head.weight"][1000:9000] = tens["head.weight"][a]
+    ref = R.RwkvRef(tens)
+    logits = ref.forward(p, ref.init_state())[-1]
+    assert (logits[1000:9000] == logits[a]).all() and logits.max() == logits[a]
+    probs = R.softmax_ref(logits[None])[0]
+    eng = rt.ModelBuilder(R.st_serialize(tens)).build(max_batch=4, token_chunk_size=16, precision=rt.Precision.Fp32)
+    rows = run_prompts(eng, [p])[0]
+    dev_probs = R.softmax_ref(rows[0][None])[0]
+    ties = np.nonzero(dev_probs == dev_probs.max())[0]
+    assert len(ties) >= 8000                                              # the device logits tie too (identical head rows)
+    rng = np.random.default_rng(3)
+    checked = 0
+    for top_k, top_p, temp in [(256, 1.0, 1.0), (40, 1.0, 0.8), (256, 0.5, 1.3), (1, 0.0, 1.0)]:
+        for _ in range(6):
+            u = float(rng.random())
+            want, margin = R.nucleus_ref(dev_probs, top_p, top_k, temp, u)
+            smp = NucleusSampler(top_p=top_p, top_k=top_k, temperature=temp, presence_penalty=0.0, frequency_penalty=0.0)
+            for b in range(4):
+                eng.state.load(eng.state.init(), b)
+            inp = rt.RnnInput([rt.RnnInputBatch(list(p))] + [rt.RnnInputBatch() for _ in range(3)])
+            _, out = eng.infer_sample(inp, [smp, None, None, None], [u, 0.0, 0.0, 0.0])
+            if margin > 1e-4:
+                assert out[0][0] == want, (top_k, top_p, temp, u, out[0], want)
+                checked += 1
+    assert checked >= 18
+    smp = NucleusSampler(top_p=0.5, top_k=0, presence_penalty=0.0, frequency_penalty=0.0)
+    eng.state.load(eng.state.init(), 0)
+    _, out = eng.infer_sample(rt.RnnInput([rt.RnnInputBatch(list(p))] + [rt.RnnInputBatch() for _ in range(3)]), [smp, None, None, None], [0.3, 0, 0, 0])
+    assert out[0][0] == 0
+    eng.close()
+
+
+def test_infer_into_pageable_and_pinned_destinations():
+    """rwkv_infer copies logits straight into pinned destinations (rwkv_host_alloc; the Python mirror hands out pieces of one
+    pinned block) and stages them for pageable ones: same bits either way, also for scattered per-slot buffers."""
+    import ctypes as C
+    t, eng = build("v6-small", rt.Precision.Fp16, B=3, chunk=16)
+    ref = R.RwkvRef(t)
+    ps = [prompt(ref, 80 + b, 4 + b) for b in range(3)]
+    want = run_prompts(eng, ps)                                          # pinned path (runtime arena)
+    V = ref.info.num_vocab
+    for b in range(3):
+        eng.state.load(eng.state.init(), b)
+    bufs = [np.full((1, V), np.nan, np.float32) for _ in range(3)]      # pageable, not contiguous
+    toks = [np.asarray(x, dtype=np.uint32) for x in ps]
+    ins = (rt._SlotInC * 3)(*[rt._SlotInC(toks[b].ctypes.data_as(C.POINTER(C.c_uint32)), toks[b].size, 0, 0) for b in range(3)])
+    outs = (rt._SlotOutC * 3)(*[rt._SlotOutC(bufs[b].ctypes.data_as(C.POINTER(C.c_float)), 1, 0, 0) for b in range(3)])
+    rt._check(rt.lib().rwkv_infer(eng._h, ins, outs))
+    for b in range(3):
+        assert outs[b].n_rows == 1 and outs[b].n_consumed == len(ps[b])
+        np.testing.assert_array_equal(bufs[b][0], want[b][0])
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["v5-small", "v6-small", "v7-small"])
 def test_single_token_steps_with_ln_prologue_interleave_with_chunks(name):
     """T = 1 steps run LayerNorm + token shift as a prologue of the consuming kernel and commit the shift state in
