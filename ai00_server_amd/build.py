@@ -14,7 +14,9 @@ LIB = os.path.join(HERE, "librwkv_hip.so")
 SOURCES = ["rwkv_kernels.hip", "rwkv_engine.cpp", "tokenizer.cpp"]
 DEPS = SOURCES + ["rwkv_kernels.h", "safetensors.hpp", os.path.join("..", "..", "include", "rwkv_abi.h"),
                os.path.join("..", "..", "include", "rwkv_runtime.hpp"), os.path.join("..", "..", "include", "rwkv_scheduler.hpp"),
-               os.path.join("..", "..", "harness", "decode_loop.cpp"), os.path.join("..", "..", "harness", "serve_loop.cpp")]
+               os.path.join("..", "..", "include", "rwkv_router.hpp"),
+               os.path.join("..", "..", "harness", "decode_loop.cpp"), os.path.join("..", "..", "harness", "serve_loop.cpp"),
+               os.path.join("..", "..", "harness", "router_loop.cpp")]
 
 
 def _hipcc() -> str:
@@ -39,7 +41,7 @@ def _sources_digest() -> str:
 
 def needs_build() -> bool:
     """Content-based (mtimes do not survive the copy to a GPU box): rebuild when a source differs from the stamp."""
-    if not os.path.exists(LIB) or not os.path.exists(HARNESS_BIN) or not os.path.exists(SERVE_BIN) or not os.path.exists(STAMP):
+    if not all(os.path.exists(p) for p in (LIB, HARNESS_BIN, SERVE_BIN, ROUTER_BIN, STAMP)):
         return True
     return open(STAMP).read().strip() != _sources_digest()
 
@@ -88,12 +90,14 @@ HARNESS_SRC = os.path.join(HERE, "..", "harness", "decode_loop.cpp")
 HARNESS_BIN = os.path.join(HERE, "..", "harness", "decode_loop")
 SERVE_SRC = os.path.join(HERE, "..", "harness", "serve_loop.cpp")
 SERVE_BIN = os.path.join(HERE, "..", "harness", "serve_loop")
+ROUTER_SRC = os.path.join(HERE, "..", "harness", "router_loop.cpp")
+ROUTER_BIN = os.path.join(HERE, "..", "harness", "router_loop")
 
 
 def build_harness(verbose: bool = True) -> str:
     """C++ mirror of ai00-core's infer task + greedy loop (harness/decode_loop.cpp), linked against the .so."""
-    for src, exe in ((HARNESS_SRC, HARNESS_BIN), (SERVE_SRC, SERVE_BIN)):
-        cmd = ["g++", "-O2", "-std=c++17", src, "-o", exe, "-L" + HERE, "-lrwkv_hip", "-Wl,-rpath," + HERE]
+    for src, exe in ((HARNESS_SRC, HARNESS_BIN), (SERVE_SRC, SERVE_BIN), (ROUTER_SRC, ROUTER_BIN)):
+        cmd = ["g++", "-O2", "-std=c++17", "-pthread", src, "-o", exe, "-L" + HERE, "-lrwkv_hip", "-Wl,-rpath," + HERE]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -99,11 +99,11 @@ struct Prefab {
         validate_info(p.hdr.info);
         size_t off = sizeof(PfHeader);
         // every length comes from the file: compare against what is LEFT (len > n - off), never off + len (which can wrap)
-        auto take = [&](uint64_t len) -> const uint8_t * {
+        auto take = [&](uint64_t len) -> const uint8_t * {            // `len` bytes at `off`, then `off` up to the next 16-byte FILE offset
             if (off > n || len > (uint64_t)(n - off)) throw RwkvError(RWKV_ERR_FORMAT, "prefab truncated");
             const uint8_t *q = b + off;
-            const uint64_t padded = (len + 15) & ~(uint64_t)15;
-            off = padded > (uint64_t)(n - off) ? n : off + (size_t)padded;
+            const size_t end = off + (size_t)len;                     // <= n (an in-memory size): neither this nor + 15 can wrap
+            off = std::min(n, (end + 15) & ~(size_t)15);              // padding cut off at the end of the file is harmless
             return q;
         };
         for (uint32_t i = 0; i < p.hdr.n_entries; ++i) {
@@ -888,6 +888,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
             g.out_hi = s.oh.hi; g.out_lo = s.oh.lo; g.ldh = s.oh.ld;
         }
         Lh.total_blocks = blocks;
+        { const char *ev = std::getenv("RWKV_TILE_XCD"); Lh.xcd_map = (ev && *ev) ? std::atoi(ev) : 1; }   // A/B switch, read per call
         launch(fam, [&] { launch_gemm_tile(Lh, shape, hilo, s_main); });
         return 1;
     }
@@ -1699,6 +1700,7 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
                     g.xhi = x.hi; g.xlo = x.lo; g.ldx = K; g.ksb = 1; g.block_begin = 0;
                     g.out_f32 = out; g.ldo = rows;
                     Lh.total_blocks = gemm_tile_blocks(shape, rows, T);
+                    { const char *ev = std::getenv("RWKV_TILE_XCD"); Lh.xcd_map = (ev && *ev) ? std::atoi(ev) : 1; }
                     if (lds_kib) *lds_kib = (float)Lh.total_blocks;
                     launch_gemm_tile(Lh, shape, hilo != 0, st);
                     continue;

@@ -104,6 +104,7 @@ struct GemmLaunch {
     int single_shot;                // every problem's rounds per wave fit in registers: issue all loads up-front
     int tail;                       // some fp16 problem has a K range that is not a multiple of 256: predicated variant
     int total_blocks;
+    int xcd_map;                    // prefill tile GEMM: XCD-banded tile numbering (rwkv_kernels.hip tg_body)
     LnProArgs lnp;
     ShiftCommit commit;             // grid = total_blocks + 1 when commit.src is set
 };

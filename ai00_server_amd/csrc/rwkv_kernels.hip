@@ -1057,10 +1057,22 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
     constexpr int BT = NTL * 16, THREADS = WAVES * 64, STRIPS = WAVES * SPW, TG_KC = KC, TG_STRIDE = KC + 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lb = (int)blockIdx.x - P.block_begin;
-    const int ntt = (L.T + BT - 1) / BT;                          // token tiles
-    const int rb = lb / ntt, tt = lb - rb * ntt;
     const int nstrips = P.rows >> 4;
+    const int ntt = (L.T + BT - 1) / BT;                          // token tiles
+    // Tile of this block.  Workgroups go round-robin to the 8 XCDs (block b -> XCD b % 8, observed placement; only speed
+    // depends on it) and every XCD has its own 4 MiB L2.  With the plain row-major numbering each XCD touches every weight
+    // strip AND every token tile; instead the tiles are numbered so that the blocks an XCD receives, in its dispatch order,
+    // walk one contiguous band of the row-major tile sequence: the XCD streams 1/8 of the weight strips once and re-reads
+    // them for its token tiles out of its own L2.  (A bijection for any grid; L.xcd_map = 0 restores row-major.)
+    int lb = (int)blockIdx.x - P.block_begin;
+    if (L.xcd_map) {
+        const int nb = ((nstrips + STRIPS - 1) / STRIPS) * ntt;   // tiles of this problem
+        const int k = lb & 7, j = lb >> 3;                        // XCD class relative to the problem's first block, rank in it
+        int start = 0;
+        for (int m = 0; m < k; ++m) start += (nb - m + 7) >> 3;   // tiles owned by the classes before this one
+        lb = start + j;
+    }
+    const int rb = lb / ntt, tt = lb - rb * ntt;
     const int strip = rb * STRIPS + wave * SPW;
     const int t0 = tt * BT;
     const int K = P.K;

@@ -1,0 +1,61 @@
+// router_loop.cpp — include/rwkv_router.hpp over REAL engines: N replicas of one model (all on the device given, so the N>1
+// path can be exercised on a one-GPU box; in production each replica names its own device index), every replica driven by
+// its own thread, requests routed by prefix affinity then least busy (replicas only, no collective).
+// Prints one line per request: "<replica> <generated token ids...>"; tests/test_gpu_parity.py compares with the oracle.
+// Usage: router_loop <model.st> <n_replicas> <device> <max_batch> <chunk> <n_new> <prompt ...> [/ <prompt ...>]...
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+
+#include "../include/rwkv_router.hpp"
+
+int main(int argc, char **argv) {
+    if (argc < 8) { std::fprintf(stderr, "usage: see header\n"); return 2; }
+    try {
+        std::ifstream f(argv[1], std::ios::binary);
+        std::vector<uint8_t> st((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        const int n_rep = std::atoi(argv[2]), dev = std::atoi(argv[3]), B = std::atoi(argv[4]), chunk = std::atoi(argv[5]), n_new = std::atoi(argv[6]);
+        std::vector<rwkv::Tokens> prompts(1);
+        for (int i = 7; i < argc; ++i) {
+            if (!std::strcmp(argv[i], "/")) prompts.emplace_back();
+            else prompts.back().push_back((uint32_t)std::strtoul(argv[i], nullptr, 10));
+        }
+        std::vector<rwkv::Runtime> rts;
+        for (int r = 0; r < n_rep; ++r) rts.push_back(rwkv::ModelBuilder(st.data(), st.size(), dev).build(B, chunk, rwkv::Precision::Fp16));
+        std::vector<rwkv::Runtime *> es;
+        for (auto &r : rts) es.push_back(&r);
+        std::vector<rwkv::RoutedRequest> reqs(prompts.size());
+        {
+            rwkv::ReplicaRouter<rwkv::Runtime> router(es);
+            for (size_t i = 0; i < prompts.size(); ++i) {
+                reqs[i].tokens = prompts[i];
+                reqs[i].max_new = n_new;
+                while (router.submit(&reqs[i]) < 0) std::this_thread::yield();   // every replica full: retry, like `enqueue`
+            }
+            router.drain();
+            // second wave: request 0 again, extended by its own output — must return to the replica that cached it
+            rwkv::RoutedRequest again;
+            again.tokens = prompts[0];
+            again.tokens.insert(again.tokens.end(), reqs[0].generated.begin(), reqs[0].generated.end());
+            again.tokens.push_back(reqs[0].generated.empty() ? 1u : reqs[0].generated.back());
+            again.max_new = n_new;
+            const auto where = router.route(again.tokens);
+            router.submit(&again);
+            router.drain();
+            for (auto &q : reqs) {
+                std::printf("%d", q.replica);
+                for (auto t : q.generated) std::printf(" %u", t);
+                std::printf("\n");
+            }
+            std::printf("%d", again.replica);
+            for (auto t : again.generated) std::printf(" %u", t);
+            std::printf("\nmeta %d %zu %d\n", where.first, where.second, reqs[0].replica);
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+}

@@ -22,6 +22,7 @@
 #include <memory>
 #include <mutex>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "rwkv_runtime.hpp"
@@ -157,6 +158,31 @@ struct SlotChoice {                              // run.rs:304-331
     }
 };
 
+// Stop-string scan of the `process` loop (run.rs:899-932), byte for byte: for every stop string walk the text buffer keeping
+// `index_safe` (everything before it can no longer be part of a match) and report (index_safe, fully matched); the winner is a
+// matched stop before an unmatched one, then the smallest index.  The caller emits buffer[..head] and keeps the tail.
+struct StopScan { size_t head = 0; bool matched = false; };
+inline StopScan scan_stops(const std::vector<uint8_t> &buffer, const std::vector<std::string> &stops) {
+    bool have = false;
+    StopScan best{buffer.size(), false};                              // no stop strings: everything is safe (`unwrap_or`)
+    for (const std::string &stop : stops) {
+        size_t index_safe = 0, index_unsafe = 0;
+        StopScan cur;
+        bool done = false;
+        while (index_unsafe < buffer.size()) {
+            const size_t index_stop = index_unsafe - index_safe;
+            if (index_stop >= stop.size()) { cur = StopScan{index_safe, true}; done = true; break; }
+            const uint8_t out = buffer[index_unsafe], st = (uint8_t)stop[index_stop];
+            ++index_unsafe;
+            if (out != st) index_safe = index_unsafe;
+        }
+        if (!done) cur = StopScan{index_safe, index_unsafe - index_safe >= stop.size()};
+        const bool better = !have || (cur.matched && !best.matched) || (cur.matched == best.matched && cur.head < best.head);
+        if (better) { best = cur; have = true; }
+    }
+    return best;
+}
+
 enum class SlotResult { Success, Fault, Failure };   // run.rs: Success(batch) / Fault(batch) (had to back a slot) / Failure (all busy)
 
 template <class Engine>
@@ -167,15 +193,26 @@ class Scheduler {
         std::vector<float> output;               // logits after the last consumed token (empty until one exists)
         RnnOption option = RnnOption::Last;
         std::vector<std::vector<float>> rows;    // Full: one entry per emitted row
+        uint64_t state_id = 0;                   // `request.state.id()`: which initial state / cache the request lives in (run.rs:443-447)
         size_t prompt_len = 0;                   // tokens of the request as queued (the "prompt", run.rs:794)
         bool cache_prompt = false;               // CachedPrompt::Future: cache the state when the prompt has been consumed
     };
 
     static constexpr size_t kMinPromptCacheTokens = 32;                          // MIN_PROMPT_CACHE_TOKENS, run.rs:40
-    explicit Scheduler(Engine &e, size_t max_cached = 256) : e_(e), slots_(e.max_batch), reqs_(e.max_batch), cache_(max_cached) {}
+    explicit Scheduler(Engine &e, size_t max_cached = 256) : e_(e), slots_(e.max_batch), reqs_(e.max_batch), max_cached_(max_cached) {}
+
+    // `check_in_state` (run.rs:376-437): a state-tuned initial state registered under an id gets its OWN prefix cache
+    // (`Cache { state: Some(state), cache: Trie::new() }`); requests that name the id start from it instead of the zero state.
+    // `slab` is what rwkv_read_init_state / `vN::read_state` produced (lib.rs:378-389).  Id 0 is the default (no init state).
+    void check_in_state(uint64_t id, std::vector<float> slab) {
+        if (id == 0) throw std::invalid_argument("state id 0 is the default state");
+        init_states_[id] = std::move(slab);
+        caches_.erase(id);
+    }
 
     // run.rs:488-626.  On Success / Fault `batch` is the slot now Busy with the request.
-    SlotResult queue(Tokens tokens, int &batch, RnnOption option = RnnOption::Last) {
+    SlotResult queue(Tokens tokens, int &batch, RnnOption option = RnnOption::Last, uint64_t state_id = 0) {
+        if (state_id != 0 && !init_states_.count(state_id)) throw std::invalid_argument("unknown state id");
         if (tokens.empty()) tokens = {0};                              // run.rs:489-492
         ++clock_;
         bool have = false;
@@ -200,19 +237,22 @@ class Scheduler {
         // (The reference does this for all three choices, Continue included: run.rs:548-626.)
         // A request that is cached whole starts with an empty suffix and the cached output row: the process loop samples from
         // it without touching the engine (`(0, Some(output)) => output`, run.rs:809-811).
-        PrefixCache::Checkout co = cache_.checkout(tokens, clock_);
+        PrefixCache &cache = cache_of(state_id);
+        PrefixCache::Checkout co = cache.checkout(tokens, clock_);
         const size_t len = co.hit ? co.prefix_len : 0;
         if (co.hit) e_.state.load(co.state, batch);
+        else if (state_id != 0) e_.state.load(init_states_[state_id], batch);       // `state.unwrap_or_else(|| self.state.init())`, run.rs:476-477
         else e_.state.load(e_.state.init(), batch);
         Request r;
         r.prefix.assign(tokens.begin(), tokens.begin() + (long)len);
         r.suffix.assign(tokens.begin() + (long)len, tokens.end());
         r.output = co.hit ? co.output : std::vector<float>();
         r.option = option;
+        r.state_id = state_id;
         r.prompt_len = tokens.size();
         // run.rs:794-803: prompts longer than MIN_PROMPT_CACHE_TOKENS that are not cached yet get a cache entry as soon as
         // they have been read in (so a second request with the same long prompt skips its prefill even while this one decodes)
-        r.cache_prompt = tokens.size() > kMinPromptCacheTokens && !cache_.contains(tokens);
+        r.cache_prompt = tokens.size() > kMinPromptCacheTokens && !cache.contains(tokens);
         reqs_[batch] = std::move(r);
         const bool back = best.kind == SlotChoice::Back;
         slots_[batch].kind = SlotKind::Busy;
@@ -253,7 +293,7 @@ class Scheduler {
                 r.output = std::move(lg);
             }
             if (r.cache_prompt && r.suffix.empty() && r.prefix.size() == r.prompt_len && !r.output.empty()) {   // run.rs:829-838
-                cache_.insert(r.prefix, e_.state.back((int)b), r.output, ++clock_);
+                cache_of(r.state_id).insert(r.prefix, e_.state.back((int)b), r.output, ++clock_);
                 r.cache_prompt = false;
             }
         }
@@ -269,14 +309,14 @@ class Scheduler {
         Request &r = reqs_[batch];
         if (!r.suffix.empty()) throw std::logic_error("finish(): tokens still pending");
         ++clock_;
-        if (!r.prefix.empty() && !r.output.empty()) cache_.insert(r.prefix, e_.state.back(batch), r.output, clock_);
+        if (!r.prefix.empty() && !r.output.empty()) cache_of(r.state_id).insert(r.prefix, e_.state.back(batch), r.output, clock_);
         slots_[batch].kind = SlotKind::Idle;
         slots_[batch].content = r.prefix;
         slots_[batch].since = clock_;
     }
 
     const SlotState &slot(int batch) const { return slots_.at((size_t)batch); }
-    PrefixCache &cache() { return cache_; }
+    PrefixCache &cache(uint64_t state_id = 0) { return cache_of(state_id); }
 
    private:
     void need_busy(int batch) const {
@@ -285,7 +325,14 @@ class Scheduler {
     Engine &e_;
     std::vector<SlotState> slots_;
     std::vector<Request> reqs_;
-    PrefixCache cache_;
+    PrefixCache &cache_of(uint64_t id) {             // `caches.fetch(id)`: one trie per initial state (run.rs:262-287)
+        auto it = caches_.find(id);
+        if (it == caches_.end()) it = caches_.emplace(std::piecewise_construct, std::forward_as_tuple(id), std::forward_as_tuple(max_cached_)).first;
+        return it->second;
+    }
+    size_t max_cached_;
+    std::map<uint64_t, PrefixCache> caches_;
+    std::map<uint64_t, std::vector<float>> init_states_;
     uint64_t clock_ = 0;
 };
 

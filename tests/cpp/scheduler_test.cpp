@@ -134,6 +134,43 @@ int main() {
         CHECK(s.queue(longp, c2) != SlotResult::Failure && c2 == b);
         CHECK(s.request(c2).prefix.size() == 40 && s.request(c2).suffix.empty() && !s.request(c2).output.empty());   // no prefill at all
     }
+    // --- per-request initial states (`check_in_state`, run.rs:376-437): own cache per state id, misses start from the init slab
+    {
+        FakeEngine e(2, 100);
+        Scheduler<FakeEngine> s(e);
+        s.check_in_state(7, {123.0f, 0.0f});
+        int a = -1, b = -1;
+        CHECK(s.queue({1, 2, 3}, a, RnnOption::Last, 7) == SlotResult::Success);
+        CHECK(s.queue({1, 2, 3}, b) == SlotResult::Success);
+        while (s.pending()) s.step();
+        CHECK(s.request(a).output != s.request(b).output);               // different starting states
+        FakeEngine e2(1, 100);
+        e2.state.slots[0] = {123.0f, 0.0f};
+        rwkv::RnnInput in; in.batches.resize(1); in.batches[0].tokens = {1, 2, 3};
+        CHECK(e2.infer(in)[0] == s.request(a).output);
+        s.finish(a); s.finish(b);
+        CHECK(s.cache(7).size() == 1 && s.cache(0).size() == 1);
+        int c = -1;
+        CHECK(s.queue({1, 2, 3, 4}, c, RnnOption::Last, 7) != SlotResult::Failure);
+        CHECK(s.request(c).prefix.size() == 3);                          // continues from state 7's cache, not the default one
+        bool threw = false;
+        try { int d; s.queue({1}, d, RnnOption::Last, 99); } catch (const std::invalid_argument &) { threw = true; }
+        CHECK(threw);
+    }
+    // --- stop strings (run.rs:899-932)
+    {
+        auto bytes = [](const char *t) { return std::vector<uint8_t>(t, t + std::strlen(t)); };
+        StopScan r = scan_stops(bytes("hello\n\nUser"), {"\n\nUser", "</s>"});
+        CHECK(r.matched && r.head == 5);                                 // emit "hello", stop
+        r = scan_stops(bytes("hello\n\nUs"), {"\n\nUser"});
+        CHECK(!r.matched && r.head == 5);                                // possible match pending: hold the tail back
+        r = scan_stops(bytes("hello world"), {"\n\nUser"});
+        CHECK(!r.matched && r.head == 11);                               // nothing pending: everything is safe to emit
+        r = scan_stops(bytes("abc"), {});
+        CHECK(!r.matched && r.head == 3);
+        r = scan_stops(bytes("ab</s>cd"), {"zzz", "</s>"});
+        CHECK(r.matched && r.head == 2);                                 // a matched stop wins over an unmatched one
+    }
     std::printf("scheduler_test: ok\n");
     return 0;
 }

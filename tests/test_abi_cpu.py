@@ -191,3 +191,15 @@ def test_graft_entry_build_is_green(built_lib):
     hard-coded ABI version once made it fail while every other test was green)."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_integration_md_lists_every_export():
+    """The Rust `extern "C"` block of INTEGRATION.md (the binding a maintainer would add) names every function include/rwkv_abi.h declares."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "rwkv_abi.h")).read()
+    names = set(re.findall(r"^\s*(?:const\s+char\s*\*|rwkv_status|int32_t|int64_t|uint64_t|size_t|void)\s*\*?\s*(rwkv_\w+)\s*\(", hdr, re.M))
+    assert len(names) >= 38
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if f"pub fn {n}(" not in md)
+    assert not missing, missing
+    assert names == set(rt.ABI_SYMBOLS), sorted(names ^ set(rt.ABI_SYMBOLS))

@@ -584,6 +584,38 @@ def test_cpp_scheduler_serves_real_engine(tmp_path):
     assert c_prefix == len(p0) + n_new                        # checked out at A's full history (prompt + every fed token)
 
 
+def test_cpp_router_over_two_real_engines_on_one_device(tmp_path):
+    """SURVEY 8(e) without a second GPU: harness/router_loop.cpp builds TWO engines of one model on device 0, drives each from
+    its own thread through include/rwkv_router.hpp and routes six requests (more than one replica holds) by least-busy, then
+    a follow-up by prefix affinity.  Every request's greedy ids equal the oracle's; both replicas served requests; the
+    follow-up went back to the replica that cached its prefix."""
+    import subprocess
+    from ai00_server_amd import build as B
+    B.build_harness(verbose=False)
+    t = R.synth_named("v6-small")
+    path = tmp_path / "m.st"
+    path.write_bytes(R.st_serialize(t))
+    ref = R.RwkvRef(t)
+    ps = [prompt(ref, 120 + i, 5 + 2 * i) for i in range(6)]
+    n_new = 6
+    args = [B.ROUTER_BIN, str(path), "2", "0", "3", "16", str(n_new)]
+    for i, p in enumerate(ps):
+        args += ([] if i == 0 else ["/"]) + [str(x) for x in p]
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    rows = [[int(x) for x in ln.split()] for ln in lines[:7]]
+    for i, p in enumerate(ps):
+        want, _ = ref.greedy(p, n_new)
+        assert rows[i][1:] == want, (i, rows[i], want)
+    assert {r[0] for r in rows[:6]} == {0, 1}                            # least-busy placement used both replicas
+    follow = ps[0] + rows[0][1:] + [rows[0][-1]]
+    want, _ = ref.greedy(follow, n_new)
+    assert rows[6][1:] == want
+    meta = [int(x) for x in lines[7].split()[1:]]
+    assert meta[0] == meta[2] == rows[6][0] and meta[1] == len(follow) - 1   # routed to the replica that cached prompt + output
+
+
 def test_on_device_typical_sampling_matches_reference_sampler():
     """rwkv_infer_sample with kind = Typical (keys |(-ln p) - H| ascending -> top_k -> tau -> temperature -> inverse CDF on
     the device) against the restatement of sampler/typical.rs on the SAME logits, penalties and bias included."""
