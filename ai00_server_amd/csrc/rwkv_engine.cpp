@@ -270,6 +270,8 @@ struct rwkv_engine {
     SampleRow *d_samp = nullptr;
     int *d_adj_row = nullptr, *d_adj_tok = nullptr, *d_samp_tok = nullptr;
     float *d_adj_val = nullptr, *d_samp_prob = nullptr;
+    unsigned char *d_allow = nullptr, *h_allow = nullptr;   // formatter masks of the rows that carry one: [n][V] bytes, pinned mirror
+    int *d_allow_row = nullptr;
     unsigned char *h_samp = nullptr;
     static constexpr size_t ADJ_CAP = 1 << 16;
     float *d_amax_v = nullptr;
@@ -317,6 +319,7 @@ struct rwkv_engine {
         if (soft_host) (void)hipHostFree(soft_host);
         if (h_meta) (void)hipHostFree(h_meta);
         if (h_samp) (void)hipHostFree(h_samp);
+        if (h_allow) (void)hipHostFree(h_allow);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (s_main) (void)hipStreamDestroy(s_main);
@@ -741,6 +744,8 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
     d_samp = dalloc<SampleRow>(chunk);
     d_adj_row = dalloc<int>(ADJ_CAP); d_adj_tok = dalloc<int>(ADJ_CAP); d_adj_val = dalloc<float>(ADJ_CAP);
     d_samp_tok = dalloc<int>(chunk); d_samp_prob = dalloc<float>(chunk);
+    d_allow = dalloc<unsigned char>((size_t)max_batch * V); d_allow_row = dalloc<int>(max_batch);
+    HIP_CHECK(hipHostMalloc((void **)&h_allow, (size_t)max_batch * V + (size_t)max_batch * 4 + 16, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **)&h_samp, (size_t)chunk * (sizeof(SampleRow) + 8) + ADJ_CAP * 12, hipHostMallocDefault));
     d_amax_v = dalloc<float>((size_t)chunk * 32);
     d_amax_i = dalloc<int>((size_t)chunk * 32);
@@ -1226,6 +1231,8 @@ void rwkv_engine::infer_sample(const rwkv_slot_input *in, const rwkv_sample_para
     float *h_val = (float *)(h_tok + ADJ_CAP);
     size_t nadj = 0;
     bool any_nt = false, any_miro = false;
+    int n_allow = 0;
+    int *h_allow_row = (int *)(h_allow + (size_t)max_batch * info.num_vocab);
     for (int b = 0; b < max_batch; ++b) {
         if (pl.slot_out_rows[b] == 0) continue;
         const int r = pl.slot_out_begin[b];
@@ -1237,6 +1244,10 @@ void rwkv_engine::infer_sample(const rwkv_slot_input *in, const rwkv_sample_para
         if (p.kind < RWKV_SAMPLER_NUCLEUS || p.kind > RWKV_SAMPLER_MIROSTAT) throw RwkvError(RWKV_ERR_UNSUPPORTED, "unknown sampler kind");
         if (p.kind == RWKV_SAMPLER_MIROSTAT) any_miro = true; else any_nt = true;
         hs[r] = SampleRow{p.top_p, p.top_k, p.temperature, p.uniform, p.kind, p.tau};
+        if (p.allow) {                                             // formatter mask: staged row by row, one H2D copy for all
+            std::memcpy(h_allow + (size_t)n_allow * info.num_vocab, p.allow, (size_t)info.num_vocab);
+            h_allow_row[n_allow++] = r;
+        }
         for (size_t i = 0; i < p.n_adj; ++i, ++nadj) { h_row[nadj] = r; h_tok[nadj] = (int)p.adj_tokens[i]; h_val[nadj] = p.adj_values[i]; }
     }
     run_plan(pl);
@@ -1247,6 +1258,11 @@ void rwkv_engine::infer_sample(const rwkv_slot_input *in, const rwkv_sample_para
             HIP_CHECK(hipMemcpyAsync(d_adj_tok, h_tok, nadj * 4, hipMemcpyHostToDevice, s_main));
             HIP_CHECK(hipMemcpyAsync(d_adj_val, h_val, nadj * 4, hipMemcpyHostToDevice, s_main));
             launch_logit_adjust(logits, info.num_vocab, d_adj_row, d_adj_tok, d_adj_val, (int)nadj, s_main);
+        }
+        if (n_allow) {                                             // after the adjustments: -inf + bias stays -inf (run.rs:676-683)
+            HIP_CHECK(hipMemcpyAsync(d_allow, h_allow, (size_t)n_allow * info.num_vocab, hipMemcpyHostToDevice, s_main));
+            HIP_CHECK(hipMemcpyAsync(d_allow_row, h_allow_row, (size_t)n_allow * 4, hipMemcpyHostToDevice, s_main));
+            launch_logit_mask(logits, info.num_vocab, d_allow_row, d_allow, n_allow, s_main);
         }
         launch_nucleus(logits, pl.n_out, info.num_vocab, d_samp, any_nt, any_miro, d_samp_tok, d_samp_prob, s_main);
         int *ht = (int *)h_meta;                                   // reuse the pinned meta buffer for the 8 bytes per row

@@ -224,6 +224,7 @@ void launch_softmax(const float *in, float *out, int n_rows, int V, hipStream_t 
 // on-device sampling front-end (f-1): V <= 65536, top_k <= 256
 struct SampleRow { float top_p; int top_k; float temperature; float uniform; int kind; float tau; };   // kind 0 nucleus, 1 typical, 2 mirostat (tau = max_surprise)
 void launch_logit_adjust(float *logits, int V, const int *rows, const int *toks, const float *vals, int n, hipStream_t s);
+void launch_logit_mask(float *logits, int V, const int *rows, const unsigned char *allow, int n, hipStream_t s);   // V % 4 == 0
 void launch_nucleus(const float *logits, int n_rows, int V, const SampleRow *sp, bool any_nucleus_typical, bool any_mirostat,
                     int *out_tok, float *out_prob, hipStream_t s);
 // two-stage arg-max; scratch_v / scratch_i hold n_rows*32 partial (value, index) pairs

@@ -2219,6 +2219,28 @@ __global__ __launch_bounds__(NUC_THREADS) void nucleus_kernel(const float *logit
     }
 }
 
+// formatter masks (run.rs:676-679, sampler/bnf.rs:35-38): row rows[j] keeps only the tokens with allow[j][token] != 0
+__global__ __launch_bounds__(256) void logit_mask_kernel(float *logits, int V, const int *rows, const unsigned char *allow) {
+    const int j = blockIdx.y;
+    float *x = logits + (long)rows[j] * V;
+    const unsigned char *a = allow + (long)j * V;
+    for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < V; i += gridDim.x * 1024) {
+        if (i + 3 < V) {
+            const unsigned m = *(const unsigned *)(a + i);
+            float4 v = *(float4 *)(x + i);
+            if (!(m & 0xFFu)) v.x = -INFINITY;
+            if (!(m & 0xFF00u)) v.y = -INFINITY;
+            if (!(m & 0xFF0000u)) v.z = -INFINITY;
+            if (!(m & 0xFF000000u)) v.w = -INFINITY;
+            *(float4 *)(x + i) = v;
+        } else {
+            for (int k = i; k < V; ++k) if (!a[k]) x[k] = -INFINITY;
+        }
+    }
+}
+void launch_logit_mask(float *logits, int V, const int *rows, const unsigned char *allow, int n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(logit_mask_kernel, dim3(16, n), dim3(256), 0, s, logits, V, rows, allow);
+}
 void launch_logit_adjust(float *logits, int V, const int *rows, const int *toks, const float *vals, int n, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(logit_adjust_kernel, dim3((n + 255) / 256), dim3(256), 0, s, logits, V, rows, toks, vals, n);
 }

@@ -56,7 +56,7 @@ class _SlotInC(C.Structure):
 class _SampleC(C.Structure):
     _fields_ = [("top_p", C.c_float), ("top_k", C.c_int32), ("temperature", C.c_float), ("uniform", C.c_float),
                 ("adj_tokens", C.POINTER(C.c_uint32)), ("adj_values", C.POINTER(C.c_float)), ("n_adj", C.c_size_t),
-                ("kind", C.c_int32), ("tau", C.c_float)]
+                ("kind", C.c_int32), ("tau", C.c_float), ("allow", C.POINTER(C.c_uint8))]
 
 
 class _SlotOutC(C.Structure):
@@ -435,17 +435,24 @@ class Runtime:
             ins[b] = _SlotInC(toks.ctypes.data_as(C.POINTER(C.c_uint32)) if toks.size else None, toks.size, 0, 0)
             s = samplers[b]
             if s is None:
-                sps[b] = _SampleC(0.0, 1, 1.0, 0.0, None, None, 0, 0, 0.0)
+                sps[b] = _SampleC(0.0, 1, 1.0, 0.0, None, None, 0, 0, 0.0, None)
                 continue
             adj = s.adjustments()
             at = np.fromiter(adj.keys(), dtype=np.uint32, count=len(adj))
             av = np.fromiter(adj.values(), dtype=np.float32, count=len(adj))
             keep += [at, av]
             kind = int(getattr(s, "kind", 0))                       # 0 nucleus (top_p), 1 typical (tau)
+            allow = getattr(s, "allow", None)                       # formatter mask: uint8 [num_vocab], 0 = forbidden (bnf.rs:35-38)
+            if allow is not None:
+                allow = np.ascontiguousarray(allow, dtype=np.uint8)
+                if allow.size != self.info.num_vocab:
+                    raise RwkvError(-1, "formatter mask must have num_vocab entries")
+                keep.append(allow)
             sps[b] = _SampleC(getattr(s, "top_p", 0.0), s.top_k, s.temperature, uniforms[b],
                               at.ctypes.data_as(C.POINTER(C.c_uint32)) if at.size else None,
                               av.ctypes.data_as(C.POINTER(C.c_float)) if av.size else None, at.size,
-                              kind, float(getattr(s, "tau", 0.0)))
+                              kind, float(getattr(s, "tau", 0.0)),
+                              allow.ctypes.data_as(C.POINTER(C.c_uint8)) if allow is not None else None)
         toks_o, probs_o = (C.c_uint32 * B)(), (C.c_float * B)()
         emitted, consumed = (C.c_uint8 * B)(), (C.c_size_t * B)()
         _check(lib().rwkv_infer_sample(self._h, ins, sps, toks_o, probs_o, emitted, consumed))
@@ -485,7 +492,7 @@ class Runtime:
         ins, sps = (_SlotInC * self.max_batch)(), (_SampleC * self.max_batch)()
         for b in range(self.max_batch):
             ins[b] = _SlotInC(C.cast(toks.ctypes.data + 4 * b, C.POINTER(C.c_uint32)) if b < B else None, 1 if b < B else 0, 0, 0)
-            sps[b] = _SampleC(top_p, top_k, temperature, 0.0, None, None, 0, 0, 0.0)
+            sps[b] = _SampleC(top_p, top_k, temperature, 0.0, None, None, 0, 0, 0.0, None)
         toks_o, probs_o = (C.c_uint32 * self.max_batch)(), (C.c_float * self.max_batch)()
         emitted, consumed = (C.c_uint8 * self.max_batch)(), (C.c_size_t * self.max_batch)()
         out_view = np.ctypeslib.as_array(toks_o)

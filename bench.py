@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--decode-only", action="store_true", help="skip the embeddings / PCIe / sampling / CPU legs (profiling)")
     ap.add_argument("--sweep", default="1,8", help="extra batch sizes reported under 'sweep' (north_star: batch 1-32)")
     ap.add_argument("--verify-steps", type=int, default=8, help="decode steps re-run through rwkv_infer + host arg-max and compared")
+    ap.add_argument("--config5", action="store_true", help="also run BASELINE config #5 (V6-7B fp16, 8 x 4096-token prefill at chunk 1024, "
+                                                           "then 256 decode steps at batch 8) and report it under 'config5'")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -151,7 +153,15 @@ def main():
         head_bytes = V * info.num_emb * 2
         vec_bytes = sum(int(np.prod(s)) * 2 for k, s in shapes.items() if len([d for d in s if d > 1]) <= 1)
         layer_gemm_bytes = eng.weight_bytes - head_bytes - vec_bytes          # weights the layer GEMM launches stream
-        achieved = layer_gemm_bytes / (g_ms / nprof * 1e-3)
+        # The event pair around a launch adds marker processing (about 2 us) to what it brackets: the pairs of a step sum to more
+        # than the step itself takes.  Calibration: the excess over the graph-replayed step (`ms_per_step`, the timed region
+        # above), spread evenly over the launches, is subtracted from every launch — rocprofv3's kernel durations tile the step
+        # the same way (profiles/*_kernel_stats_*.csv: their sum equals the step), so the calibrated averages agree with them.
+        n_launch = sum(v[1] for v in fam_ms.values()) / nprof
+        pairs_ms = sum(v[0] for v in fam_ms.values()) / nprof
+        marker_us = max(0.0, (pairs_ms - ms_per_step) / n_launch * 1e3)
+        g_step_ms = g_ms / nprof - marker_us * 1e-3 * (g_n / nprof)           # layer-GEMM family time inside one step
+        achieved = layer_gemm_bytes / (g_step_ms * 1e-3)
         # HBM traffic per launch from the PMC passes (scripts/collect_pmc.py on the same workload; committed under
         # profiles/).  Not collectable inside this process: counters need rocprofv3 around the run.
         traffic, traffic_src = None, None
@@ -167,10 +177,11 @@ def main():
                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": layer_gemm_bytes / max(1, g_n // nprof),
-                "launches_per_step": g_n // nprof, "avg_launch_us": g_ms / g_n * 1e3,
+                "launches_per_step": g_n // nprof, "avg_launch_us": g_step_ms / (g_n / nprof) * 1e3,
+                "avg_launch_us_raw_event_pairs": g_ms / g_n * 1e3, "event_pair_overhead_us": marker_us,
                 "bytes_per_step": layer_gemm_bytes,
-                "head_gemm_GBps": head_bytes / (h_ms / nprof * 1e-3) / 1e9,
-                "family_ms_per_step": {k: v[0] / nprof for k, v in fam_ms.items()},
+                "head_gemm_GBps": head_bytes / max(1e-9, (h_ms / nprof - marker_us * 1e-3 * (h_n / nprof)) * 1e-3) / 1e9,
+                "family_ms_per_step": {k: v[0] / nprof - marker_us * 1e-3 * (v[1] / nprof) for k, v in fam_ms.items()},
                 "step": {"bytes": ab["per_step"], "frac_of_peak": step_frac, "W_q": ab["W_q"], "S": ab["S"]}}
 
     sweep = {}
@@ -256,6 +267,43 @@ def main():
             pass
     eng.close()
 
+    # BASELINE config #5 (optional leg): RWKV-V6-World-7B fp16, batch 8, 4096-token prompts (token_chunk_size 1024: one 1024-row
+    # step per call), then streamed decode.  Prefill is bounded by the MFMA rate: algorithmic flops = 2 * (params - embedding) per
+    # token against the 2.5 PFLOP/s dense fp16 peak; decode by HBM as above.
+    cfg5 = None
+    if rank == 0 and world == 1 and args.config5:
+        st7, t7 = R.synth_st("v6-7b", fast=True)
+        i7 = R.model_info(t7)
+        sh7 = {k: v.shape for k, v in t7.items()}
+        flops_tok = 2.0 * sum(int(np.prod(v)) for k, v in sh7.items() if k != "emb.weight")
+        e7 = rt.ModelBuilder(st7, adapter=local_rank).build(max_batch=8, token_chunk_size=1024, precision=rt.Precision.Fp16)
+        del st7, t7
+        docs = [[t % i7.num_vocab for t in R.synth_prompt(500 + b, 4096)] for b in range(8)]
+        best = None
+        for rep in range(2):
+            z = e7.state.init()
+            for b in range(8):
+                e7.state.load(z, b)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            inp = rt.RnnInput([rt.RnnInputBatch(list(docs[b]), rt.RnnOption.Last) for b in range(8)])
+            calls = 0
+            while inp.num_token() > 0:
+                inp, outs = e7.infer(inp)
+                calls += 1
+            dt7 = time.perf_counter() - t
+            best = dt7 if best is None else min(best, dt7)
+        f7 = np.array([int(np.argmax(outs[b][-1])) for b in range(8)], dtype=np.uint32)
+        e7.decode_greedy(f7, 8)
+        _, dms = e7.decode_greedy(f7, 256)
+        ab7 = R.algorithmic_bytes(i7, sh7, 0, 0, 8)
+        cfg5 = {"workload": "RWKV-v6-7b fp16, batch 8, 4096-token prompts, token_chunk_size 1024, then 256 decode steps",
+                "prefill_tokens_per_s": 8 * 4096 / best, "prefill_s": best, "infer_calls": calls,
+                "prefill_TFLOPs": 8 * 4096 * flops_tok / best / 1e12, "prefill_frac_of_mfma_peak": 8 * 4096 * flops_tok / best / 2.5e15,
+                "decode_tokens_per_s": 8 * 256 / (dms * 1e-3), "decode_ms_per_step": dms / 256,
+                "decode_frac_of_hbm_peak": ab7["per_step"] / (dms / 256 * 1e-3) / HBM_PEAK}
+        e7.close()
+
     if rank == 0:
         line = {"metric": "decode tokens/sec (whole job)", "value": value, "unit": "tokens/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -265,7 +313,7 @@ def main():
                            "quant": args.quant, "batch_per_gpu": B, "precision": args.precision,
                            "parallelism": f"replicas x{world} (no collective)"},
                 "tokens_per_s_per_gpu": value / world, "device_ms_per_step": dev_ms / args.steps,
-                "roofline": roof, "cpu_baseline": cpu, "embeddings": emb, "pcie_inclusive_tokens_per_s": pcie, "on_device_sampling_tokens_per_s": sampled, "sweep": sweep or None, "tokens_verified": tokens_verified,
+                "roofline": roof, "cpu_baseline": cpu, "embeddings": emb, "pcie_inclusive_tokens_per_s": pcie, "on_device_sampling_tokens_per_s": sampled, "sweep": sweep or None, "tokens_verified": tokens_verified, "config5": cfg5,
                 "load_s": t_load, "synth_s": t_synth}
         print(json.dumps(line), flush=True)
     if dist is not None:

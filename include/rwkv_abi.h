@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define RWKV_ABI_VERSION 2   /* 2: rwkv_sample_params gained kind/tau; rwkv_engine_save_prefab */
+#define RWKV_ABI_VERSION 3   /* 2: rwkv_sample_params gained kind/tau; rwkv_engine_save_prefab
+                              * 3: rwkv_sample_params gained allow (formatter mask); rwkv_host_alloc/free; RWKV_OPTION_NONE */
 
 typedef int32_t rwkv_status;
 enum {
@@ -178,6 +179,11 @@ typedef struct rwkv_sample_params {
                                    /*   top_p / top_k / temperature unused; out_probs[b] returns the TOKEN SURPRISE           */
                                    /*   log2(sum) - log2(p) the caller needs for `max_surprise -= rate * (surprise - tau)`.   */
                                    /*   Exact while max_surprise < 13 (<= 8192 candidates); beyond, the tail below 2^-13 is cut. */
+    const uint8_t *allow;          /* NULL, or num_vocab bytes: allow[token] == 0 forbids the token (its logit becomes -inf before  */
+                                   /*   the softmax).  This is what a `Formatter::transform` leaves behind (run.rs:676-679,         */
+                                   /*   sampler/bnf.rs:35-38: kbnf's mask_logits): the grammar state machine stays on the host and  */
+                                   /*   hands over its current allowed-token set, so BNF-constrained requests can sample on the     */
+                                   /*   device too.                                                                                 */
 } rwkv_sample_params;
 enum { RWKV_SAMPLER_NUCLEUS = 0, RWKV_SAMPLER_TYPICAL = 1, RWKV_SAMPLER_MIROSTAT = 2 };
 /* Like rwkv_infer with RWKV_OPTION_LAST on every slot, but slots whose pending tokens are exhausted by this call

@@ -26,7 +26,15 @@ int main() {
         std::vector<std::unique_ptr<FakeEngine>> engines;
         std::vector<FakeEngine *> es;
         for (int i = 0; i < 8; ++i) { engines.emplace_back(new FakeEngine(4, 3)); es.push_back(engines.back().get()); }
+        // eight long requests first (tens of thousands of fake steps each, submitted microseconds apart): every later one sees the
+        // earlier ones still in flight, so least-busy walks the replicas in index order — the placement rule, checked exactly
+        std::vector<RoutedRequest> longs(8);
         ReplicaRouter<FakeEngine> router(es);
+        for (int i = 0; i < 8; ++i) {
+            longs[(size_t)i].tokens = Tokens{(uint32_t)(100 + i)};
+            longs[(size_t)i].max_new = 30000;
+            CHECK(router.submit(&longs[(size_t)i]) == i);
+        }
         std::vector<RoutedRequest> reqs(64);
         for (int i = 0; i < 64; ++i) {
             reqs[(size_t)i].tokens = Tokens{(uint32_t)(i % 7 + 1), (uint32_t)(i % 5 + 2), (uint32_t)(i + 3)};
@@ -38,9 +46,8 @@ int main() {
             else std::this_thread::yield();
         }
         router.drain();
-        int used = 0;
-        for (int r = 0; r < 8; ++r) used += router.steps(r) > 0;
-        CHECK(used == 8);                                                // least-busy placement reaches every replica
+        for (int r = 0; r < 8; ++r) CHECK(router.steps(r) >= 30000);     // every replica ran its long request to the end
+        for (auto &q : longs) CHECK(q.done && (int)q.generated.size() == q.max_new);
         for (auto &q : reqs) {
             CHECK(q.done && q.replica >= 0 && (int)q.generated.size() == q.max_new);
             CHECK(q.generated == greedy_alone(q.tokens, q.max_new));
@@ -53,7 +60,7 @@ int main() {
         std::vector<FakeEngine *> es{&e0, &e1, &e2};
         ReplicaRouter<FakeEngine> router(es);
         RoutedRequest a, b, c;
-        a.tokens = {9, 8, 7, 6}; a.max_new = 3;
+        a.tokens = {9, 8, 7, 6}; a.max_new = 3000;                        // long enough to still be in flight when b is routed
         b.tokens = {1, 2}; b.max_new = 2;
         CHECK(router.submit(&a) == 0);                                   // all idle: lowest index
         CHECK(router.submit(&b) == 1);                                   // replica 0 has one in flight: least busy is 1

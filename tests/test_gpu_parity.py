@@ -473,6 +473,39 @@ def test_on_device_sampling_full_vocabulary_ties_and_top_k_zero():
     eng.close()
 
 
+def test_on_device_sampling_with_a_formatter_mask():
+    """`Formatter::transform` on the device path (run.rs:676-683, sampler/bnf.rs:35-38): the grammar's allowed-token set arrives
+    as a dense mask; forbidden logits become -inf after the penalties and before the bias, exactly as the host path orders them."""
+    from ai00_server_amd.harness import NucleusSampler
+    t, eng = build("v6-small", rt.Precision.Fp32, B=2, chunk=16)
+    ref = R.RwkvRef(t)
+    V = ref.info.num_vocab
+    p = prompt(ref, 140, 9)
+    logits = ref.forward(p, ref.init_state())[-1]
+    rng = np.random.default_rng(9)
+    checked = 0
+    for trial in range(12):
+        allow = (rng.random(V) < 0.08).astype(np.uint8)
+        allow[int(np.argmax(logits))] = 0                                 # the unconstrained favourite is forbidden
+        allow[rng.integers(0, V)] = 1
+        x = logits.copy()
+        x[allow == 0] = -np.inf
+        x[7] += np.float32(2.0)                                           # bias on a token: stays -inf if forbidden
+        u = float(rng.random())
+        want, margin = R.nucleus_ref(R.softmax_ref(x[None])[0], 0.9, 50, 1.1, u)
+        smp = NucleusSampler(top_p=0.9, top_k=50, temperature=1.1, presence_penalty=0.0, frequency_penalty=0.0, bias={7: 2.0})
+        smp.allow = allow
+        for b in range(2):
+            eng.state.load(eng.state.init(), b)
+        _, out = eng.infer_sample(rt.RnnInput([rt.RnnInputBatch(list(p)), rt.RnnInputBatch()]), [smp, None], [u, 0.0])
+        assert allow[out[0][0]] == 1
+        if margin > 1e-4:
+            assert out[0][0] == want, (trial, out[0], want)
+            checked += 1
+    assert checked >= 8
+    eng.close()
+
+
 def test_infer_into_pageable_and_pinned_destinations():
     """rwkv_infer copies logits straight into pinned destinations (rwkv_host_alloc; the Python mirror hands out pieces of one
     pinned block) and stages them for pageable ones: same bits either way, also for scattered per-slot buffers."""
