@@ -1050,7 +1050,8 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
             static const int no_fuse = env_int("RWKV_NO_V6_FUSE"), no_ln_fuse = env_int("RWKV_NO_LN_FUSE");
             att_fused = !no_fuse && !no_ln_fuse && v6_mix_ln_supported(T, C, Dm, hilo, np);
             if (!att_fused) launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
-            if (v6_mix_supported(T, C, Dm) && !no_fuse) {
+            static const int no_wide = env_int("RWKV_NO_V6_WIDE");     // A/B: two tile-GEMM launches instead of the wide fused form
+            if ((v6_mix_supported(T, C, Dm) || (v6_mix_wide_supported(T, C, Dm) && !no_wide)) && !no_fuse) {
                 // fused: x_c = xx + dx * (mu_c + W2_c tanh(W1_c z)) in one launch
                 V6MixArgs m{};
                 m.W1 = w.W1->data;

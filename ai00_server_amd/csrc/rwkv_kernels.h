@@ -133,6 +133,7 @@ struct V6MixArgs {
     const float *mu_x;              // with lnp: z = xx + dx * mu_x
 };
 bool v6_mix_supported(int T, int C, int Dm);
+bool v6_mix_wide_supported(int T, int C, int Dm);                   // steps with more than 32 rows: block = (mix, 32-token tile), all strips
 bool v6_mix_ln_supported(int T, int C, int Dm, bool hilo, int np);   // the LayerNorm-prologue form (lnp set)
 void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s);
 

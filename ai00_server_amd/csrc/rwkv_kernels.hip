@@ -784,7 +784,11 @@ int gemm_max_rounds(int fmt, int NT, bool hilo) { return NT == 4 ? 2 : (fmt == W
 // apply tanh and keep m_c in LDS as the f16 (hi, lo) operand; then wave w multiplies strip w of W2_c (K = Dm)
 // with it and applies the lerp epilogue, emitting the five GEMM operands.
 // =====================================================================================
-template <int NT, bool HILO, int DS, bool LNP>
+// WIDE (steps with more than 32 rows, prefill included): grid (1, 5, ceil(T/32)) — a block owns one mix c and one 32-token
+// tile, computes m_c for its tokens once and then walks ALL strips of W2_c (8 waves, strip = wave, wave+8, ...).  Per block:
+// z tile 160 KB + W1_c 164 KB + W2_c 164 KB + the xx/dx tile, against 5 x C/16 x T/16 tiles of work: one launch of ~15 us
+// for a 512-row step instead of the two tile-GEMM launches (W1: 24 workgroups, 25 us; W2 with K = 32: 46 us) it replaces.
+template <int NT, bool HILO, int DS, bool LNP, bool WIDE = false>
 __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -792,6 +796,7 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     const int c = blockIdx.y;                                     // mix index
     const int sg = blockIdx.x;                                    // strip group (8 strips of W2_c)
     const int C = a.C, Dm = a.Dm, T = a.T;
+    const int t0 = WIDE ? (int)blockIdx.z * NT * 16 : 0;          // first token of this block's tile
     // DS = Dm/16 strips of W1_c (2 or 4)
     const int KT1 = C >> 5;                                       // k-tiles of W1 per strip
     const int kst = KT1 >> 3;                                     // k-steps per wave in phase 1 (C/8/32)
@@ -808,9 +813,12 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     const int row0 = strip_c * 16 + (lane >> 4) * 4;
     u32x4 w2t[DS / 2];
     float4 xxv[NT], dxv[NT];
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (!WIDE) {
 #pragma unroll
-    for (int ks = 0; ks < DS / 2; ++ks) w2t[ks] = ((const u32x4 *)a.W2[c])[((long)strip_c * (DS / 2) + ks) * 64 + lane];
-    const float4 mu = *(const float4 *)(a.mu[c] + row0);
+        for (int ks = 0; ks < DS / 2; ++ks) w2t[ks] = ((const u32x4 *)a.W2[c])[((long)strip_c * (DS / 2) + ks) * 64 + lane];
+        mu = *(const float4 *)(a.mu[c] + row0);
+    }
     const act_t bxx = act_buf(a.xx), bdx = act_buf(a.dx), bzh = act_buf(a.zhi), bzl = act_buf(a.zlo);
     const act_t boh = act_buf(a.ohi[c]), bol = act_buf(a.olo[c]);
     // LNP (single-token steps): LayerNorm + token shift are redone here by every block (ln_prologue_*): z arrives in LDS in
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
             xxv[nt] = x;
             dxv[nt] = make_float4(pr.x - x.x, pr.y - x.y, pr.z - x.z, pr.w - x.w);
         }
-    } else {
+    } else if constexpr (!WIDE) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             int t = nt * 16 + (lane & 15);
@@ -859,7 +867,7 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
                 const int kt = wave * kst + k0 + j;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int tile = min(nt, (T - 1) >> 4);
+                    const int tile = min((t0 >> 4) + nt, (T - 1) >> 4);
                     const int tl = min(lane & 15, T - 1 - tile * 16);
                     if constexpr (LNP) {
                         zb[j][nt] = *(const f16x8 *)(z_l + lnp_op_off(T, kt * 32 + (lane >> 4) * 8, tl));
@@ -910,14 +918,16 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     }
     __syncthreads();
     TRACE_K(0, 3);
-    // ---- phase 2: strip (sg*8 + wave) of W2_c times m_c, lerp epilogue (operands prefetched before phase 1)
-    if (strip < (C >> 4)) {
+    // ---- phase 2: a strip of W2_c times m_c, lerp epilogue.  Decode form: strip sg*8 + wave, operands prefetched before
+    //      phase 1.  WIDE: every strip of W2_c, round-robin over the block's 8 waves, operands fetched per strip.
+    auto do_strip = [&](int sidx, const u32x4 (&w2)[DS / 2], const float4 &muv, const float4 (&xxs)[NT], const float4 (&dxs)[NT]) {
+        const int r0 = sidx * 16 + (lane >> 4) * 4;
         f32x4 o[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < DS / 2; ++ks) {
-            const f16x8 af = __builtin_bit_cast(f16x8, w2t[ks]);
+            const f16x8 af = __builtin_bit_cast(f16x8, w2[ks]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int off = (nt * 16 + (lane & 15)) * mstride + ks * 32 + (lane >> 4) * 8;
@@ -927,28 +937,55 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int t = nt * 16 + (lane & 15);
+            const int t = t0 + nt * 16 + (lane & 15);
             if (t < T) {
-                const float4 xx = xxv[nt], dx = dxv[nt];
+                const float4 xx = xxs[nt], dx = dxs[nt];
                 float4 r;
-                r.x = xx.x + dx.x * (mu.x + o[nt][0]);
-                r.y = xx.y + dx.y * (mu.y + o[nt][1]);
-                r.z = xx.z + dx.z * (mu.z + o[nt][2]);
-                r.w = xx.w + dx.w * (mu.w + o[nt][3]);
-                act_store_operand4(boh, bol, a.olo[c] != nullptr, opd_off(t, row0, a.ldh), r);
+                r.x = xx.x + dx.x * (muv.x + o[nt][0]);
+                r.y = xx.y + dx.y * (muv.y + o[nt][1]);
+                r.z = xx.z + dx.z * (muv.z + o[nt][2]);
+                r.w = xx.w + dx.w * (muv.w + o[nt][3]);
+                act_store_operand4(boh, bol, a.olo[c] != nullptr, opd_off(t, r0, a.ldh), r);
             }
         }
+    };
+    if constexpr (WIDE) {
+        for (int sidx = wave; sidx < (C >> 4); sidx += 8) {
+            const int r0 = sidx * 16 + (lane >> 4) * 4;
+            u32x4 w2[DS / 2];
+#pragma unroll
+            for (int ks = 0; ks < DS / 2; ++ks) w2[ks] = ((const u32x4 *)a.W2[c])[((long)sidx * (DS / 2) + ks) * 64 + lane];
+            const float4 muv = *(const float4 *)(a.mu[c] + r0);
+            float4 xxs[NT], dxs[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int t = min(t0 + nt * 16 + (lane & 15), T - 1);
+                xxs[nt] = act_ld4(bxx, (long)t * C + r0);
+                dxs[nt] = act_ld4(bdx, (long)t * C + r0);
+            }
+            do_strip(sidx, w2, muv, xxs, dxs);
+        }
+    } else {
+        if (strip < (C >> 4)) do_strip(strip, w2t, mu, xxv, dxv);
     }
     TRACE_K(0, 4);
 }
 
 bool v6_mix_supported(int T, int C, int Dm) { return T <= 32 && C % 256 == 0 && (Dm == 32 || Dm == 64); }
+bool v6_mix_wide_supported(int T, int C, int Dm) { return T > 32 && C % 256 == 0 && (Dm == 32 || Dm == 64); }
 
 void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
-    const int NT = a.T <= 16 ? 1 : 2;
+    const bool wide = a.T > 32;                                // v6_mix_wide_supported: one block per (mix, 32-token tile)
+    const int NT = (a.T <= 16 && !wide) ? 1 : 2;
     const bool lnp = a.lnp.x_in != nullptr;                    // host: T <= LNP_MAX_T, !hilo, C <= 4096 (v6_mix_ln_supported)
     const size_t lds = (size_t)8 * 4 * NT * 64 * 16 + (size_t)2 * NT * 16 * (a.Dm + 8) * 2 + (lnp ? lnp_lds_bytes(LNP_MAX_T, a.C, hilo) : 0);
     dim3 grid((a.C / 16 + 7) / 8, 5), block(512);
+    if (wide) {
+        grid = dim3(1, 5, (a.T + 31) / 32);
+        if (a.Dm == 32) { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 2, false, true>), grid, block, lds, s, a); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 2, false, true>), grid, block, lds, s, a); }
+        else { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 4, false, true>), grid, block, lds, s, a); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 4, false, true>), grid, block, lds, s, a); }
+        return;
+    }
     static bool attr_done[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
