@@ -1359,14 +1359,16 @@ void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s) 
 // =====================================================================================
 // Row kernels (one 256-thread block per row)
 // =====================================================================================
-// PT = float4 groups per thread (C <= PT*1024).  Everything stays in registers (fully unrolled, predicated),
-// all global loads of a phase are issued before the first dependent use.
-#define ROW_FOR(i, c) _Pragma("unroll") for (int i = 0, c = threadIdx.x * 4; i < PT; ++i, c += 1024) if (c < C)
+// PT = float4 groups per thread, NTHR = threads per row block (C <= PT*NTHR*4).  Everything stays in registers (fully unrolled,
+// predicated), all global loads of a phase are issued before the first dependent use.  Decode-shaped steps (a few dozen rows =
+// a few dozen workgroups on 256 CUs) run ln_shift with 1024 threads per row: the kernel is one latency chain over ~90 KB per
+// row, and 16 waves with ~6 loads each get it issued four times as fast as 4 waves with ~21.
+#define ROW_FOR(i, c) _Pragma("unroll") for (int i = 0, c = threadIdx.x * 4; i < PT; ++i, c += NTHR * 4) if (c < C)
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *(const float4 *)p; }
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-template <int PT>
+template <int PT, int NTHR = 256>
 __device__ __forceinline__ void row_load_sum(act_t x_in, act_t P, int np, long pstride,
                                              int row, int C, float4 (&v)[PT]) {
     constexpr int MAXNP = 8;                                       // all loads in flight at once, summed in fixed order
@@ -1381,28 +1383,32 @@ __device__ __forceinline__ void row_load_sum(act_t x_in, act_t P, int np, long p
         if (j < np) { ROW_FOR(i, c) v[i] = v[i] + pp[j][i]; }
     }
 }
-// block-wide sum without the leading barrier: `buf` (4 floats of LDS) must not have been read since the last barrier
+// block-wide sum without the leading barrier: `buf` (NTHR/64 floats of LDS) must not have been read since the last barrier
 // by anything still in flight — callers alternate two buffers.
-__device__ __forceinline__ float block_sum256_nb(float v, float *buf) {
+template <int NTHR>
+__device__ __forceinline__ float block_sum_nb(float v, float *buf) {
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
     __syncthreads();
-    return buf[0] + buf[1] + buf[2] + buf[3];
+    float r = buf[0];
+#pragma unroll
+    for (int w = 1; w < NTHR / 64; ++w) r += buf[w];
+    return r;
 }
 // two-pass LayerNorm (mean, then centred variance), eps 1e-5 — same order as the oracle's _ln.
-// `red` = 8 floats of LDS (mean uses [0..3], variance [4..7]); wv/bv = the row's weight and bias, loaded by the caller
-// together with everything else the kernel needs so that no load waits behind a reduction.
-template <int PT>
+// `red` = 2 * NTHR/64 floats of LDS (mean uses the first half, variance the second); wv/bv = the row's weight and bias, loaded
+// by the caller together with everything else the kernel needs so that no load waits behind a reduction.
+template <int PT, int NTHR = 256>
 __device__ __forceinline__ void row_layernorm(float4 (&v)[PT], int C, const float4 (&wv)[PT], const float4 (&bv)[PT], float *red) {
     float s = 0.f;
     ROW_FOR(i, c) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    const float mean = block_sum256_nb(s, red) / (float)C;
+    const float mean = block_sum_nb<NTHR>(s, red) / (float)C;
     float q = 0.f;
     ROW_FOR(i, c) {
         const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
         q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
     }
-    const float var = block_sum256_nb(q, red + 4) / (float)C;
+    const float var = block_sum_nb<NTHR>(q, red + NTHR / 64) / (float)C;
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     ROW_FOR(i, c) {
         v[i].x = (v[i].x - mean) * rstd * wv[i].x + bv[i].x;
@@ -1413,9 +1419,9 @@ __device__ __forceinline__ void row_layernorm(float4 (&v)[PT], int C, const floa
 }
 
 
-template <int PT>
-__global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
-    __shared__ float red[8];
+template <int PT, int NTHR>
+__global__ __launch_bounds__(NTHR) void ln_shift_kernel(const LnShiftArgs a) {
+    __shared__ float red[2 * NTHR / 64];
     const int t = blockIdx.x, C = a.C;
     TRACE_K(2, 0);
     // every load that does not depend on another load is issued here, parameters first: the kernel is one latency
@@ -1430,20 +1436,20 @@ __global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
     float4 xv[PT], pv[PT];
     if (prev < 0) { ROW_FOR(i, c) pv[i] = ld4(sx + c); }
     const act_t bx = act_buf(a.x_in), bP = act_buf(a.P), bxo = act_buf(a.x_out), bxx = act_buf(a.xx_out), bdx = act_buf(a.dx_out);
-    row_load_sum<PT>(bx, bP, a.np, a.pstride, t, C, xv);
-    if (prev >= 0) row_load_sum<PT>(bx, bP, a.np, a.pstride, prev, C, pv);
+    row_load_sum<PT, NTHR>(bx, bP, a.np, a.pstride, t, C, xv);
+    if (prev >= 0) row_load_sum<PT, NTHR>(bx, bP, a.np, a.pstride, prev, C, pv);
     TRACE_K(2, 1);
     if (a.x_out) { ROW_FOR(i, c) act_st4(bxo, (long)t * C + c, xv[i]); }
-    row_layernorm<PT>(xv, C, wv, bv, red);
+    row_layernorm<PT, NTHR>(xv, C, wv, bv, red);
     TRACE_K(2, 2);
-    if (prev >= 0) row_layernorm<PT>(pv, C, wv, bv, red);
+    if (prev >= 0) row_layernorm<PT, NTHR>(pv, C, wv, bv, red);
     if (last >= 0) {            // this block owns the slot's token-shift state write (after its own read above)
         if (last == t) {
             ROW_FOR(i, c) *(float4 *)(sx + c) = xv[i];
         } else {
             float4 lv[PT];
-            row_load_sum<PT>(bx, bP, a.np, a.pstride, last, C, lv);
-            row_layernorm<PT>(lv, C, wv, bv, red);
+            row_load_sum<PT, NTHR>(bx, bP, a.np, a.pstride, last, C, lv);
+            row_layernorm<PT, NTHR>(lv, C, wv, bv, red);
             ROW_FOR(i, c) *(float4 *)(sx + c) = lv[i];
         }
     }
@@ -1487,10 +1493,22 @@ __global__ __launch_bounds__(256) void ln_shift_kernel(const LnShiftArgs a) {
         else hipLaunchKernelGGL((KERN<8>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__);             \
     } while (0)
 
-void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s) { ROW_DISPATCH(ln_shift_kernel, a.C, T, a); }
+void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s) {
+    static const int wide_off = std::getenv("RWKV_LN_256") ? std::atoi(std::getenv("RWKV_LN_256")) : 0;   // A/B switch
+    if (T <= 64 && !wide_off) {                                   // few rows: 1024 threads per row
+        if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<1, 1024>), dim3(T), dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL((ln_shift_kernel<2, 1024>), dim3(T), dim3(1024), 0, s, a);
+        return;
+    }
+    if (a.C <= 1024) hipLaunchKernelGGL((ln_shift_kernel<1, 256>), dim3(T), dim3(256), 0, s, a);
+    else if (a.C <= 2048) hipLaunchKernelGGL((ln_shift_kernel<2, 256>), dim3(T), dim3(256), 0, s, a);
+    else if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<4, 256>), dim3(T), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ln_shift_kernel<8, 256>), dim3(T), dim3(256), 0, s, a);
+}
 
 template <int PT>
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
+    constexpr int NTHR = 256;
     __shared__ float red[8];
     const int t = blockIdx.x, C = a.C;
     float4 wv[PT], bv[PT];
@@ -1510,6 +1528,7 @@ void launch_embed(const EmbedArgs &a, int T, hipStream_t s) { ROW_DISPATCH(embed
 
 template <int PT>
 __global__ __launch_bounds__(256) void ln_out_kernel(const LnOutArgs a) {
+    constexpr int NTHR = 256;
     __shared__ float red[8];
     const int o = blockIdx.x, C = a.C;
     float4 wv[PT], bv[PT];
