@@ -868,7 +868,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         Lh.T = T;
         // 64x64 tiles measured best everywhere (tile_bench): with 256-k chunks while the launch is latency-bound
         // (few blocks: one L2 round trip per chunk dominates), with 128-k chunks (more blocks per CU) once it is
-        // throughput-bound.  RWKV_TILE_SHAPE overrides (0..9) for experiments.
+        // throughput-bound.  RWKV_TILE_SHAPE overrides (0..10) for experiments.
         const char *ev_shape = std::getenv("RWKV_TILE_SHAPE");     // read per call: the parity tests force every shape in one process
         const int f_shape = (ev_shape && *ev_shape) ? std::atoi(ev_shape) : -1;
         long tot64 = 0;
@@ -878,7 +878,20 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         // grids: 7B fp16 prefill at chunk 1024 25.9 -> 27.5 k tok/s, but 21.3 -> 17.8 k at chunk 512; the 256x128
         // GLDS shape (9) wins isolated large fp16 GEMMs (404 -> 536 TFLOP/s) and loses the model (small matrices starve)
         if (T >= 1024 && tot64 >= 2500) shape = 7;
-        if (f_shape >= 0 && f_shape < GEMM_TILE_SHAPES) shape = f_shape;
+        // The pipelined 128x128 kernel (shape 10) keeps two blocks per CU resident, 512 tiles a round, and runs ~820 TFLOP/s on
+        // whole rounds against ~540 for the 64x64 shapes whatever the grid (scripts/tile_bench2.py); a partial last round costs
+        // a whole one (blocks left alone on a CU are latency-bound), so it is used when its rounds are at least 65 % full:
+        // V6-3B chunk 2048 60.8 -> 69.5 k prefill tok/s, V6-7B chunk 1024 30.4 -> 32.7 k.  RWKV_TILE3_FILL=<percent> (0 = never).
+        bool ok3 = true;
+        {
+            long t3 = 0;
+            for (auto &sp : ps) { t3 += gemm_tile_blocks(GEMM_TILE3, sp.W->rows, T); ok3 = ok3 && gemm_tile3_supported(hilo, sp.W->K); }
+            const char *ev_fill = std::getenv("RWKV_TILE3_FILL");
+            const long fill_min = (ev_fill && *ev_fill) ? std::atol(ev_fill) : 65;
+            const long rounds = (t3 + 511) / 512;
+            if (ok3 && fill_min > 0 && t3 >= 400 && t3 * 100 >= fill_min * rounds * 512) shape = GEMM_TILE3;
+        }
+        if (f_shape >= 0 && f_shape < GEMM_TILE_SHAPES && (f_shape != GEMM_TILE3 || ok3)) shape = f_shape;
         int blocks = 0;
         for (size_t i = 0; i < ps.size(); ++i) {
             const ProbSpec &s = ps[i];
@@ -1710,6 +1723,7 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
                         shape = GEMM_TILE_SHAPES - 1;
                         for (int sh = 0; sh < GEMM_TILE_SHAPES; ++sh) if (gemm_tile_blocks(sh, rows, T) >= 1024) { shape = sh; break; }
                     }
+                    if (shape == GEMM_TILE3 && !gemm_tile3_supported(hilo != 0, K)) throw RwkvError(RWKV_ERR_INVALID, "bench_gemm: shape 10 needs K % 128 == 0 and no hi/lo operand");
                     Lh = GemmLaunch{};
                     Lh.nprob = 1; Lh.T = T;
                     GemmProb &g = Lh.p[0];

@@ -115,8 +115,10 @@ void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s);
 int gemm_max_rounds(int fmt, int NT, bool hilo);
 // prefill path (T >= GEMM_TILE_MIN_T): LDS-tiled MFMA GEMM, no K split; uses p[].block_begin and total_blocks only
 constexpr int GEMM_TILE_MIN_T = 193;                     // measured crossover (V6-3B Int8): up to 192 rows the decode kernel's 64-row passes win or tie
-constexpr int GEMM_TILE_SHAPES = 10;                      // 256x128, 128x128, 64x128, 64x64 (rows x tokens, 128-k chunks); 64x64 and 128x128 with 256-k chunks
+constexpr int GEMM_TILE_SHAPES = 11;                      // 256x128, 128x128, 64x128, 64x64 (rows x tokens, 128-k chunks); 64x64 and 128x128 with 256-k chunks
 int gemm_tile_blocks(int shape, int rows, int T);
+constexpr int GEMM_TILE3 = 10;                            // the pipelined 128x128 kernel (non-hi/lo operands, K % 128 == 0)
+bool gemm_tile3_supported(bool hilo, int K);
 void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s);                             // rounds of 256 k a wave can hold at once (single-shot)
 
 // V6 fused time-mix LoRA (tanh(W1 z) -> W2 -> lerp), decode-shaped steps only

@@ -1089,6 +1089,43 @@ __device__ __forceinline__ void glds16(const _Float16 *g, _Float16 *lds) {
                                      (__attribute__((address_space(3))) void *)(uintptr_t)(uint32_t)(uintptr_t)lds, 16, 0, 0);
 }
 
+// Epilogue of the tile kernels: acc[h][nt][r] = row (strip+h)*16 + (lane>>4)*4 + r, token t0 + nt*16 + (lane&15)
+template <int SPW, int NTL>
+__device__ __forceinline__ void tg_epilogue(const GemmLaunch &L, const GemmProb &P, f32x4 (&acc)[SPW][NTL], int strip, int nstrips, int t0, int lane) {
+#pragma unroll
+    for (int h = 0; h < SPW; ++h) {
+        if (strip + h < nstrips) {
+            const int row0 = (strip + h) * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) {
+                const int t = t0 + nt * 16 + (lane & 15);
+                if (t < L.T) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = acc[h][nt][r];
+                        if (P.bias) x += P.bias[row0 + r];
+                        x = apply_act(P.act, x);
+                        if (P.post == POST_MUL) x *= P.m0[(long)t * P.ldm + row0 + r];
+                        else if (P.post == POST_MIX)
+                            x = P.m0[(long)t * P.ldm + row0 + r] + P.m1[(long)t * P.ldm + row0 + r] * x;
+                        v[r] = x;
+                    }
+                    if (P.out_f32) *(float4 *)(P.out_f32 + (long)t * P.ldo + row0) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (P.out_hi) {
+                        f16x4 hh, ll;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { _Float16 a, b; split_hilo(v[r], a, b); hh[r] = a; ll[r] = b; }
+                        const long oo = opd_off(t, row0, P.ldh);
+                        *(f16x4 *)(P.out_hi + oo) = hh;
+                        if (P.out_lo) *(f16x4 *)(P.out_lo + oo) = ll;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <bool HILO, int WAVES, int SPW, int NTL, int KC, int FMT, bool GLDS>
 __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
     constexpr int BT = NTL * 16, THREADS = WAVES * 64, STRIPS = WAVES * SPW, TG_KC = KC, TG_STRIDE = KC + 8;
@@ -1275,39 +1312,7 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
         }
     }
     }
-    // ---- epilogue
-#pragma unroll
-    for (int h = 0; h < SPW; ++h) {
-        if (strip + h < nstrips) {
-            const int row0 = (strip + h) * 16 + (lane >> 4) * 4;
-#pragma unroll
-            for (int nt = 0; nt < NTL; ++nt) {
-                const int t = t0 + nt * 16 + (lane & 15);
-                if (t < L.T) {
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float x = acc[h][nt][r];
-                        if (P.bias) x += P.bias[row0 + r];
-                        x = apply_act(P.act, x);
-                        if (P.post == POST_MUL) x *= P.m0[(long)t * P.ldm + row0 + r];
-                        else if (P.post == POST_MIX)
-                            x = P.m0[(long)t * P.ldm + row0 + r] + P.m1[(long)t * P.ldm + row0 + r] * x;
-                        v[r] = x;
-                    }
-                    if (P.out_f32) *(float4 *)(P.out_f32 + (long)t * P.ldo + row0) = make_float4(v[0], v[1], v[2], v[3]);
-                    if (P.out_hi) {
-                        f16x4 hh, ll;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { _Float16 a, b; split_hilo(v[r], a, b); hh[r] = a; ll[r] = b; }
-                        const long oo = opd_off(t, row0, P.ldh);
-                        *(f16x4 *)(P.out_hi + oo) = hh;
-                        if (P.out_lo) *(f16x4 *)(P.out_lo + oo) = ll;
-                    }
-                }
-            }
-        }
-    }
+    tg_epilogue<SPW, NTL>(L, P, acc, strip, nstrips, t0, lane);
 }
 
 template <bool HILO, int WAVES, int SPW, int NTL, int KC, bool GLDS>
@@ -1322,15 +1327,205 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tile_kernel(const GemmLaunch 
     else tg_body<HILO, WAVES, SPW, NTL, KC, W_NF4, GLDS>(L, P, smem);
 }
 
+// =====================================================================================
+// Pipelined tile kernel (shape 10): 128 rows x 128 tokens per block, 4 waves, wave w owns strips {2w, 2w+1} x all 8 token tiles
+// (64 accumulator registers).  Per k-step the block moves (128 + 128) x 64 B through the CU's L2 port for 64 MFMAs — half
+// of what the 64x64 shapes move per MFMA, which is what bounds them (the port sustains ~56 B/clk, they need 128 B/clk at full
+// MFMA rate) — and everything is prefetched further ahead than one chunk:
+//   * X: ring of T3_NB = 4 LDS stages of [8 token tiles][2 k-steps] fragment tiles (64 k, 16 KiB), filled by global_load_lds
+//     three stages ahead.  A stage is published by a COUNTED s_waitcnt vmcnt(N) + raw s_barrier at the end of the stage before
+//     it is read (N = the VMEM instructions issued after that stage's DMAs: the two younger stages' 4 + 4 DMAs and one weight
+//     group), so neither the younger DMAs nor the weight prefetch are drained at a barrier — __syncthreads() would wait vmcnt(0).
+//     It is restaged one barrier after its last ds_read (lgkmcnt(0) in front of that barrier).
+//   * weights: HBM/L2 -> registers in groups of 128 k (two stages), three register sets, loaded two groups (4 stages) ahead.
+// Host guarantees K % 128 == 0 and a non-hi/lo operand.  vmcnt is in-order, so a count that is too SMALL only waits longer; the
+// weight-group constant below is therefore the number of 16-byte tile loads (scale loads not counted).
+// =====================================================================================
+constexpr int T3_NB = 4, T3_STAGE_HALFS = 16 * 512;
+// Every VMEM instruction of the K loop is inline asm: hipcc then keeps no vmcnt bookkeeping for the loop (its own bookkeeping
+// degrades to vmcnt(0) as soon as a load sits behind a branch or an LDS-DMA is pending), and the counted waits below are exact.
+// A register written by such a load is used only after (1) a counted wait that retires the load and (2) t3_arrived(), an empty
+// asm that makes the compiler treat the register as produced at that point, so no use can be scheduled ahead of the wait.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void t3_ld16(u32x4 &d, const void *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void t3_ld8(u32x2 &d, const void *p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void t3_dma16(const void *g, unsigned lds_byte) {      // lane l -> LDS byte lds_byte + 16 l; M0 preserved
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_byte) : "memory");
+}
+template <int N> __device__ __forceinline__ void t3_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// weight group of 128 k for two strips: tile loads + (quantised) one scale word per strip; NLOAD = VMEM instructions issued
+template <int FMT> struct T3Set {
+    static constexpr int NQ = 4 / Fmt<FMT>::KS, NLOAD = 2 * NQ + (FMT == W_F16 ? 0 : 2);
+    u32x4 q[2][NQ];
+    u32x2 s[2];
+};
+template <int FMT>
+__device__ __forceinline__ void t3_load(T3Set<FMT> &w, const GemmProb &P, int strip, int nstrips, int k0, int lane) {
+    constexpr int SH = Fmt<FMT>::SH;
+    const int KT = P.K >> SH;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int sidx = min(strip + h, nstrips - 1);
+        const u32x4 *base = (const u32x4 *)P.W + ((long)sidx * KT + (k0 >> SH)) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < T3Set<FMT>::NQ; ++j) t3_ld16(w.q[h][j], base + j * 64);
+        if constexpr (FMT != W_F16) t3_ld8(w.s[h], (const u32x2 *)P.S + ((long)sidx * (P.K >> 8) + (k0 >> 8)) * 16 + (lane & 15));
+    }
+}
+template <int FMT> __device__ __forceinline__ void t3_arrived(T3Set<FMT> &w) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int j = 0; j < T3Set<FMT>::NQ; ++j) asm volatile("" : "+v"(w.q[h][j]));
+        if constexpr (FMT != W_F16) asm volatile("" : "+v"(w.s[h]));
+    }
+}
+// A fragment of k-step ks (0..3) of the group at k0: same arithmetic as tg_frag, on a T3Set
+template <int FMT>
+__device__ __forceinline__ f16x8 t3_frag(const T3Set<FMT> &w, int h, int ks, int k0, const Nf4Lut &lut) {
+    TRound<FMT, 1, 128> r;
+#pragma unroll
+    for (int j = 0; j < T3Set<FMT>::NQ; ++j) r.q[0][j] = w.q[h][j];
+    r.s[0] = make_uint2(w.s[h].x, w.s[h].y);
+    return tg_frag<FMT, 1, 128>(r, 0, ks, k0, lut);
+}
+
+template <int FMT>
+__device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
+    constexpr int SPW = 2, NTL = 8, BT = 128, STRIPS = 8, NA = T3Set<FMT>::NLOAD;
+    using Set = T3Set<FMT>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nstrips = P.rows >> 4;
+    const int ntt = (L.T + BT - 1) / BT;
+    int lb = (int)blockIdx.x - P.block_begin;
+    if (L.xcd_map) {                                              // XCD-banded tile numbering, as in tg_body
+        const int nb = ((nstrips + STRIPS - 1) / STRIPS) * ntt;
+        const int k = lb & 7, j = lb >> 3;
+        int start = 0;
+        for (int m = 0; m < k; ++m) start += (nb - m + 7) >> 3;
+        lb = start + j;
+    }
+    const int rb = lb / ntt, tt = lb - rb * ntt;
+    const int strip = rb * STRIPS + wave * SPW;
+    const int t0 = tt * BT;
+    const int nst = P.K >> 6, nsc = P.K >> 7;
+    const _Float16 *xs = (const _Float16 *)smem;                  // [T3_NB][token tile 0..7][k-step 0..1][lane][8]
+    const unsigned xs_byte = (unsigned)(uintptr_t)smem;           // LDS byte address of the ring (dynamic LDS starts at 0 here, kept general)
+    const int last_tile = (L.T - 1) >> 4;
+    Nf4Lut lut;
+    if constexpr (FMT == W_NF4) lut = make_nf4_lut();
+
+    f32x4 acc[SPW][NTL];
+#pragma unroll
+    for (int h = 0; h < SPW; ++h)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) acc[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // the four X tiles of a stage this wave fetches: i = m*4 + wave -> (token tile i >> 1, k-step i & 1); tiles past the step
+    // are clamped to its last tile (their columns are never stored)
+    const _Float16 *xsrc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int i = m * 4 + wave;
+        const int ttile = min((t0 >> 4) + (i >> 1), last_tile);
+        xsrc[m] = P.xhi + ((long)ttile * (P.ldx >> 5) + (i & 1)) * 512 + lane * 8;
+    }
+    auto dma = [&](int s) {
+        const unsigned dst = xs_byte + (unsigned)(((s & (T3_NB - 1)) * T3_STAGE_HALFS + wave * 512) * 2);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) t3_dma16(xsrc[m] + (long)s * 1024, dst + m * 4 * 1024);
+    };
+    auto stage = [&](const Set &w, int s, auto half) {
+        constexpr int H = decltype(half)::value;
+        const _Float16 *bh = xs + (s & (T3_NB - 1)) * T3_STAGE_HALFS + lane * 8;
+        const int k0 = (s >> 1) * 128;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f16x8 xv[NTL];
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) xv[nt] = *(const f16x8 *)(bh + (nt * 2 + q) * 512);
+            f16x8 af[SPW];
+#pragma unroll
+            for (int h = 0; h < SPW; ++h) af[h] = t3_frag<FMT>(w, h, H * 2 + q, k0, lut);
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+                for (int h = 0; h < SPW; ++h) acc[h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[h], xv[nt], acc[h][nt], 0, 0, 0);
+        }
+    };
+    // End of stage s: stage s+1 must be complete in LDS for every wave, and (s odd) the weight group of the next two stages in
+    // this wave's registers.  Steady state (s + 4 < nst): younger than both are exactly DMA(s+2), DMA(s+3) and ONE weight group
+    // (issued at the start of whichever of s-1, s is even) = 8 + NA instructions; the last four stages drain instead.
+    auto publish = [&](int s) {
+        if (s + 4 < nst) t3_wait_barrier<8 + NA>();
+        else if (s + 1 < nst) t3_wait_barrier<0>();
+    };
+    auto super = [&](Set &cur, Set &refill, int sc) {
+        int s = 2 * sc;
+        t3_arrived<FMT>(cur);
+        if (sc + 2 < nsc) t3_load<FMT>(refill, P, strip, nstrips, (sc + 2) * 128, lane);
+        if (s + 3 < nst) dma(s + 3);
+        stage(cur, s, std::integral_constant<int, 0>{});
+        publish(s);
+        s += 1;
+        if (s + 3 < nst) dma(s + 3);
+        stage(cur, s, std::integral_constant<int, 1>{});
+        publish(s);
+    };
+
+    Set a0, a1, a2;
+    t3_load<FMT>(a0, P, strip, nstrips, 0, lane);
+    t3_load<FMT>(a1, P, strip, nstrips, nsc > 1 ? 128 : 0, lane);
+    t3_load<FMT>(a2, P, strip, nstrips, 0, lane);                 // placeholder contents (every register defined); refilled at sc = 0
+    dma(0);
+    if (nst > 1) dma(1);
+    if (nst > 2) dma(2);
+    if (nst > 2) t3_wait_barrier<8>(); else t3_wait_barrier<0>();   // DMA(0) and the three weight groups have landed
+    for (int sc = 0; sc < nsc; sc += 3) {
+        super(a0, a2, sc);
+        if (sc + 1 < nsc) super(a1, a0, sc + 1);
+        if (sc + 2 < nsc) super(a2, a1, sc + 2);
+    }
+    tg_epilogue<SPW, NTL>(L, P, acc, strip, nstrips, t0, lane);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tile3_kernel(const GemmLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int pi = 0;
+    for (int i = 1; i < L.nprob; ++i)
+        if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
+    const GemmProb &P = L.p[pi];
+    if (P.fmt == W_F16) tg3_body<W_F16>(L, P, smem);
+    else if (P.fmt == W_INT8) tg3_body<W_INT8>(L, P, smem);
+    else tg3_body<W_NF4>(L, P, smem);
+}
+bool gemm_tile3_supported(bool hilo, int K) { return !hilo && K % 128 == 0; }
+
 // tile shapes, largest first: {waves, strips per wave, n-tiles, k per chunk}
 static const int kTileShapes[GEMM_TILE_SHAPES][5] = {{8, 2, 8, 128, 0}, {8, 1, 8, 128, 0}, {4, 1, 8, 128, 0}, {4, 1, 4, 128, 0}, {4, 1, 4, 256, 0}, {8, 1, 8, 256, 0},
-                                                     {4, 1, 4, 256, 1}, {4, 2, 4, 128, 1}, {4, 2, 8, 128, 1}, {8, 2, 8, 128, 1}};
+                                                     {4, 1, 4, 256, 1}, {4, 2, 4, 128, 1}, {4, 2, 8, 128, 1}, {8, 2, 8, 128, 1}, {4, 2, 8, 128, 2}};
 int gemm_tile_blocks(int shape, int rows, int T) {
     const int strips = kTileShapes[shape][0] * kTileShapes[shape][1], bt = kTileShapes[shape][2] * 16;
     return ((rows / 16 + strips - 1) / strips) * ((T + bt - 1) / bt);
 }
 
 void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s) {
+    if (kTileShapes[shape][4] == 2) {                          // pipelined 128x128 kernel (caller checked gemm_tile3_supported)
+        static bool attr3[16] = {false};
+        int dev3 = 0;
+        (void)hipGetDevice(&dev3);
+        if (!attr3[dev3 & 15]) {
+            (void)hipFuncSetAttribute((const void *)gemm_tile3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr3[dev3 & 15] = true;
+        }
+        hipLaunchKernelGGL(gemm_tile3_kernel, dim3(L.total_blocks), dim3(256), (size_t)T3_NB * T3_STAGE_HALFS * 2, s, L);
+        return;
+    }
     const int bt = kTileShapes[shape][2] * 16, kc = kTileShapes[shape][3];
     const size_t lds = kTileShapes[shape][4] ? (size_t)2 * (hilo ? 2 : 1) * (bt / 16) * (kc / 32) * 1024
                                              : (size_t)2 * (hilo ? 2 : 1) * bt * (kc + 8) * 2;

@@ -76,7 +76,7 @@ def main():
 
     t0 = time.time()
     eng = (rt.ModelBuilder(st, adapter=local_rank).quant(ql, rt.Quant(qt))
-           .build(max_batch=max(B, 1), token_chunk_size=max(512, B),
+           .build(max_batch=max(B, 1), token_chunk_size=max(2048, B),
                   precision=rt.Precision.Fp32 if args.precision == "fp32" else rt.Precision.Fp16))
     t_load = time.time() - t0
     del st

@@ -128,10 +128,10 @@ def wide3b():
 
 
 @pytest.mark.parametrize("shape,qt", [(3, 0), (3, 1), (3, 2), (7, 0), (7, 1), (7, 2), (4, 1), (0, 1), (1, 1), (2, 1), (5, 1),
-                                       (6, 1), (8, 1), (9, 1), (9, 0)])
+                                       (6, 1), (8, 1), (9, 1), (9, 0), (10, 0), (10, 1), (10, 2)])
 def test_every_prefill_tile_shape_at_3b_width(wide3b, shape, qt):
-    """gemm_tile_kernel in each of its ten shapes (rwkv_engine.cpp picks 4, 3 or 7 by grid size; the rest are reachable
-    through RWKV_TILE_SHAPE) on a 548-row ragged step of 3B-wide matrices, plus `wkv_chunk_kernel<6,64>` at H = 40."""
+    """gemm_tile_kernel in each of its ten shapes and the pipelined 128x128 kernel (shape 10) (rwkv_engine.cpp picks by grid
+    size; the rest are reachable through RWKV_TILE_SHAPE) on a 548-row ragged step of 3B-wide matrices, plus `wkv_chunk_kernel<6,64>` at H = 40."""
     st, ps, ref = wide3b
     want, states = ref[qt]
     os.environ["RWKV_TILE_SHAPE"] = str(shape)
@@ -146,9 +146,39 @@ def test_every_prefill_tile_shape_at_3b_width(wide3b, shape, qt):
     eng.close()
 
 
+def test_pipelined_tile_kernel_is_bit_identical_to_the_64x64_shape_over_repeated_runs(wide3b):
+    """Race screen for the counted-vmcnt K loop of shape 10 (inline-asm loads, LDS-DMA ring, raw barriers): both kernels add the
+    k-steps of a row in the same order into fp32 MFMA accumulators, so logits and state must be BIT-identical to the 64x64
+    shape's, on every one of several runs (a landed-too-late tile would show up as a differing run)."""
+    st, ps, _ = wide3b
+    outs = {}
+    for shape in (4, 10):
+        os.environ["RWKV_TILE_SHAPE"] = str(shape)
+        try:
+            for qt in (0, 1, 2):
+                eng = engine(st, (2 if qt else 0, qt), 4, 1024)
+                runs = []
+                for rep in range(4):
+                    for b in range(4):
+                        eng.state.load(eng.state.init(), b)
+                    rows = feed(eng, ps)
+                    runs.append((np.stack([rows[b][-1] for b in range(4)]), np.stack([eng.state.back(b) for b in range(4)])))
+                outs[(shape, qt)] = runs
+                eng.close()
+        finally:
+            os.environ.pop("RWKV_TILE_SHAPE", None)
+    for qt in (0, 1, 2):
+        ref_l, ref_s = outs[(4, qt)][0]
+        for shape in (4, 10):
+            for rep, (lg, stt) in enumerate(outs[(shape, qt)]):
+                assert np.array_equal(lg, ref_l), f"logits differ: shape {shape} quant {qt} run {rep}"
+                assert np.array_equal(stt, ref_s), f"state differs: shape {shape} quant {qt} run {rep}"
+
+
 def test_config5_7b_width_1024_row_prefill_and_8_slot_decode():
     """BASELINE config #5 shapes (C=4096, F=14336, Dm=64, Dd=128, fp16), two layers: an 8 x 128 = 1024-row prefill step
-    (the planner's own choice: the GLDS 128x64 tile, `wkv_chunk_kernel<6,128>`), then 8-slot decode both ways."""
+    (the planner's own choice: the pipelined 128x128 tile kernel on the 1032-tile r/k/v/g/decay launch, 64x64 tiles on the
+    rest, `wkv_chunk_kernel<6,128>`), then 8-slot decode both ways."""
     tens = R.synth_checkpoint(6, 2, 4096, 14336, 2048, seed=29)
     rb = R.RwkvRefBatch(tens)
     B = 8
