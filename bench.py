@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--decode-only", action="store_true", help="skip the embeddings / PCIe / sampling / CPU legs (profiling)")
     ap.add_argument("--sweep", default="1,8", help="extra batch sizes reported under 'sweep' (north_star: batch 1-32)")
     ap.add_argument("--verify-steps", type=int, default=8, help="decode steps re-run through rwkv_infer + host arg-max and compared")
-    ap.add_argument("--config5", action="store_true", help="also run BASELINE config #5 (V6-7B fp16, 8 x 4096-token prefill at chunk 1024, "
+    ap.add_argument("--config5", action="store_true", help="also run BASELINE config #5 (V6-7B fp16, 8 x 4096-token prefill at chunk 2048, "
                                                            "then 256 decode steps at batch 8) and report it under 'config5'")
     args = ap.parse_args()
 
@@ -216,7 +216,7 @@ def main():
         docs = [[t % V for t in R.synth_prompt(100 + b, doc_len)] for b in range(B)]
         zero = eng.state.init()
         best = None
-        for rep in range(2):
+        for rep in range(3):
             for b in range(B):
                 eng.state.load(zero, b)
             t = time.perf_counter()
@@ -267,7 +267,7 @@ def main():
             pass
     eng.close()
 
-    # BASELINE config #5 (optional leg): RWKV-V6-World-7B fp16, batch 8, 4096-token prompts (token_chunk_size 1024: one 1024-row
+    # BASELINE config #5 (optional leg): RWKV-V6-World-7B fp16, batch 8, 4096-token prompts (token_chunk_size 2048: one 2048-row
     # step per call), then streamed decode.  Prefill is bounded by the MFMA rate: algorithmic flops = 2 * (params - embedding) per
     # token against the 2.5 PFLOP/s dense fp16 peak; decode by HBM as above.
     cfg5 = None
@@ -276,7 +276,7 @@ def main():
         i7 = R.model_info(t7)
         sh7 = {k: v.shape for k, v in t7.items()}
         flops_tok = 2.0 * sum(int(np.prod(v)) for k, v in sh7.items() if k != "emb.weight")
-        e7 = rt.ModelBuilder(st7, adapter=local_rank).build(max_batch=8, token_chunk_size=1024, precision=rt.Precision.Fp16)
+        e7 = rt.ModelBuilder(st7, adapter=local_rank).build(max_batch=8, token_chunk_size=2048, precision=rt.Precision.Fp16)
         del st7, t7
         docs = [[t % i7.num_vocab for t in R.synth_prompt(500 + b, 4096)] for b in range(8)]
         best = None
@@ -297,7 +297,7 @@ def main():
         e7.decode_greedy(f7, 8)
         _, dms = e7.decode_greedy(f7, 256)
         ab7 = R.algorithmic_bytes(i7, sh7, 0, 0, 8)
-        cfg5 = {"workload": "RWKV-v6-7b fp16, batch 8, 4096-token prompts, token_chunk_size 1024, then 256 decode steps",
+        cfg5 = {"workload": "RWKV-v6-7b fp16, batch 8, 4096-token prompts, token_chunk_size 2048, then 256 decode steps",
                 "prefill_tokens_per_s": 8 * 4096 / best, "prefill_s": best, "infer_calls": calls,
                 "prefill_TFLOPs": 8 * 4096 * flops_tok / best / 1e12, "prefill_frac_of_mfma_peak": 8 * 4096 * flops_tok / best / 2.5e15,
                 "decode_tokens_per_s": 8 * 256 / (dms * 1e-3), "decode_ms_per_step": dms / 256,

@@ -23,11 +23,11 @@ run_stats v6-3b_int8_b32 $BENCH --workload v6-3b --quant int8 --batch 32
 run_stats v6-3b_int8_b1 $BENCH --workload v6-3b --quant int8 --batch 1
 run_stats v6-7b_fp16_b8 $BENCH --workload v6-7b --quant none --batch 8
 run_stats v7-2.9b_nf4_b32 $BENCH --workload v7-2.9b --quant nf4 --batch 32
-run_stats prefill_v6-3b_int8_32x256 python $R/scripts/prefill_probe.py v6-3b 1 32 256 512
+run_stats prefill_v6-3b_int8_32x256 python $R/scripts/prefill_probe.py v6-3b 1 32 256 2048
 # MFMA utilisation (north_star): matrix-pipe busy cycles against shader busy cycles, decode B=32 and the prefill run
 for name in decode_v6-3b_int8_b32 prefill_v6-3b_int8; do
   rm -rf $O/pmc_$name
-  if [ $name = decode_v6-3b_int8_b32 ]; then CMD="$BENCH --workload v6-3b --quant int8 --batch 32 --steps 12"; else CMD="python $R/scripts/prefill_probe.py v6-3b 1 32 256 512"; fi
+  if [ $name = decode_v6-3b_int8_b32 ]; then CMD="$BENCH --workload v6-3b --quant int8 --batch 32 --steps 12"; else CMD="python $R/scripts/prefill_probe.py v6-3b 1 32 256 2048"; fi
   timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_$name -o p -- $CMD > $O/pmc_$name.log 2>&1
   python - $O/pmc_$name $P/${TAG}_pmc_mfma_$name.txt <<'PY'
 import csv, glob, collections, sys
