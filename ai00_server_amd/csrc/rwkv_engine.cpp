@@ -220,6 +220,7 @@ struct StepPlan {
     int T = 0, n_seq = 0, n_out = 0;
     std::vector<int> token, slot, prev, last, seq_slot, seq_begin, seq_len, out_rows;
     std::vector<int> slot_consumed, slot_out_begin, slot_out_rows;   // per slot
+    uint64_t id = 0;                // plans with the same id have identical metadata apart from the token ids
 };
 
 struct rwkv_dstate {
@@ -264,12 +265,16 @@ struct rwkv_engine {
     long pstride = 0;
     // row meta (device + pinned host)
     int *d_meta = nullptr, *h_meta = nullptr;
+    int *h_tok = nullptr, *dv_tok = nullptr;               // pinned token ids of a dense step and their device-visible alias
+    StepPlan last_plan;                                    // plan cache: a serving loop repeats the same dense decode pattern
+    std::vector<size_t> last_ntok;
+    std::vector<int> last_opt;
+    uint64_t plan_counter = 0, uploaded_id = 0;
     size_t meta_cap = 0;
     int *d_tok_feedback = nullptr, *d_hist = nullptr, *d_amax_i = nullptr;
     // sampling front-end: per-row params, sparse adjustments (row, token, value), outputs; pinned host mirror
-    SampleRow *d_samp = nullptr;
-    int *d_adj_row = nullptr, *d_adj_tok = nullptr, *d_samp_tok = nullptr;
-    float *d_adj_val = nullptr, *d_samp_prob = nullptr;
+    int *d_adj_row = nullptr, *d_adj_tok = nullptr;
+    float *d_adj_val = nullptr;
     unsigned char *d_allow = nullptr, *h_allow = nullptr;   // formatter masks of the rows that carry one: [n][V] bytes, pinned mirror
     int *d_allow_row = nullptr;
     unsigned char *h_samp = nullptr;
@@ -320,6 +325,7 @@ struct rwkv_engine {
         if (logits_host) (void)hipHostFree(logits_host);
         if (soft_host) (void)hipHostFree(soft_host);
         if (h_meta) (void)hipHostFree(h_meta);
+        if (h_tok) (void)hipHostFree(h_tok);
         if (h_samp) (void)hipHostFree(h_samp);
         if (h_allow) (void)hipHostFree(h_allow);
         if (ev0) (void)hipEventDestroy(ev0);
@@ -738,14 +744,14 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
     meta_cap = (size_t)chunk * 5 + (size_t)max_batch * 3 + 16;
     d_meta = dalloc<int>(meta_cap);
     HIP_CHECK(hipHostMalloc((void **)&h_meta, meta_cap * 4, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&h_tok, (size_t)max_batch * 4, hipHostMallocMapped | hipHostMallocCoherent));   // uncached on the device: always the host's latest store
+    HIP_CHECK(hipHostGetDevicePointer((void **)&dv_tok, h_tok, 0));
     d_tok_feedback = dalloc<int>(chunk);
     soft_rows_cap = (size_t)std::max(1, max_batch);
     soft_in = dalloc<float>(soft_rows_cap * V);
     soft_out = dalloc<float>(soft_rows_cap * V);
     HIP_CHECK(hipHostMalloc((void **)&soft_host, soft_rows_cap * V * 4, hipHostMallocDefault));
-    d_samp = dalloc<SampleRow>(chunk);
     d_adj_row = dalloc<int>(ADJ_CAP); d_adj_tok = dalloc<int>(ADJ_CAP); d_adj_val = dalloc<float>(ADJ_CAP);
-    d_samp_tok = dalloc<int>(chunk); d_samp_prob = dalloc<float>(chunk);
     d_allow = dalloc<unsigned char>((size_t)max_batch * V); d_allow_row = dalloc<int>(max_batch);
     HIP_CHECK(hipHostMalloc((void **)&h_allow, (size_t)max_batch * V + (size_t)max_batch * 4 + 16, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **)&h_samp, (size_t)chunk * (sizeof(SampleRow) + 8) + ADJ_CAP * 12, hipHostMallocDefault));
@@ -946,6 +952,17 @@ static void water_fill(long budget, const std::vector<size_t> &pending, std::vec
 
 void rwkv_engine::plan_step(const rwkv_slot_input *in, StepPlan &pl) {
     const int B = max_batch;
+    // A decode loop hands the same pattern (the same slots, one token each, every row emitted) step after step: the plan of
+    // the previous call is reused with the new token ids (dense: row index == slot index).
+    if (last_plan.dense && (int)last_ntok.size() == B) {
+        bool same = true;
+        for (int b = 0; b < B && same; ++b) same = in[b].n_tokens == last_ntok[b] && (in[b].n_tokens == 0 || in[b].option == last_opt[b]);
+        if (same) {
+            pl = last_plan;
+            for (int r = 0; r < pl.T; ++r) pl.token[r] = (int)in[r].tokens[0];
+            return;
+        }
+    }
     pl.slot_consumed.assign(B, 0);
     pl.slot_out_begin.assign(B, 0);
     pl.slot_out_rows.assign(B, 0);
@@ -976,6 +993,11 @@ void rwkv_engine::plan_step(const rwkv_slot_input *in, StepPlan &pl) {
     static const int no_dense = std::getenv("RWKV_NO_DENSE") ? std::atoi(std::getenv("RWKV_NO_DENSE")) : 0;   // A/B switch
     pl.dense = !no_dense && pl.T > 0 && pl.n_seq == pl.T && pl.n_out == pl.T;
     for (int i = 0; i < pl.n_seq && pl.dense; ++i) pl.dense = pl.seq_slot[i] == i;
+    pl.id = ++plan_counter;
+    last_plan = pl;
+    last_ntok.assign(B, 0);
+    last_opt.assign(B, 0);
+    for (int b = 0; b < B; ++b) { last_ntok[b] = in[b].n_tokens; last_opt[b] = in[b].option; }
 }
 
 // meta layout in d_meta: token[chunk] slot[chunk] prev[chunk] last[chunk] out_rows[chunk] seq_slot[B] seq_begin[B] seq_len[B]
@@ -1000,6 +1022,7 @@ void rwkv_engine::upload_plan(const StepPlan &pl) {
     std::memcpy(h + 5 * chunk + max_batch, pl.seq_begin.data(), pl.n_seq * 4);
     std::memcpy(h + 5 * chunk + 2 * max_batch, pl.seq_len.data(), pl.n_seq * 4);
     HIP_CHECK(hipMemcpyAsync(d_meta, h, meta_cap * 4, hipMemcpyHostToDevice, s_main));
+    uploaded_id = pl.id;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1189,7 +1212,17 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
 
 // upload the row metadata and enqueue the step (graph replay when this shape was seen before)
 void rwkv_engine::run_plan(const StepPlan &pl) {
-    upload_plan(pl);
+    // Dense steps read their token ids from pinned host memory through its device-visible alias (one uncached read per row in
+    // the embedding kernel) and nothing else changes between two steps of the same plan, so a repeated dense plan needs no
+    // host-to-device copy at all; everything else uploads its metadata.
+    const int *tok_ptr = d_meta;
+    if (pl.dense) {
+        std::memcpy(h_tok, pl.token.data(), (size_t)pl.T * 4);
+        tok_ptr = dv_tok;
+        if (pl.id != uploaded_id) upload_plan(pl);
+    } else {
+        upload_plan(pl);
+    }
     const uint64_t key = ((uint64_t)pl.dense << 63) | ((uint64_t)pl.T << 40) | ((uint64_t)pl.n_seq << 20) | (uint64_t)pl.n_out;
     if (use_graphs && !profiling) {
         auto it = graphs.find(key);
@@ -1197,14 +1230,14 @@ void rwkv_engine::run_plan(const StepPlan &pl) {
         // prefill tails would pay capture + instantiation (milliseconds) for a single replay and churn the cache
         if (it == graphs.end() && graph_seen.insert(key).second) {
             if (graph_seen.size() > 4096) graph_seen.clear();
-            run_layers(pl.T, pl.n_seq, pl.n_out, d_meta, pl.dense);
+            run_layers(pl.T, pl.n_seq, pl.n_out, tok_ptr, pl.dense);
             return;
         }
         if (it == graphs.end()) {
             hipGraph_t g = nullptr;
             HIP_CHECK(hipStreamBeginCapture(s_main, hipStreamCaptureModeThreadLocal));
             try {
-                run_layers(pl.T, pl.n_seq, pl.n_out, d_meta, pl.dense);
+                run_layers(pl.T, pl.n_seq, pl.n_out, tok_ptr, pl.dense);
             } catch (...) {
                 (void)hipStreamEndCapture(s_main, &g);
                 if (g) (void)hipGraphDestroy(g);
@@ -1222,7 +1255,7 @@ void rwkv_engine::run_plan(const StepPlan &pl) {
         }
         HIP_CHECK(hipGraphLaunch(it->second.exec, s_main));
     } else {
-        run_layers(pl.T, pl.n_seq, pl.n_out, d_meta, pl.dense);
+        run_layers(pl.T, pl.n_seq, pl.n_out, tok_ptr, pl.dense);
     }
 }
 
@@ -1266,9 +1299,18 @@ void rwkv_engine::infer_sample(const rwkv_slot_input *in, const rwkv_sample_para
         }
         for (size_t i = 0; i < p.n_adj; ++i, ++nadj) { h_row[nadj] = r; h_tok[nadj] = (int)p.adj_tokens[i]; h_val[nadj] = p.adj_values[i]; }
     }
+    // The sampler kernel reads its per-row parameters from, and writes its 8 bytes per row to, pinned host memory directly
+    // (device-visible mapping of h_samp): no copy operation sits in front of the step or between it and the host seeing its
+    // tokens.  (Measured against an H2D copy of the parameters ahead of the step: no difference beyond run-to-run noise.)
+    const SampleRow *rows_ptr = nullptr;
+    HIP_CHECK(hipHostGetDevicePointer((void **)&rows_ptr, hs, 0));
     run_plan(pl);
     if (pl.n_out > 0) {
-        HIP_CHECK(hipMemcpyAsync(d_samp, hs, (size_t)pl.n_out * sizeof(SampleRow), hipMemcpyHostToDevice, s_main));
+        int *ht = (int *)(h_samp + (size_t)chunk * sizeof(SampleRow) + (size_t)ADJ_CAP * 12);
+        float *hp = (float *)(ht + chunk);
+        int *dv_out_tok = nullptr;
+        HIP_CHECK(hipHostGetDevicePointer((void **)&dv_out_tok, ht, 0));
+        float *dv_prob = (float *)(dv_out_tok + chunk);
         if (nadj) {
             HIP_CHECK(hipMemcpyAsync(d_adj_row, h_row, nadj * 4, hipMemcpyHostToDevice, s_main));
             HIP_CHECK(hipMemcpyAsync(d_adj_tok, h_tok, nadj * 4, hipMemcpyHostToDevice, s_main));
@@ -1280,11 +1322,7 @@ void rwkv_engine::infer_sample(const rwkv_slot_input *in, const rwkv_sample_para
             HIP_CHECK(hipMemcpyAsync(d_allow_row, h_allow_row, (size_t)n_allow * 4, hipMemcpyHostToDevice, s_main));
             launch_logit_mask(logits, info.num_vocab, d_allow_row, d_allow, n_allow, s_main);
         }
-        launch_nucleus(logits, pl.n_out, info.num_vocab, d_samp, any_nt, any_miro, d_samp_tok, d_samp_prob, s_main);
-        int *ht = (int *)h_meta;                                   // reuse the pinned meta buffer for the 8 bytes per row
-        float *hp = (float *)(h_meta + chunk);
-        HIP_CHECK(hipMemcpyAsync(ht, d_samp_tok, (size_t)pl.n_out * 4, hipMemcpyDeviceToHost, s_main));
-        HIP_CHECK(hipMemcpyAsync(hp, d_samp_prob, (size_t)pl.n_out * 4, hipMemcpyDeviceToHost, s_main));
+        launch_nucleus(logits, pl.n_out, info.num_vocab, rows_ptr, any_nt, any_miro, dv_out_tok, dv_prob, s_main);
         HIP_CHECK(hipStreamSynchronize(s_main));
         for (int b = 0; b < max_batch; ++b) {
             if (pl.slot_out_rows[b] == 0) continue;

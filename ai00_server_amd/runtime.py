@@ -499,9 +499,11 @@ class Runtime:
         l, h = lib(), self._h
         _check(l.rwkv_infer_sample(h, ins, sps, toks_o, probs_o, emitted, consumed))
         t = time.perf_counter()
+        sp_view = np.frombuffer(sps, dtype=np.dtype({"names": ["uniform"], "formats": [np.float32],
+                                                     "offsets": [_SampleC.uniform.offset], "itemsize": C.sizeof(_SampleC)}))
+        u32 = u.astype(np.float32)
         for s_ in range(n_steps):
-            for b in range(B):
-                sps[b].uniform = u[s_, b]
+            sp_view["uniform"][:B] = u32[s_, :B]                 # one strided store instead of B attribute writes
             rc = l.rwkv_infer_sample(h, ins, sps, toks_o, probs_o, emitted, consumed)
             if rc:
                 _check(rc)

@@ -779,3 +779,56 @@ def test_full_width_v7_shapes_two_layers_nf4():
         assert int(np.argmax(got)) == int(np.argmax(want[i]))
     assert np.abs(eng.state.back(1) - s).max() <= tol(rt.Precision.Fp16, s)
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["v6-small", "v7-small"])
+def test_repeated_dense_steps_reuse_the_plan_and_survive_pattern_changes(name):
+    """A decode loop repeats one slot pattern, so the engine reuses the previous call's plan and reads the token ids of a dense
+    step from pinned host memory instead of uploading metadata.  Patterns that alternate — all three slots, slot 0 alone (dense
+    with one row), slot 1 alone (not dense: row 0 is slot 1), slots {0, 2}, all three again, through rwkv_infer, rwkv_infer_sample
+    and rwkv_decode_greedy — must leave every slot exactly where the oracle's independent per-slot recurrences are."""
+    t, eng = build(name, rt.Precision.Fp32, B=3, chunk=16)
+    ref = R.RwkvRef(t)
+    V = ref.info.num_vocab
+    states = [ref.init_state() for _ in range(3)]
+    rng = np.random.default_rng(5)
+    patterns = [(0, 1, 2), (0, 1, 2), (0,), (0,), (1,), (1,), (0, 2), (0, 1, 2), (0, 1, 2), (2,), (0, 1, 2)]
+    for step, act in enumerate(patterns):
+        toks = {b: int(rng.integers(1, V)) for b in act}
+        want = {b: ref.forward([toks[b]], states[b])[-1] for b in act}
+        if step % 3 == 2:                                           # through the sampling entry point, top_k = 1 == arg-max
+            class ArgMax:                                           # nucleus with top_k = 1 keeps the arg-max only (nucleus.rs:77-89)
+                top_p, top_k, temperature = 0.5, 1, 1.0
+
+                def adjustments(self):
+                    return {}
+            inp = rt.RnnInput([rt.RnnInputBatch([toks[b]] if b in act else []) for b in range(3)])
+            _, out = eng.infer_sample(inp, [ArgMax() if b in act else None for b in range(3)], [0.3] * 3)
+            for b in range(3):
+                if b in act:
+                    assert out[b] is not None and out[b][0] == int(np.argmax(want[b])), f"step {step} slot {b}"
+                else:
+                    assert out[b] is None
+        else:
+            inp = rt.RnnInput([rt.RnnInputBatch([toks[b]] if b in act else []) for b in range(3)])
+            _, outs = eng.infer(inp)
+            for b in range(3):
+                if b in act:
+                    assert np.abs(outs[b][-1] - want[b]).max() <= tol(rt.Precision.Fp32, want[b]), f"step {step} slot {b}"
+                else:
+                    assert len(outs[b]) == 0
+    first = [int(rng.integers(1, V)) for _ in range(3)]
+    ids, _ = eng.decode_greedy(first, 5)                            # uploads its own plan: the cache must notice
+    cur = list(first)
+    for s in range(5):
+        for b in range(3):
+            lg = ref.forward([cur[b]], states[b])[-1]
+            cur[b] = int(np.argmax(lg))
+            assert int(ids[s, b]) == cur[b], f"greedy step {s} slot {b}"
+    toks = [int(rng.integers(1, V)) for _ in range(3)]
+    _, outs = eng.infer(rt.RnnInput([rt.RnnInputBatch([toks[b]]) for b in range(3)]))
+    for b in range(3):
+        want = ref.forward([toks[b]], states[b])[-1]
+        assert np.abs(outs[b][-1] - want).max() <= tol(rt.Precision.Fp32, want)
+        assert np.abs(eng.state.back(b) - states[b]).max() <= tol(rt.Precision.Fp32, states[b])
+    eng.close()
