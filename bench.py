@@ -79,7 +79,6 @@ def main():
            .build(max_batch=max(B, 1), token_chunk_size=max(2048, B),
                   precision=rt.Precision.Fp32 if args.precision == "fp32" else rt.Precision.Fp16))
     t_load = time.time() - t0
-    del st
 
     V = info.num_vocab
     first = np.array([R.synth_prompt(s, 1)[0] % V for s in range(B)], dtype=np.uint32)
@@ -214,22 +213,36 @@ def main():
     if rank == 0 and world == 1 and not args.decode_only:
         doc_len, layer = 256, info.num_layer - 1
         docs = [[t % V for t in R.synth_prompt(100 + b, doc_len)] for b in range(B)]
-        zero = eng.state.init()
-        best = None
-        for rep in range(3):
-            for b in range(B):
-                eng.state.load(zero, b)
-            t = time.perf_counter()
-            inp = rt.RnnInput([rt.RnnInputBatch(list(docs[b]) if b < B else [], rt.RnnOption.NoOutput)   # state-only: no head GEMM, no logits
-                               for b in range(eng.max_batch)])
-            while inp.num_token() > 0:
-                inp, _ = eng.infer(inp)
-            vecs = [eng.state.embed(layer, b) for b in range(B)]
-            dt_e = time.perf_counter() - t
-            best = dt_e if best is None else min(best, dt_e)
+
+        def embed_rate(e):
+            zero = e.state.init()
+            best = None
+            for rep in range(3):
+                for b in range(B):
+                    e.state.load(zero, b)
+                t = time.perf_counter()
+                inp = rt.RnnInput([rt.RnnInputBatch(list(docs[b]) if b < B else [], rt.RnnOption.NoOutput)   # state-only: no head GEMM, no logits
+                                   for b in range(e.max_batch)])
+                while inp.num_token() > 0:
+                    inp, _ = e.infer(inp)
+                vecs = [e.state.embed(layer, b) for b in range(B)]
+                dt_e = time.perf_counter() - t
+                best = dt_e if best is None else min(best, dt_e)
+            return best
+
+        best = embed_rate(eng)
         emb = {"value": B / best, "unit": "embeddings/s", "doc_tokens": doc_len, "docs": B,
                "prefill_tokens_per_s": B * doc_len / best, "token_chunk_size": eng.token_chunk_size,
                "embedding": f"layer {layer} WKV rows [64 x {info.num_emb}] via rwkv_state_back_layer"}
+        # the same job at SURVEY config #4's token_chunk_size (256 tokens per rwkv_infer call): a second engine over the same
+        # checkpoint, since the chunk is a load-time parameter (ReloadRequest::token_chunk_size, lib.rs:221-223)
+        e256 = (rt.ModelBuilder(st, adapter=local_rank).quant(ql, rt.Quant(qt))
+                .build(max_batch=max(B, 1), token_chunk_size=256,
+                       precision=rt.Precision.Fp32 if args.precision == "fp32" else rt.Precision.Fp16))
+        b256 = embed_rate(e256)
+        e256.close()
+        emb["at_token_chunk_size_256"] = {"value": B / b256, "prefill_tokens_per_s": B * doc_len / b256}
+    del st
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.decode_only:
@@ -277,6 +290,7 @@ def main():
         sh7 = {k: v.shape for k, v in t7.items()}
         flops_tok = 2.0 * sum(int(np.prod(v)) for k, v in sh7.items() if k != "emb.weight")
         e7 = rt.ModelBuilder(st7, adapter=local_rank).build(max_batch=8, token_chunk_size=2048, precision=rt.Precision.Fp16)
+        e7b = rt.ModelBuilder(st7, adapter=local_rank).build(max_batch=8, token_chunk_size=1024, precision=rt.Precision.Fp16)   # SURVEY's chunk for config #5
         del st7, t7
         docs = [[t % i7.num_vocab for t in R.synth_prompt(500 + b, 4096)] for b in range(8)]
         best = None
@@ -293,6 +307,20 @@ def main():
                 calls += 1
             dt7 = time.perf_counter() - t
             best = dt7 if best is None else min(best, dt7)
+        def prefill7(e):
+            bst = None
+            for rep in range(2):
+                z = e.state.init()
+                for b in range(8):
+                    e.state.load(z, b)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                inp = rt.RnnInput([rt.RnnInputBatch(list(docs[b]), rt.RnnOption.Last) for b in range(8)])
+                while inp.num_token() > 0:
+                    inp, _ = e.infer(inp)
+                d = time.perf_counter() - t
+                bst = d if bst is None else min(bst, d)
+            return bst
         f7 = np.array([int(np.argmax(outs[b][-1])) for b in range(8)], dtype=np.uint32)
         e7.decode_greedy(f7, 8)
         _, dms = e7.decode_greedy(f7, 256)
@@ -303,6 +331,8 @@ def main():
                 "decode_tokens_per_s": 8 * 256 / (dms * 1e-3), "decode_ms_per_step": dms / 256,
                 "decode_frac_of_hbm_peak": ab7["per_step"] / (dms / 256 * 1e-3) / HBM_PEAK}
         e7.close()
+        cfg5["prefill_tokens_per_s_at_token_chunk_size_1024"] = 8 * 4096 / prefill7(e7b)
+        e7b.close()
 
     if rank == 0:
         line = {"metric": "decode tokens/sec (whole job)", "value": value, "unit": "tokens/s", "n_gpus": world,
