@@ -950,20 +950,31 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
         }
     };
     if constexpr (WIDE) {
-        for (int sidx = wave; sidx < (C >> 4); sidx += 8) {
-            const int r0 = sidx * 16 + (lane >> 4) * 4;
-            u32x4 w2[DS / 2];
+        // strips sg*8 + wave, then + 8*gridDim.x: the launch spreads a mix's strips over gridDim.x blocks when the step has few
+        // token tiles (each of them recomputes m_c for its tile); the next strip's operands are requested before the current
+        // strip is multiplied, so a strip costs its MFMAs and stores, not an L2 round trip
+        struct StripIn { u32x4 w2[DS / 2]; float4 muv, xxs[NT], dxs[NT]; };
+        const int sstep = 8 * (int)gridDim.x, nst = C >> 4;
+        auto fetch = [&](int sidx, StripIn &in) {
+            const int sc = min(sidx, nst - 1);
+            const int r0 = sc * 16 + (lane >> 4) * 4;
 #pragma unroll
-            for (int ks = 0; ks < DS / 2; ++ks) w2[ks] = ((const u32x4 *)a.W2[c])[((long)sidx * (DS / 2) + ks) * 64 + lane];
-            const float4 muv = *(const float4 *)(a.mu[c] + r0);
-            float4 xxs[NT], dxs[NT];
+            for (int ks = 0; ks < DS / 2; ++ks) in.w2[ks] = ((const u32x4 *)a.W2[c])[((long)sc * (DS / 2) + ks) * 64 + lane];
+            in.muv = *(const float4 *)(a.mu[c] + r0);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int t = min(t0 + nt * 16 + (lane & 15), T - 1);
-                xxs[nt] = act_ld4(bxx, (long)t * C + r0);
-                dxs[nt] = act_ld4(bdx, (long)t * C + r0);
+                in.xxs[nt] = act_ld4(bxx, (long)t * C + r0);
+                in.dxs[nt] = act_ld4(bdx, (long)t * C + r0);
             }
-            do_strip(sidx, w2, muv, xxs, dxs);
+        };
+        StripIn cur, nxt;
+        int sidx = sg * 8 + wave;
+        if (sidx < nst) fetch(sidx, cur);
+        for (; sidx < nst; sidx += sstep) {
+            if (sidx + sstep < nst) fetch(sidx + sstep, nxt);
+            do_strip(sidx, cur.w2, cur.muv, cur.xxs, cur.dxs);
+            cur = nxt;
         }
     } else {
         if (strip < (C >> 4)) do_strip(strip, w2t, mu, xxv, dxv);
@@ -981,7 +992,8 @@ void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
     const size_t lds = (size_t)8 * 4 * NT * 64 * 16 + (size_t)2 * NT * 16 * (a.Dm + 8) * 2 + (lnp ? lnp_lds_bytes(LNP_MAX_T, a.C, hilo) : 0);
     dim3 grid((a.C / 16 + 7) / 8, 5), block(512);
     if (wide) {
-        grid = dim3(1, 5, (a.T + 31) / 32);
+        const int ntile = (a.T + 31) / 32;
+        grid = dim3(std::max(1, std::min(8, 256 / (5 * ntile))), 5, ntile);   // fill the chip when the step has few token tiles
         if (a.Dm == 32) { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 2, false, true>), grid, block, lds, s, a); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 2, false, true>), grid, block, lds, s, a); }
         else { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 4, false, true>), grid, block, lds, s, a); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 4, false, true>), grid, block, lds, s, a); }
         return;

@@ -9,6 +9,10 @@ info = R.model_info(tens)
 eng = rt.ModelBuilder(st).quant(info.num_layer if quant else 0, rt.Quant(quant)).build(max_batch=B, token_chunk_size=chunk)
 V = info.num_vocab
 prompts = [[t % V for t in R.synth_prompt(s, T)] for s in range(B)]
+if os.environ.get('PROBE_MAPS'):
+    for ln in open('/proc/self/maps'):
+        if 'r-xp' in ln and any(k in ln for k in ('hip', 'hsa', 'rocprof', 'rwkv', 'libc.so', 'roctx', 'amd_comgr')):
+            print('MAP', ln.strip(), flush=True)
 for rep in range(2):
     inp = rt.RnnInput([rt.RnnInputBatch(list(p), rt.RnnOption.Last) for p in prompts])
     t0 = time.perf_counter(); calls = 0
