@@ -882,6 +882,11 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         long tot64 = 0;
         for (auto &s : ps) tot64 += gemm_tile_blocks(3, s.W->rows, T);
         int shape = tot64 <= 1536 ? 4 : 3;
+        // fp16 weights fill a wave's registers twice as fast as Int8: the 128-k chunks (more blocks per CU) win at every grid size
+        // since the LDS image is in fragment order (rkvg fp16 T = 512: 489 -> 534 TFLOP/s, T = 256: 374 -> 456)
+        bool all_f16 = true;
+        for (auto &s : ps) all_f16 = all_f16 && s.W->fmt == W_F16;
+        if (all_f16) shape = 3;
         // the direct-to-LDS 128x64 shape (7: two strips per wave, X tiles by global_load_lds) pays only for very large
         // grids: 7B fp16 prefill at chunk 1024 25.9 -> 27.5 k tok/s, but 21.3 -> 17.8 k at chunk 512; the 256x128
         // GLDS shape (9) wins isolated large fp16 GEMMs (404 -> 536 TFLOP/s) and loses the model (small matrices starve)

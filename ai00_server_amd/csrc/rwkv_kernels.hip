@@ -1028,7 +1028,7 @@ bool v6_mix_ln_supported(int T, int C, int Dm, bool hilo, int np) {
 // by all waves; the wave's weight tiles go HBM/L2 -> registers (prefetched one chunk ahead) and every
 // dequantised A fragment feeds 8 MFMAs.  Bound: MFMA (2*rows*K*T flops), weights re-read T/128 times from L2/MALL.
 // =====================================================================================
-// KC = k per chunk (128 or 256); LDS row stride KC + 8 halfs (16 B pad: conflict-free ds_read_b128)
+// KC = k per chunk (128 or 256)
 template <int FMT, int SPW, int KC> struct TRound { u32x4 q[SPW][(KC / 32) / Fmt<FMT>::KS]; uint2 s[SPW]; };
 
 // FULL = true: the whole chunk lies inside K -> no predicates (strips beyond the matrix are clamped to the last
@@ -1140,7 +1140,7 @@ __device__ __forceinline__ void tg_epilogue(const GemmLaunch &L, const GemmProb 
 
 template <bool HILO, int WAVES, int SPW, int NTL, int KC, int FMT, bool GLDS>
 __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
-    constexpr int BT = NTL * 16, THREADS = WAVES * 64, STRIPS = WAVES * SPW, TG_KC = KC, TG_STRIDE = KC + 8;
+    constexpr int BT = NTL * 16, THREADS = WAVES * 64, STRIPS = WAVES * SPW, TG_KC = KC;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nstrips = P.rows >> 4;
@@ -1163,8 +1163,8 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
     const int t0 = tt * BT;
     const int K = P.K;
     const int nchunk = (K + TG_KC - 1) / TG_KC;
-    constexpr int PART = GLDS ? NTL * (KC / 32) * 512 : BT * TG_STRIDE;   // halfs per (buffer, hi|lo)
-    _Float16 *xs = (_Float16 *)smem;                              // [buf][hi|lo][BT][TG_STRIDE]
+    constexpr int PART = NTL * (KC / 32) * 512;                   // halfs per (buffer, hi|lo): [token tile][k-tile][lane][8], fragment order
+    _Float16 *xs = (_Float16 *)smem;                              // [buf][hi|lo][token tile][k-tile][lane][8]
     constexpr int XP = BT * TG_KC / 8 / THREADS;                  // 16-byte pieces per thread per part
     Nf4Lut lut;
     if constexpr (FMT == W_NF4) lut = make_nf4_lut();
@@ -1177,7 +1177,7 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
 
     // X staging registers (one chunk ahead of the LDS buffer being multiplied).  The operand is B-tiled in HBM
     // (opd_off): piece p of a chunk = (tile p/64, lane p%64), so a wave reads one contiguous 1 KiB tile per step and
-    // scatters it into the row-major LDS image (row stride KC+8 halfs: conflict-free).  Token tiles beyond the step
+    // writes it to LDS in the same order (stage_store).  Token tiles beyond the step
     // are clamped to its last tile (their results are never stored); FULL chunks carry no predicates at all.
     struct XRegs { uint4 h[XP], l[HILO ? XP : 1]; };
     constexpr int KTC = TG_KC / 32;                               // k-tiles per chunk
@@ -1201,15 +1201,16 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
             }
         }
     };
+    // the LDS image keeps the operand's own fragment order (piece p = tile p/64, lane p%64 lands at 16 p): contiguous
+    // ds_write_b128 per wave, and the MFMA loop reads a fragment with one contiguous conflict-free ds_read_b128 (a padded
+    // row-major image cost 40 % extra LDS cycles in bank conflicts under gfx950's b128 lane grouping)
     auto stage_store = [&](const XRegs &x, int buf) {
         _Float16 *bh = xs + (HILO ? buf * 2 : buf) * PART;
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int p = tid + i * THREADS;
-            const int tile = p >> 6, j = p & 63;
-            const int r = (tile / KTC) * 16 + (j & 15), c8 = (tile % KTC) * 4 + (j >> 4);
-            *(uint4 *)(bh + r * TG_STRIDE + c8 * 8) = x.h[i];
-            if constexpr (HILO) *(uint4 *)(bh + PART + r * TG_STRIDE + c8 * 8) = x.l[i];
+            *(uint4 *)(bh + p * 8) = x.h[i];
+            if constexpr (HILO) *(uint4 *)(bh + PART + p * 8) = x.l[i];
         }
     };
     // GLDS staging: tile i = (token tile i / KTC, k-tile i % KTC) of the chunk is one 1 KiB direct-to-LDS load, issued by
@@ -1243,7 +1244,7 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
                 f16x8 xv[NTL], xc[HILO ? NTL : 1];                  // all B fragments of the k-step in flight at once
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt) {
-                    const int off = GLDS ? ((nt * KTC + ks) * 64 + lane) * 8 : (nt * 16 + (lane & 15)) * TG_STRIDE + ks * 32 + (lane >> 4) * 8;
+                    const int off = ((nt * KTC + ks) * 64 + lane) * 8;
                     xv[nt] = *(const f16x8 *)(bh + off);
                     if constexpr (HILO) xc[nt] = *(const f16x8 *)(bh + PART + off);
                 }
@@ -1539,8 +1540,7 @@ void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s) 
         return;
     }
     const int bt = kTileShapes[shape][2] * 16, kc = kTileShapes[shape][3];
-    const size_t lds = kTileShapes[shape][4] ? (size_t)2 * (hilo ? 2 : 1) * (bt / 16) * (kc / 32) * 1024
-                                             : (size_t)2 * (hilo ? 2 : 1) * bt * (kc + 8) * 2;
+    const size_t lds = (size_t)2 * (hilo ? 2 : 1) * (bt / 16) * (kc / 32) * 1024;
     static bool attr_done[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
