@@ -5,9 +5,11 @@
 //   2. request B = prompt1 is queued while A is mid-flight and rides the next step (continuous batching);
 //   3. both decode `n_new` greedy tokens and finish (states cached under their contents);
 //   4. request C = prompt0 + A's tokens + `tail` continues from the cached state (Continue, prefix = all of A) and
-//      decodes `n_new` more.
+//      decodes `n_new` more;
+//   5. C's slot scores three choices (GenerateKind::Choose, calibrated) and gets its state back.
 // Usage: serve_loop <model.st> <quant_layers> <quant_type> <max_batch> <chunk> <n_new> <prompt0 ...> / <prompt1 ...> / <tail ...>
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,6 +64,12 @@ int main(int argc, char **argv) {
             sched.push(c, tc);
             sched.step();
         }
+        // 5. GenerateKind::Choose on C where it stands (run.rs:936-979): choices = the first three tokens of prompt1, the tail, and an
+        //    empty one; calibrated against the initial state; the slot's state must come back bit-identical (device snapshot)
+        const std::vector<float> before = sched.state(c);
+        const std::vector<rwkv::Tokens> choices = {rwkv::Tokens(parts[1].begin(), parts[1].begin() + std::min<size_t>(3, parts[1].size())), parts[2], {}};
+        const std::vector<float> ppl = sched.choose(c, choices, true);
+        const bool restored = sched.state(c) == before;
         sched.finish(c);
         for (auto t : gen_a) std::printf("%u ", t);
         std::printf("\n");
@@ -70,6 +78,7 @@ int main(int argc, char **argv) {
         for (auto t : gen_c) std::printf("%u ", t);
         std::printf("\n");
         std::printf("meta %d %d %d %d %d %zu\n", riders_first, riders_second, a, c, (int)rc, c_prefix);
+        std::printf("choose %.6f %.6f %s restored %d\n", ppl[0], ppl[1], std::isinf(ppl[2]) ? "inf" : "finite", (int)restored);
         return 0;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());

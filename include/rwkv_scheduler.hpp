@@ -6,6 +6,8 @@
 //   Scheduler::queue           run.rs:488-626   pick a slot, check the state out of the cache, load it, split prefix / suffix
 //   Scheduler::step            run.rs:1113-1157 one `infer` over EVERY slot that has tokens pending
 //   Scheduler::finish          run.rs:629-662   busy slot -> Idle(content), state + output cached under the content
+//   Scheduler::perplexity      run.rs:699-755   Full rows of a token list -> -mean ln p of the realised tokens
+//   Scheduler::choose / state  run.rs:936-989   GenerateKind::Choose (perplexity per choice, optional calibration) / ::State
 //
 // Differences from the reference, on purpose: (1) synchronous — the caller owns the thread (the reference spreads this over
 // tokio tasks and channels; the decisions are the same); (2) `step()` re-collects the pending tokens of all busy slots on
@@ -17,7 +19,9 @@
 //                                       std::vector<RnnOutputBatch> infer(RnnInput &)  (consumes tokens in place).
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <limits>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -268,37 +272,69 @@ class Scheduler {
     }
 
     // one device step over every busy slot with tokens pending; returns the number of slots that rode it
-    int step() {
-        RnnInput in;
-        in.batches.resize(slots_.size());
-        int riders = 0;
-        for (size_t b = 0; b < slots_.size(); ++b) {
-            if (slots_[b].kind != SlotKind::Busy || reqs_[b].suffix.empty()) continue;
-            in.batches[b].tokens = reqs_[b].suffix;
-            in.batches[b].option = reqs_[b].option;
-            ++riders;
-        }
-        if (!riders) return 0;
-        std::vector<RnnOutputBatch> out = e_.infer(in);
-        const size_t V = (size_t)e_.info.num_vocab;
-        for (size_t b = 0; b < slots_.size(); ++b) {
-            if (slots_[b].kind != SlotKind::Busy || reqs_[b].suffix.empty()) continue;
-            Request &r = reqs_[b];
-            const size_t consumed = r.suffix.size() - in.batches[b].tokens.size();
-            r.prefix.insert(r.prefix.end(), r.suffix.begin(), r.suffix.begin() + (long)consumed);
-            r.suffix.erase(r.suffix.begin(), r.suffix.begin() + (long)consumed);
-            for (size_t row = 0; row + 1 <= out[b].size() / V; ++row) {
-                std::vector<float> lg(out[b].begin() + (long)(row * V), out[b].begin() + (long)((row + 1) * V));
-                if (r.option == RnnOption::Full) r.rows.push_back(lg);
-                r.output = std::move(lg);
-            }
-            if (r.cache_prompt && r.suffix.empty() && r.prefix.size() == r.prompt_len && !r.output.empty()) {   // run.rs:829-838
-                cache_of(r.state_id).insert(r.prefix, e_.state.back((int)b), r.output, ++clock_);
-                r.cache_prompt = false;
-            }
-        }
-        return riders;
+    int step() { return step_impl(nullptr); }
+
+    // `perplexity` (run.rs:699-755).  `tokens` ride the engine with RnnOption::Full on slot `batch` (whose request must have
+    // nothing pending); row j (j = 1, 2, …) yields softmax(row)[tokens'[j]] — exp / sum WITHOUT max subtraction, as the
+    // reference computes it — where tokens' = tokens when the probability of tokens[0] is known (`head`, the sampled
+    // distribution of the prompt's last token), else [0] ++ tokens; result = -sum(ln p) / len(tokens').  The slot's state
+    // advances by tokens'; every other busy slot with tokens pending rides the same device steps.
+    float perplexity(int batch, const Tokens &tokens, const float *head) {
+        need_busy(batch);
+        if (!reqs_[(size_t)batch].suffix.empty()) throw std::logic_error("perplexity(): the slot still has tokens pending");
+        Probe pr;
+        pr.batch = batch;
+        if (head) { pr.p.push_back(*head); pr.all = tokens; }
+        else { pr.all.push_back(0); pr.all.insert(pr.all.end(), tokens.begin(), tokens.end()); }
+        pr.left = pr.all;
+        pr.want = tokens.size();
+        while (!pr.left.empty()) step_impl(&pr);
+        double acc = 0.0;
+        for (float x : pr.p) acc += std::log((double)x);
+        return (float)(-acc / (double)pr.all.size());
     }
+
+    // GenerateKind::Choose (run.rs:936-979): once the prompt has been read in, score every non-empty choice by the perplexity
+    // of its tokens continuing the prompt (`head` = probs[choice[0]], `probs` being the distribution `sample()` returned for
+    // the prompt's last token; empty `probs` = plain softmax of the request's last logits); with `calibrate`, first add minus
+    // the perplexity of the choice on its own from the request's initial state.  The slot's state is snapshotted before and put
+    // back after every evaluation (`read` / `write`, run.rs:938, 960, 976), so the request can go on afterwards.  Empty
+    // choices score +inf.
+    std::vector<float> choose(int batch, const std::vector<Tokens> &choices, bool calibrate, std::vector<float> probs = {}) {
+        need_busy(batch);
+        Request &r = reqs_[(size_t)batch];
+        if (!r.suffix.empty() || r.output.empty()) throw std::logic_error("choose(): the prompt has not been read in yet");
+        if (probs.empty()) {
+            probs = r.output;
+            float mx = probs[0];
+            for (float x : probs) mx = std::max(mx, x);
+            double sum = 0.0;
+            for (float &x : probs) { x = std::exp(x - mx); sum += x; }
+            for (float &x : probs) x = (float)(x / sum);
+        }
+        auto backed = snapshot(e_.state, batch, 0);
+        std::vector<float> ppl(choices.size(), std::numeric_limits<float>::infinity());
+        if (calibrate) {
+            const std::vector<float> init = r.state_id != 0 ? init_states_.at(r.state_id) : e_.state.init();
+            for (size_t i = 0; i < choices.size(); ++i) {
+                if (choices[i].empty()) continue;
+                e_.state.load(init, batch);
+                ppl[i] = -perplexity(batch, choices[i], nullptr);
+            }
+            restore(e_.state, backed, batch, 0);
+        }
+        for (size_t i = 0; i < choices.size(); ++i) {
+            if (choices[i].empty()) continue;
+            const float head = probs.at(choices[i][0]);
+            const float p = perplexity(batch, choices[i], &head);
+            ppl[i] = calibrate ? ppl[i] + p : p;
+            restore(e_.state, backed, batch, 0);
+        }
+        return ppl;
+    }
+
+    // GenerateKind::State (run.rs:980-985): the slot's state slab as it stands (`Token::Embed(embed, shape)`).
+    std::vector<float> state(int batch) { need_busy(batch); return e_.state.back(batch); }
 
     Request &request(int batch) { need_busy(batch); return reqs_[batch]; }
 
@@ -319,6 +355,65 @@ class Scheduler {
     PrefixCache &cache(uint64_t state_id = 0) { return cache_of(state_id); }
 
    private:
+    struct Probe {                                // a Full run on one slot that is not part of its request (perplexity)
+        int batch = -1;
+        Tokens all, left;                         // tokens' and what of it is still to feed
+        std::vector<float> p;
+        size_t index = 1, want = 0;
+    };
+    int step_impl(Probe *probe) {
+        RnnInput in;
+        in.batches.resize(slots_.size());
+        int riders = 0;
+        for (size_t b = 0; b < slots_.size(); ++b) {
+            if (probe && (int)b == probe->batch) {
+                in.batches[b].tokens = probe->left;
+                in.batches[b].option = RnnOption::Full;
+                ++riders;
+                continue;
+            }
+            if (slots_[b].kind != SlotKind::Busy || reqs_[b].suffix.empty()) continue;
+            in.batches[b].tokens = reqs_[b].suffix;
+            in.batches[b].option = reqs_[b].option;
+            ++riders;
+        }
+        if (!riders) return 0;
+        std::vector<RnnOutputBatch> out = e_.infer(in);
+        const size_t V = (size_t)e_.info.num_vocab;
+        for (size_t b = 0; b < slots_.size(); ++b) {
+            if (probe && (int)b == probe->batch) {
+                probe->left = in.batches[b].tokens;                                 // what the engine did not consume yet
+                for (size_t row = 0; row + 1 <= out[b].size() / V; ++row, ++probe->index) {
+                    if (probe->p.size() >= probe->want || probe->index >= probe->all.size()) continue;
+                    const float *lg = out[b].data() + row * V;
+                    float sum = 0.f;
+                    for (size_t v = 0; v < V; ++v) sum += std::exp(lg[v]);
+                    probe->p.push_back(std::exp(lg[probe->all[probe->index]]) / sum);
+                }
+                continue;
+            }
+            if (slots_[b].kind != SlotKind::Busy || reqs_[b].suffix.empty()) continue;
+            Request &r = reqs_[b];
+            const size_t consumed = r.suffix.size() - in.batches[b].tokens.size();
+            r.prefix.insert(r.prefix.end(), r.suffix.begin(), r.suffix.begin() + (long)consumed);
+            r.suffix.erase(r.suffix.begin(), r.suffix.begin() + (long)consumed);
+            for (size_t row = 0; row + 1 <= out[b].size() / V; ++row) {
+                std::vector<float> lg(out[b].begin() + (long)(row * V), out[b].begin() + (long)((row + 1) * V));
+                if (r.option == RnnOption::Full) r.rows.push_back(lg);
+                r.output = std::move(lg);
+            }
+            if (r.cache_prompt && r.suffix.empty() && r.prefix.size() == r.prompt_len && !r.output.empty()) {   // run.rs:829-838
+                cache_of(r.state_id).insert(r.prefix, e_.state.back((int)b), r.output, ++clock_);
+                r.cache_prompt = false;
+            }
+        }
+        return riders;
+    }
+    // device-resident snapshot when the engine's State has read / write (rwkv::State), host round trip otherwise
+    template <class S> static auto snapshot(S &s, int b, int) -> decltype(s.read(b)) { return s.read(b); }
+    template <class S> static std::vector<float> snapshot(S &s, int b, long) { return s.back(b); }
+    template <class S, class T> static auto restore(S &s, const T &t, int b, int) -> decltype(s.write(t, b)) { return s.write(t, b); }
+    template <class S> static void restore(S &s, const std::vector<float> &t, int b, long) { s.load(t, b); }
     void need_busy(int batch) const {
         if (batch < 0 || batch >= (int)slots_.size() || slots_[(size_t)batch].kind != SlotKind::Busy) throw std::invalid_argument("slot is not busy");
     }

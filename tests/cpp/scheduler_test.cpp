@@ -171,6 +171,86 @@ int main() {
         r = scan_stops(bytes("ab</s>cd"), {"zzz", "</s>"});
         CHECK(r.matched && r.head == 2);                                 // a matched stop wins over an unmatched one
     }
+    // --- GenerateKind::Choose / ::State and `perplexity` (run.rs:699-755, 936-989) against a stand-alone replay of the fake engine
+    {
+        // replay: state (hash, count) after `toks` from `st`, and the fake logits row of every token
+        auto replay = [](std::vector<float> st, const Tokens &toks, std::vector<std::vector<float>> &rows) {
+            for (uint32_t t : toks) {
+                st[0] = std::fmod(st[0] * 31.0f + (float)t + 1.0f, 65521.0f);
+                st[1] += 1.0f;
+                std::vector<float> lg(8);
+                for (int v = 0; v < 8; ++v) lg[(size_t)v] = std::fmod(st[0] + 7.0f * v, 13.0f);
+                rows.push_back(lg);
+            }
+            return st;
+        };
+        auto prob = [](const std::vector<float> &lg, uint32_t tok) {       // exp / sum, no max subtraction (run.rs:737-740)
+            float sum = 0.f;
+            for (float x : lg) sum += std::exp(x);
+            return std::exp(lg[tok]) / sum;
+        };
+        auto ref_ppl = [&](const std::vector<float> &st, const Tokens &toks, const float *head) {
+            Tokens all = toks;
+            std::vector<float> p;
+            if (head) p.push_back(*head); else all.insert(all.begin(), 0u);
+            std::vector<std::vector<float>> rows;
+            replay(st, all, rows);
+            for (size_t j = 1; j < all.size(); ++j) p.push_back(prob(rows[j - 1], all[j]));
+            double acc = 0.0;
+            for (float x : p) acc += std::log((double)x);
+            return (float)(-acc / (double)all.size());
+        };
+        FakeEngine e(2, 2);                                              // 2 tokens per slot per call: several steps per evaluation
+        Scheduler<FakeEngine> s(e);
+        const Tokens prompt = {5, 1, 2, 6, 3};
+        int b = -1, other = -1;
+        CHECK(s.queue(prompt, b) == SlotResult::Success);
+        while (s.pending()) s.step();
+        std::vector<std::vector<float>> prow;
+        const std::vector<float> after_prompt = replay(e.state.init(), prompt, prow);
+        CHECK(e.state.back(b) == after_prompt && s.request(b).output == prow.back());
+        // another request is mid-prefill while the choices are scored: it must ride the same device steps
+        CHECK(s.queue({7, 7, 7, 7, 7, 7, 7, 7, 7}, other) == SlotResult::Success && other != b);
+        const std::vector<Tokens> choices = {{1, 2, 3}, {}, {4}, {6, 6, 0, 1, 2}};
+        // probabilities handed in by the caller (what `sample()` returned), here: a plain softmax of the last logits
+        std::vector<float> probs(8);
+        { float mx = *std::max_element(prow.back().begin(), prow.back().end()); double sum = 0; for (int v = 0; v < 8; ++v) { probs[(size_t)v] = std::exp(prow.back()[(size_t)v] - mx); sum += probs[(size_t)v]; } for (float &x : probs) x = (float)(x / sum); }
+        const int calls_before = e.calls;
+        std::vector<float> got = s.choose(b, choices, false, probs);
+        CHECK(got.size() == 4 && std::isinf(got[1]) && got[1] > 0);      // the empty choice keeps +inf
+        for (size_t i : {0u, 2u, 3u}) {
+            const float head = probs[choices[i][0]];
+            const float want = ref_ppl(after_prompt, choices[i], &head);
+            CHECK(std::fabs(got[i] - want) <= 1e-6f * std::max(1.0f, std::fabs(want)));
+        }
+        CHECK(e.calls > calls_before);
+        CHECK(e.state.back(b) == after_prompt);                          // the slot is back where the prompt left it
+        CHECK(s.request(other).suffix.empty() && s.request(other).prefix.size() == 9);   // the other request rode along
+        // default probabilities (softmax of the request's last logits) and calibration against the initial state
+        std::vector<float> cal = s.choose(b, choices, true);
+        for (size_t i : {0u, 2u, 3u}) {
+            const float head = probs[choices[i][0]];
+            const float want = -ref_ppl(e.state.init(), choices[i], nullptr) + ref_ppl(after_prompt, choices[i], &head);
+            CHECK(std::fabs(cal[i] - want) <= 2e-6f * std::max(1.0f, std::fabs(want)));
+        }
+        CHECK(e.state.back(b) == after_prompt);
+        // perplexity on its own: no head -> token 0 is prepended and counted in the denominator
+        const float pp = s.perplexity(b, {2, 2}, nullptr);
+        CHECK(std::fabs(pp - ref_ppl(after_prompt, {2, 2}, nullptr)) <= 1e-6f);
+        // State kind: the slab as it stands
+        std::vector<std::vector<float>> tmp;
+        CHECK(s.state(b) == replay(after_prompt, {0, 2, 2}, tmp));
+        // the request can go on afterwards
+        s.push(b, 4);
+        while (s.pending()) s.step();
+        s.finish(b); s.finish(other);
+        // misuse: choices before the prompt has been read in
+        int c = -1;
+        CHECK(s.queue({1, 1, 1, 1}, c) != SlotResult::Failure);
+        bool threw = false;
+        try { s.choose(c, choices, false); } catch (const std::logic_error &) { threw = true; }
+        CHECK(threw);
+    }
     std::printf("scheduler_test: ok\n");
     return 0;
 }

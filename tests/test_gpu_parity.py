@@ -615,6 +615,27 @@ def test_cpp_scheduler_serves_real_engine(tmp_path):
     assert riders_first == 1 and riders_second == 2          # 21 prompt tokens at chunk 8: A is mid-flight when B joins
     assert slot_c == slot_a and rc == 0                       # Continue on A's slot, SlotResult::Success
     assert c_prefix == len(p0) + n_new                        # checked out at A's full history (prompt + every fed token)
+    # stage 5: GenerateKind::Choose (run.rs:936-979) on C's slot, calibrated, against the oracle's own evaluation
+    ch = lines[4].split()
+    assert ch[0] == "choose" and ch[3] == "inf" and ch[4:] == ["restored", "1"]
+    ctx = p0 + gen_a + tail + gen_c
+    st = ref.init_state()
+    lg = ref.forward(ctx, st)[-1].astype(np.float32)
+    probs = np.exp(lg - lg.max())
+    probs /= probs.sum(dtype=np.float32)
+
+    def ref_ppl(state, toks, head):                           # run.rs:699-755
+        all_ = list(toks) if head is not None else [0] + list(toks)
+        p = [head] if head is not None else []
+        rows = ref.forward(all_, state.copy(), full=True)
+        for j in range(1, len(all_)):
+            e = np.exp(rows[j - 1].astype(np.float32))
+            p.append(float(e[all_[j]] / e.sum(dtype=np.float32)))
+        return -sum(np.log(x) for x in p) / len(all_)
+
+    for got, choice in zip(ch[1:3], (p1[:3], tail)):
+        want = -ref_ppl(ref.init_state(), choice, None) + ref_ppl(st, choice, float(probs[choice[0]]))
+        assert abs(float(got) - want) <= 5e-3 * max(1.0, abs(want)), (got, want)
 
 
 def test_cpp_router_over_two_real_engines_on_one_device(tmp_path):
