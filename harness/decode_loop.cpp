@@ -2,6 +2,9 @@
 // on top of include/rwkv_runtime.hpp.  Usage:
 //   decode_loop <model.st> <quant_layers> <quant_type> <max_batch> <chunk> <n_new> <prompt tokens of slot 0> [/ <slot 1> ...]
 // Prints one line of greedy token ids per slot (arg-max == Nucleus top_k=1, nucleus.rs:77-89; token 0 stops, run.rs:855).
+// With RWKV_DECODE_SAMPLER=nucleus|typical|mirostat the same loop samples on the device instead (rwkv_infer_sample) with the
+// host-side sampler state of include/rwkv_sampler.hpp: init(prompt), then per token adjustments -> infer_sample -> update; the
+// uniform draw of (step, slot) is frac(0.137 + 0.618034 (step + 1) + 0.31 slot) so that a test can replay it.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -9,7 +12,11 @@
 #include <fstream>
 #include <iterator>
 
+#include <cmath>
+#include <string>
+
 #include "../include/rwkv_runtime.hpp"
+#include "../include/rwkv_sampler.hpp"
 
 int main(int argc, char **argv) {
     if (argc < 8) { std::fprintf(stderr, "usage: see header\n"); return 2; }
@@ -29,6 +36,46 @@ int main(int argc, char **argv) {
         for (size_t s = 0; s < prompts.size() && (int)s < B; ++s) {
             pending[s] = prompts[s].empty() ? std::vector<uint32_t>{0} : prompts[s];      // run.rs:489-492
             live[s] = true;
+        }
+        const char *mode_env = std::getenv("RWKV_DECODE_SAMPLER");
+        const std::string mode = mode_env ? mode_env : "";
+        if (!mode.empty()) {
+            std::vector<rwkv::NucleusSampler> nuc((size_t)B);
+            std::vector<rwkv::TypicalSampler> typ((size_t)B);
+            std::vector<rwkv::MirostatSampler> mir((size_t)B);
+            for (int b = 0; b < B; ++b) if (live[b]) { nuc[(size_t)b].init(pending[b]); typ[(size_t)b].init(pending[b]); }
+            for (int step = 0; step < n_new; ++step) {
+                rwkv::RnnInput input;
+                input.batches.resize((size_t)B);
+                std::vector<rwkv::SamplerAdjust> adj((size_t)B);
+                std::vector<rwkv_sample_params> sp((size_t)B);
+                for (int b = 0; b < B; ++b) {
+                    const float u = std::fmod(0.137f + 0.618034f * (float)(step + 1) + 0.31f * (float)b, 1.0f);
+                    if (live[b]) input.batches[(size_t)b].tokens = pending[b];
+                    if (mode == "typical") { adj[(size_t)b] = typ[(size_t)b].adjustments(); sp[(size_t)b] = typ[(size_t)b].params_for(u, adj[(size_t)b]); }
+                    else if (mode == "mirostat") sp[(size_t)b] = mir[(size_t)b].params_for(u, adj[(size_t)b]);
+                    else { adj[(size_t)b] = nuc[(size_t)b].adjustments(); sp[(size_t)b] = nuc[(size_t)b].params_for(u, adj[(size_t)b]); }
+                }
+                std::vector<rwkv::Runtime::Sampled> got((size_t)B);
+                while (input.num_token() > 0) {
+                    auto out = rt.infer_sample(input, sp);
+                    for (int b = 0; b < B; ++b) if (out[(size_t)b].emitted) got[(size_t)b] = out[(size_t)b];
+                }
+                for (int b = 0; b < B; ++b) {
+                    if (!live[b]) continue;
+                    const uint32_t tok = got[(size_t)b].token;
+                    if (mode == "typical") typ[(size_t)b].update(tok);
+                    else if (mode == "mirostat") mir[(size_t)b].update(got[(size_t)b].prob);       // the token surprise
+                    else nuc[(size_t)b].update(tok);
+                    gen[b].push_back(tok);
+                    pending[b] = {tok};
+                }
+            }
+            for (size_t s = 0; s < prompts.size() && (int)s < B; ++s) {
+                for (auto t : gen[s]) std::printf("%u ", t);
+                std::printf("\n");
+            }
+            return 0;
         }
         bool any = true;
         while (any) {

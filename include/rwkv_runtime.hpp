@@ -97,6 +97,30 @@ class Runtime {
         }
         return bufs;
     }
+    // rwkv_infer_sample: the on-device sampling front-end.  Slots whose pending tokens this call exhausts get a
+    // sampled token instead of a logits row; `sp[b]` comes from a host-side sampler (include/rwkv_sampler.hpp).  `input` is
+    // consumed in place like infer().
+    struct Sampled { bool emitted = false; uint32_t token = 0; float prob = 0.f; };
+    std::vector<Sampled> infer_sample(RnnInput &input, const std::vector<rwkv_sample_params> &sp) {
+        if ((int)input.batches.size() != max_batch || (int)sp.size() != max_batch) throw std::invalid_argument("infer_sample: need max_batch entries");
+        std::vector<rwkv_slot_input> in((size_t)max_batch);
+        for (int b = 0; b < max_batch; ++b) {
+            auto &ib = input.batches[(size_t)b];
+            in[(size_t)b] = rwkv_slot_input{ib.tokens.data(), ib.tokens.size(), (int32_t)RnnOption::Last, 0};
+        }
+        std::vector<uint32_t> tok((size_t)max_batch);
+        std::vector<float> prob((size_t)max_batch);
+        std::vector<uint8_t> emitted((size_t)max_batch);
+        std::vector<size_t> consumed((size_t)max_batch);
+        check(rwkv_infer_sample(e_.get(), in.data(), sp.data(), tok.data(), prob.data(), emitted.data(), consumed.data()));
+        std::vector<Sampled> out((size_t)max_batch);
+        for (int b = 0; b < max_batch; ++b) {
+            auto &t = input.batches[(size_t)b].tokens;
+            t.erase(t.begin(), t.begin() + (long)consumed[(size_t)b]);
+            out[(size_t)b] = Sampled{emitted[(size_t)b] != 0, tok[(size_t)b], prob[(size_t)b]};
+        }
+        return out;
+    }
     rwkv_engine *raw() const { return e_.get(); }
     ModelInfo info{};
     int max_batch = 0;

@@ -326,6 +326,52 @@ def test_cpp_host_mirror_decode_loop(tmp_path):
         assert got == want[:n] and (n == 12 or want[n] == 0)
 
 
+@pytest.mark.parametrize("mode", ["nucleus", "typical", "mirostat"])
+def test_cpp_sampler_state_drives_on_device_sampling(tmp_path, mode):
+    """harness/decode_loop.cpp with RWKV_DECODE_SAMPLER: include/rwkv_sampler.hpp (penalty maps / max_surprise on the host) +
+    Runtime::infer_sample over the real engine.  The Python mirrors (harness.NucleusSampler & co, themselves checked against the
+    reference samplers' restatements elsewhere in this file) replay the same loop with the same uniform draws on a second engine:
+    the ids must be identical token for token — same kernel, same adjustments, same feedback."""
+    import subprocess
+    from ai00_server_amd import build as B
+    from ai00_server_amd import harness as H
+    exe = B.build_harness(verbose=False) if not os.path.exists(B.HARNESS_BIN) else B.HARNESS_BIN
+    t = R.synth_named("v6-small")
+    path = tmp_path / "m.st"
+    path.write_bytes(R.st_serialize(t))
+    ref = R.RwkvRef(t)
+    p0, p1 = prompt(ref, 52, 9), prompt(ref, 53, 14)
+    n_new = 10
+    args = [exe, str(path), "2", "1", "3", "8", str(n_new)] + [str(x) for x in p0] + ["/"] + [str(x) for x in p1]
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300, env=dict(os.environ, RWKV_DECODE_SAMPLER=mode))
+    assert out.returncode == 0, out.stderr
+    got = [[int(x) for x in ln.split()] for ln in out.stdout.strip().splitlines()]
+    _, eng = build("v6-small", rt.Precision.Fp16, quant=(2, 1), B=3, chunk=8)
+    make = {"nucleus": H.NucleusSampler, "typical": H.TypicalSampler, "mirostat": H.MirostatSampler}[mode]
+    smp = [make(), make(), None]
+    pend = [list(p0), list(p1), []]
+    for b in range(2):
+        smp[b].init(pend[b])
+    want = [[], []]
+    for step in range(n_new):
+        us = [float(np.fmod(np.float32(0.137) + np.float32(0.618034) * np.float32(step + 1) + np.float32(0.31) * np.float32(b), np.float32(1.0)))
+              for b in range(3)]
+        inp = rt.RnnInput([rt.RnnInputBatch(list(pend[b])) for b in range(3)])
+        res = [None] * 3
+        while inp.num_token() > 0:
+            inp, outs = eng.infer_sample(inp, smp, us)
+            for b in range(2):
+                if outs[b] is not None:
+                    res[b] = outs[b]
+        for b in range(2):
+            tok, prob = res[b]
+            smp[b].update(prob if mode == "mirostat" else tok)
+            want[b].append(tok)
+            pend[b] = [tok]
+    eng.close()
+    assert got == want
+
+
 def test_full_v6_3b_greedy_ids_match_oracle():
     """BASELINE headline shape, all 32 layers (fp16 weights): 24-token prompt + 24 greedy tokens, ids identical to
     the fp32 oracle; last-prompt logits within the Fp16 tolerance; then the same ids again from the device-resident
