@@ -44,6 +44,21 @@ struct CachedItem {                              // run.rs:201-223
 class PrefixCache {                              // `Trie<Tokens, CachedItem>` keyed by whole token sequences
    public:
     explicit PrefixCache(size_t max_cached = 256) : max_cached_(max_cached) {}      // MAX_CACHE_ITEMS, run.rs:41
+    PrefixCache(const PrefixCache &) = delete;
+    PrefixCache &operator=(const PrefixCache &) = delete;
+    // A key is one trie node per token, so a cached 100k-token context is a 100k-deep chain of owning pointers: letting the
+    // default destructors unwind it recurses once per token and overflows the stack.  Tear the trie down iteratively.
+    ~PrefixCache() {
+        std::vector<std::unique_ptr<Node>> work;
+        for (auto &kv : root_.next) work.push_back(std::move(kv.second));
+        root_.next.clear();
+        while (!work.empty()) {
+            std::unique_ptr<Node> n = std::move(work.back());
+            work.pop_back();
+            for (auto &kv : n->next) work.push_back(std::move(kv.second));
+            n->next.clear();
+        }                                                                           // n dies here with no children left
+    }
     struct Checkout { size_t prefix_len = 0; std::vector<float> state, output; bool hit = false; };
     // longest cached key that is a prefix of `tokens` (run.rs:447-455); refreshes the item's stamp (CachedItem::update)
     Checkout checkout(const Tokens &tokens, uint64_t now) {
@@ -112,9 +127,15 @@ class PrefixCache {                              // `Trie<Tokens, CachedItem>` k
         uint32_t tok = 0;
         std::multimap<uint64_t, Node *>::iterator age;                              // valid while `item` is set
     };
-    static size_t count_nodes(const Node *n) {
-        size_t c = 1;
-        for (auto &kv : n->next) c += count_nodes(kv.second.get());
+    static size_t count_nodes(const Node *root) {                                   // iterative for the same reason as the destructor
+        size_t c = 0;
+        std::vector<const Node *> work{root};
+        while (!work.empty()) {
+            const Node *n = work.back();
+            work.pop_back();
+            ++c;
+            for (auto &kv : n->next) work.push_back(kv.second.get());
+        }
         return c;
     }
     void touch(Node *n, uint64_t now) {

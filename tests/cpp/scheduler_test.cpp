@@ -171,6 +171,22 @@ int main() {
         r = scan_stops(bytes("ab</s>cd"), {"zzz", "</s>"});
         CHECK(r.matched && r.head == 2);                                 // a matched stop wins over an unmatched one
     }
+    // --- a very long cached context: one trie node per token, torn down (destructor, eviction) without recursing per token
+    {
+        Tokens longkey(300000);
+        for (size_t i = 0; i < longkey.size(); ++i) longkey[i] = (uint32_t)(i * 2654435761u % 65536u);
+        {
+            PrefixCache c(2);
+            c.insert(longkey, {1.0f}, {2.0f}, 1);
+            CHECK(c.nodes() == longkey.size() && c.match_len(longkey) == longkey.size());
+            Tokens other = longkey;
+            other[150000] ^= 1u;                                         // shares half of the chain
+            c.insert(other, {3.0f}, {4.0f}, 2);
+            CHECK(c.nodes() == longkey.size() + (longkey.size() - 150000));
+            c.insert({7, 7, 7}, {5.0f}, {6.0f}, 3);                      // third item: the oldest (longkey) is evicted, its private tail pruned
+            CHECK(c.size() == 2 && c.match_len(longkey) == 0 && c.nodes() == longkey.size() + 3);
+        }                                                                // destructor over a 300k-deep chain
+    }
     // --- GenerateKind::Choose / ::State and `perplexity` (run.rs:699-755, 936-989) against a stand-alone replay of the fake engine
     {
         // replay: state (hash, count) after `toks` from `st`, and the fake logits row of every token
