@@ -28,14 +28,32 @@ static void mutate(std::vector<uint8_t> &b, size_t window) {
     if (b.empty()) return;
     window = window < b.size() ? window : b.size();
     switch (rnd() % 6) {
-        case 0: for (int k = 0, n = 1 + (int)(rnd() % 4); k < n; ++k) b[rnd() % window] ^= (uint8_t)(1u << (rnd() % 8)); break;      // bit flips
-        case 1: for (int k = 0, n = 1 + (int)(rnd() % 8); k < n; ++k) b[rnd() % window] = (uint8_t)rnd(); break;                    // random bytes
-        case 2: b.resize(rnd() % (b.size() + 1)); break;                                                                            // truncate anywhere
-        case 3: { const uint64_t v[] = {0, 1, 7, 8, 0xFFFFFFFFull, 0x7FFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull, (uint64_t)b.size(), (uint64_t)b.size() * 2};
-                  const uint64_t x = v[rnd() % 9]; if (b.size() >= 8) std::memcpy(b.data(), &x, 8); break; }                       // header length field
-        case 4: { const size_t at = rnd() % window, n = 1 + rnd() % 16; const char *digits = "0123456789-eE.[]{},:\"";
-                  for (size_t i = at; i < at + n && i < b.size(); ++i) b[i] = (uint8_t)digits[rnd() % 21]; break; }                 // JSON-ish garbage
-        case 5: { const size_t at = rnd() % window; b.insert(b.begin() + (long)at, (size_t)(1 + rnd() % 32), (uint8_t)('9')); break; }   // long numbers
+        case 0:                                                                      // bit flips
+            for (int k = 0, n = 1 + (int)(rnd() % 4); k < n; ++k) b[rnd() % window] ^= (uint8_t)(1u << (rnd() % 8));
+            break;
+        case 1:                                                                      // random bytes
+            for (int k = 0, n = 1 + (int)(rnd() % 8); k < n; ++k) b[rnd() % window] = (uint8_t)rnd();
+            break;
+        case 2:                                                                      // truncate anywhere
+            b.resize(rnd() % (b.size() + 1));
+            break;
+        case 3: {                                                                    // header length field
+            const uint64_t v[] = {0, 1, 7, 8, 0xFFFFFFFFull, 0x7FFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull, (uint64_t)b.size(), (uint64_t)b.size() * 2};
+            const uint64_t x = v[rnd() % 9];
+            if (b.size() >= 8) std::memcpy(b.data(), &x, 8);
+            break;
+        }
+        case 4: {                                                                    // JSON-ish garbage
+            const size_t at = rnd() % window, n = 1 + rnd() % 16;
+            const char *digits = "0123456789-eE.[]{},:\"";
+            for (size_t i = at; i < at + n && i < b.size(); ++i) b[i] = (uint8_t)digits[rnd() % 21];
+            break;
+        }
+        case 5: {                                                                    // long numbers
+            const size_t at = rnd() % window;
+            b.insert(b.begin() + (long)at, (size_t)(1 + rnd() % 32), (uint8_t)'9');
+            break;
+        }
     }
 }
 
