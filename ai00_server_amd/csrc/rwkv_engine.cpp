@@ -945,11 +945,12 @@ static void water_fill(long budget, const std::vector<size_t> &pending, std::vec
         std::vector<int> next;
         for (int b : act) {
             if (budget <= 0) break;
-            const long want = (long)pending[b] - take_out[b];
+            const long pend = (long)std::min<size_t>(pending[b], (size_t)1 << 40);   // a count, whatever the caller put there
+            const long want = pend - take_out[b];
             const long take = std::min({want, share, budget});
             take_out[b] += (int)take;
             budget -= take;
-            if (take_out[b] < (long)pending[b]) next.push_back(b);
+            if (take_out[b] < pend) next.push_back(b);
         }
         act.swap(next);
     }

@@ -159,7 +159,11 @@ class SafeTensors {
                 ws();
                 int64_t x = 0;
                 bool any = false;
-                while (peek() >= '0' && peek() <= '9') { x = x * 10 + (next() - '0'); any = true; }
+                while (peek() >= '0' && peek() <= '9') {
+                    if (x > (INT64_MAX - 9) / 10) throw std::runtime_error("safetensors: integer out of range");
+                    x = x * 10 + (next() - '0');
+                    any = true;
+                }
                 if (!any) throw std::runtime_error("safetensors: expected integer");
                 v.push_back(x);
                 ws();
@@ -169,7 +173,10 @@ class SafeTensors {
             }
             return v;
         }
-        void skip_value() {
+        // values the loader has no use for (`__metadata__`, unknown keys).  Nesting is bounded: a header is attacker-controlled
+        // bytes and every level is a stack frame.
+        void skip_value(int depth = 0) {
+            if (depth > 64) throw std::runtime_error("safetensors: header nested too deeply");
             ws();
             char c = peek();
             if (c == '"') { string(); return; }
@@ -181,7 +188,7 @@ class SafeTensors {
                 for (;;) {
                     ws();
                     if (c == '{') { string(); ws(); expect(':'); }
-                    skip_value();
+                    skip_value(depth + 1);
                     ws();
                     if (peek() == ',') { next(); continue; }
                     expect(close);

@@ -121,7 +121,11 @@ struct P {
     long integer() {
         long v = 0;
         bool any = false;
-        while (peek() >= '0' && peek() <= '9') { v = v * 10 + (next() - '0'); any = true; }
+        while (peek() >= '0' && peek() <= '9') {
+            if (v > (1L << 40)) throw std::runtime_error("tokenizer: integer out of range");   // token ids and byte values only
+            v = v * 10 + (next() - '0');
+            any = true;
+        }
         if (!any) throw std::runtime_error("tokenizer: expected integer");
         return v;
     }

@@ -17,9 +17,9 @@ for name in ("v5-tiny", "v6-tiny", "v7-tiny"):
 PY
 python -c "import sys; sys.path.insert(0, '$R'); from ai00_server_amd import build; build.build(verbose=False)"
 for f in rwkv_engine tokenizer; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -x hip -fsanitize=address -fno-omit-frame-pointer -c $R/ai00_server_amd/csrc/$f.cpp -o $O/$f.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -x hip -fsanitize=address,undefined -fno-omit-frame-pointer -c $R/ai00_server_amd/csrc/$f.cpp -o $O/$f.o
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -shared-libsan -o $O/librwkv_hip.so $R/ai00_server_amd/csrc/rwkv_kernels.p*.o $O/rwkv_engine.o $O/tokenizer.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -shared-libsan -o $O/librwkv_hip.so $R/ai00_server_amd/csrc/rwkv_kernels.p*.o $O/rwkv_engine.o $O/tokenizer.o
 CXX=/opt/rocm/lib/llvm/bin/clang++
 RT=$(dirname $($CXX -print-file-name=libclang_rt.asan-x86_64.so))
 for t in fuzz_cpu_entry_points scheduler_test router_test sampler_test; do

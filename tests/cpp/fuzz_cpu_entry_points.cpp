@@ -66,6 +66,27 @@ int main(int argc, char **argv) {
     long ok_info = 0, ok_tok = 0;
     // the unmodified inputs must be accepted
     for (auto &m : models) { rwkv_model_info mi{}; if (rwkv_model_info_from_st(m.data(), m.size(), &mi) != RWKV_OK) { std::printf("valid model rejected: %s\n", rwkv_last_error()); return 1; } }
+    // deeply nested JSON (every level used to be a stack frame of the header parser) and absurd chunk plans
+    for (const char *open : {"[", "{\"a\":", "{\"1\":[", "\"", "{\"__metadata__\":[[", "9"}) {
+        std::string s;
+        for (int i = 0; i < 300000; ++i) s += open;
+        rwkv_tokenizer *t = nullptr;
+        if (rwkv_tokenizer_create(s.data(), s.size(), &t) == RWKV_OK && t) rwkv_tokenizer_destroy(t);
+        std::vector<uint8_t> b(8 + s.size());
+        const uint64_t n = s.size();
+        std::memcpy(b.data(), &n, 8);
+        std::memcpy(b.data() + 8, s.data(), s.size());
+        rwkv_model_info mi{};
+        if (rwkv_model_info_from_st(b.data(), b.size(), &mi) == RWKV_OK) { std::printf("nonsense header accepted\n"); return 1; }
+    }
+    {
+        const size_t huge[4] = {(size_t)-1, (size_t)1 << 63, 5, ((size_t)1 << 62) + 3};
+        int32_t consumed[4] = {0, 0, 0, 0};
+        if (rwkv_plan_chunk(4, 2147483647, huge, consumed) != RWKV_OK) { std::printf("plan_chunk rejected a large plan\n"); return 1; }
+        long total = 0;
+        for (int c : consumed) { if (c < 0) { std::printf("negative share\n"); return 1; } total += c; }
+        if (total != 2147483647L) { std::printf("budget not spent: %ld\n", total); return 1; }
+    }
     for (long it = 0; it < iters; ++it) {
         // ---- safetensors: mutate inside the header (the first 8 + header_len bytes) or cut the file
         std::vector<uint8_t> m = models[rnd() % models.size()];
