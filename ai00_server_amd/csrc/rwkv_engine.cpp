@@ -82,7 +82,7 @@ static void validate_info(const rwkv_model_info &i) {
     if (i.num_layer <= 0 || i.num_layer > 4096 || i.num_emb <= 0 || i.num_hidden <= 0 || i.num_vocab <= 0 || i.num_head <= 0 ||
         i.num_vocab > (1 << 24) || i.num_hidden > (1 << 20))
         throw RwkvError(RWKV_ERR_FORMAT, "model dimensions out of range");
-    if (i.head_size != 64 || i.num_emb != i.num_head * 64) throw RwkvError(RWKV_ERR_UNSUPPORTED, "head size must be 64");
+    if (i.head_size != 64 || (int64_t)i.num_emb != (int64_t)i.num_head * 64) throw RwkvError(RWKV_ERR_UNSUPPORTED, "head size must be 64");
     if (i.num_emb % 64 || i.num_hidden % 32 || i.num_vocab % 16)
         throw RwkvError(RWKV_ERR_UNSUPPORTED, "dims must satisfy C%64==0, F%32==0, V%16==0");
     if (i.num_emb > 8192) throw RwkvError(RWKV_ERR_UNSUPPORTED, "num_emb > 8192");
@@ -1419,10 +1419,10 @@ rwkv_status rwkv_model_info_from_st(const uint8_t *st_bytes, size_t st_len, rwkv
     return guard([&] {
         if (!out) throw RwkvError(RWKV_ERR_INVALID, "null out");
         if (prefab_sniff(st_bytes, st_len)) {                   // lib.rs:585-588: safetensors or prefab, by content
-            PfHeader h;
-            std::memcpy(&h, st_bytes, sizeof(h));
-            if (h.version != kPrefabVersion) throw RwkvError(RWKV_ERR_UNSUPPORTED, "prefab version mismatch");
-            *out = h.info;
+            // the whole entry table is walked (headers only: no payload byte is touched), so a truncated or corrupt image is
+            // refused here, where a caller asks "what is this file", rather than halfway through a load
+            const Prefab p = Prefab::parse(st_bytes, st_len);
+            *out = p.hdr.info;
             return;
         }
         SafeTensors st = SafeTensors::parse(st_bytes, st_len);

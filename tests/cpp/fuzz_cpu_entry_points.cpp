@@ -57,6 +57,35 @@ static void mutate(std::vector<uint8_t> &b, size_t window) {
     }
 }
 
+// A small but complete prefab image in the documented layout (rwkv_engine.cpp, "Prefab"): header, then entries
+// { head; name; pad 16; data; pad 16; scales; pad 16 } — one fp32 vector, one raw fp16 tensor, one fp16 matrix, one Int8 and one NF4 matrix.
+struct PfHead { uint32_t kind; int32_t fmt, rows, K; uint32_t counted, name_len; uint64_t n_elems, data_bytes, scale_bytes; };
+struct PfHdr { char magic[8]; uint32_t version, n_entries; rwkv_model_info info; int32_t quant_layers, quant_type; };
+static std::vector<uint8_t> make_prefab() {
+    std::vector<uint8_t> b;
+    auto put = [&](const void *p, size_t n) { const uint8_t *q = (const uint8_t *)p; b.insert(b.end(), q, q + n); };
+    auto pad = [&] { while (b.size() % 16) b.push_back(0); };
+    PfHdr h{};
+    std::memcpy(h.magic, "RWKVHIP", 8);
+    h.version = 1; h.n_entries = 5;
+    h.info = rwkv_model_info{6, 2, 64, 128, 256, 1, 64, 0};
+    h.quant_layers = 2; h.quant_type = 1;
+    put(&h, sizeof(h));
+    auto entry = [&](uint32_t kind, int32_t fmt, int32_t rows, int32_t K, uint64_t n_elems, uint64_t db, uint64_t sb, const char *name) {
+        PfHead e{kind, fmt, rows, K, 1u, (uint32_t)std::strlen(name), n_elems, db, sb};
+        put(&e, sizeof(e));
+        put(name, std::strlen(name)); pad();
+        b.insert(b.end(), (size_t)db, (uint8_t)0x3c); pad();
+        if (sb) { b.insert(b.end(), (size_t)sb, (uint8_t)0x01); pad(); }
+    };
+    entry(0, 0, 0, 0, 64, 256, 0, "blocks.0.ln1.weight");
+    entry(1, 0, 0, 0, 64 * 256, 2 * 64 * 256, 0, "emb.weight");
+    entry(2, 0, 64, 64, 0, 64 * 64 * 2, 0, "blocks.0.att.key.weight");
+    entry(2, 1, 64, 256, 0, 64 * 256, 64 * 2 * 4, "blocks.0.ffn.key.weight");
+    entry(2, 2, 64, 256, 0, 64 * 256 / 2, 64 * 4 * 2, "blocks.0.ffn.value.weight");
+    return b;
+}
+
 int main(int argc, char **argv) {
     if (argc < 4) { std::fprintf(stderr, "usage: fuzz_cpu_entry_points <iterations> <vocab.json> <model.st>...\n"); return 2; }
     const long iters = std::atol(argv[1]);
@@ -66,6 +95,22 @@ int main(int argc, char **argv) {
     long ok_info = 0, ok_tok = 0;
     // the unmodified inputs must be accepted
     for (auto &m : models) { rwkv_model_info mi{}; if (rwkv_model_info_from_st(m.data(), m.size(), &mi) != RWKV_OK) { std::printf("valid model rejected: %s\n", rwkv_last_error()); return 1; } }
+    // prefab images: the seed must be accepted whole, mutated ones must come back with a status
+    const std::vector<uint8_t> prefab = make_prefab();
+    {
+        rwkv_model_info mi{};
+        if (rwkv_model_info_from_st(prefab.data(), prefab.size(), &mi) != RWKV_OK || mi.num_emb != 64) { std::printf("valid prefab rejected: %s\n", rwkv_last_error()); return 1; }
+        long ok_pf = 0;
+        for (long it = 0; it < iters; ++it) {
+            std::vector<uint8_t> m = prefab;
+            for (int k = 0, n = 1 + (int)(rnd() % 3); k < n; ++k) {
+                mutate(m, m.size());
+                if (m.size() >= 8 && rnd() % 2) std::memcpy(m.data(), "RWKVHIP", 8);      // keep most of them on the prefab path
+            }
+            if (rwkv_model_info_from_st(m.data(), m.size(), &mi) == RWKV_OK) ++ok_pf;
+        }
+        std::printf("prefab: %ld of %ld mutated images still accepted\n", ok_pf, iters);
+    }
     // deeply nested JSON (every level used to be a stack frame of the header parser) and absurd chunk plans
     for (const char *open : {"[", "{\"a\":", "{\"1\":[", "\"", "{\"__metadata__\":[[", "9"}) {
         std::string s;
