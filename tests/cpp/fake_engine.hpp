@@ -1,5 +1,6 @@
 // A deterministic stand-in for rwkv::Runtime (no GPU, no HIP) for the CPU tests of the scheduling core and the router.
 #pragma once
+#include <atomic>
 #include <cmath>
 
 #include "../../include/rwkv_scheduler.hpp"
@@ -16,7 +17,7 @@ struct FakeEngine {
     rwkv::ModelInfo info{};
     FakeState state;
     int chunk;            // tokens a slot may consume per infer call (like token_chunk_size / active slots)
-    int calls = 0;
+    std::atomic<int> calls{0};   // read by the test thread while a replica thread may be stepping
     std::vector<int> riders;
     FakeEngine(int B, int chunk_) : max_batch(B), chunk(chunk_) { info.num_vocab = 8; state.slots.assign((size_t)B, state.init()); }
     std::vector<rwkv::RnnOutputBatch> infer(rwkv::RnnInput &in) {
