@@ -27,3 +27,6 @@ for t in fuzz_cpu_entry_points scheduler_test router_test sampler_test; do
 done
 $O/fuzz_cpu_entry_points $N $R/tests/golden/vocab_sample.json $O/v5-tiny.st $O/v6-tiny.st $O/v7-tiny.st
 $O/scheduler_test; $O/router_test; $O/sampler_test > /dev/null && echo "sampler_test: ok"
+# the router once more under ThreadSanitizer (host threads only; against the product build of the library)
+g++ -O1 -g -std=c++17 -fsanitize=thread -pthread $R/tests/cpp/router_test.cpp -o $O/router_tsan -L$R/ai00_server_amd -lrwkv_hip -Wl,-rpath,$R/ai00_server_amd
+for i in 1 2 3; do $O/router_tsan; done
