@@ -289,7 +289,8 @@ struct rwkv_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // graph cache for decode-shaped steps
-    struct GraphEntry { hipGraphExec_t exec = nullptr; };
+    struct GraphEntry { hipGraphExec_t exec = nullptr; uint64_t used = 0; };
+    uint64_t graph_clock = 0;
     std::map<uint64_t, GraphEntry> graphs;
     std::map<int, hipGraphExec_t> greedy_graphs;               // rwkv_decode_greedy: step + arg-max feedback, keyed by slot count
     std::set<uint64_t> graph_seen;
@@ -1253,12 +1254,15 @@ void rwkv_engine::run_plan(const StepPlan &pl) {
             GraphEntry ge;
             HIP_CHECK(hipGraphInstantiate(&ge.exec, g, nullptr, nullptr, 0));
             HIP_CHECK(hipGraphDestroy(g));
-            if (graphs.size() > 64) {
-                for (auto &o : graphs) (void)hipGraphExecDestroy(o.second.exec);
-                graphs.clear();
+            if (graphs.size() >= 64) {                             // full: the least recently replayed shape goes, the rest stay warm
+                auto victim = graphs.begin();
+                for (auto o = graphs.begin(); o != graphs.end(); ++o) if (o->second.used < victim->second.used) victim = o;
+                (void)hipGraphExecDestroy(victim->second.exec);
+                graphs.erase(victim);
             }
             it = graphs.emplace(key, ge).first;
         }
+        it->second.used = ++graph_clock;
         HIP_CHECK(hipGraphLaunch(it->second.exec, s_main));
     } else {
         run_layers(pl.T, pl.n_seq, pl.n_out, tok_ptr, pl.dense);
