@@ -166,19 +166,46 @@ class MirostatSampler:
 
 class ReplicaRouter:
     """Request-level sharding over independent engines (one per GPU): round-robin for batch jobs, least-busy for
-    interactive requests.  No collective: each replica owns its weights, slots and stream."""
+    interactive requests.  No collective: each replica owns its weights, slots and stream.  (The full policy —
+    longest cached prefix first, full replicas skipped, one driving thread per engine — is the C++ `rwkv::ReplicaRouter`,
+    include/rwkv_router.hpp; this class is the single-threaded form the Python tests drive.)"""
 
     def __init__(self, runtimes: list):
         self.loops = [InferLoop(r) for r in runtimes]
         self.busy = [0] * len(runtimes)
 
     def pick(self) -> int:
-        i = min(range(len(self.busy)), key=lambda j: self.busy[j])
+        """Least-busy replica that still has a free slot (ties: lowest index); -1 when every replica is full."""
+        free = [j for j in range(len(self.busy)) if self.busy[j] < self.loops[j].rt.max_batch]
+        if not free:
+            return -1
+        i = min(free, key=lambda j: self.busy[j])
         self.busy[i] += 1
         return i
 
     def release(self, i: int):
         self.busy[i] -= 1
+
+    def generate(self, prompts: list, n_new: int) -> list:
+        """Interactive requests: each prompt goes to the least-busy replica (`pick`), takes the next free slot there, and is
+        decoded greedily (`greedy_process`); a prompt that finds every replica full waits for the current wave to finish."""
+        out = [None] * len(prompts)
+        todo = list(range(len(prompts)))
+        while todo:
+            wave = []
+            used = [0] * len(self.loops)
+            while todo:
+                r = self.pick()
+                if r < 0:
+                    break
+                i = todo.pop(0)
+                wave.append((i, r, used[r]))
+                used[r] += 1
+            for i, r, slot in wave:
+                self.loops[r].rt.state.load(self.loops[r].rt.state.init(), slot)
+                out[i] = greedy_process(self.loops[r], slot, list(prompts[i]), n_new)
+                self.release(r)
+        return out
 
     @staticmethod
     def shard(n_items: int, rank: int, world: int) -> range:
@@ -195,7 +222,7 @@ class ReplicaRouter:
                 group = mine[g:g + B]
                 for slot, d in enumerate(group):
                     loop.rt.state.load(loop.rt.state.init(), slot)
-                    loop.submit(InferRequest(slot, list(docs[d]), RnnOption.Last))
+                    loop.submit(InferRequest(slot, list(docs[d]), RnnOption.NoOutput))   # state-only: no head GEMM, no logits
                 loop.run_pending()
                 for slot, d in enumerate(group):
                     out[d] = loop.rt.state.embed(layer, slot)

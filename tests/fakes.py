@@ -60,6 +60,8 @@ class OracleRuntime:
             lg = self.ref.forward(toks, self.states[b], full=True)
             if full:
                 outs.append(lg)
+            elif ib.option == RnnOption.NoOutput:
+                outs.append(np.zeros((0, self.ref.info.num_vocab), np.float32))
             elif len(ib.tokens) == 0:
                 outs.append(lg[-1:])
             else:

@@ -121,3 +121,22 @@ def test_two_rank_gloo_replica_job_matches_single_rank():
     emb = ReplicaRouter([OracleRuntime(ref, max_batch=2)]).embed_documents(docs, layer=0)
     assert cnt == 6 and tmax == 2.0
     assert abs(chk - sum(float(np.abs(e).sum()) for e in emb)) < 1e-6 * max(1.0, chk)
+
+
+def test_router_places_interactive_requests_on_the_least_busy_replica():
+    """`pick`: least busy replica with a free slot, lowest index on ties, -1 when all are full; `generate` spreads prompts over the
+    replicas that way and every answer equals the single-engine answer."""
+    ref = _ref("v5-tiny")
+    router = ReplicaRouter([OracleRuntime(ref, max_batch=2) for _ in range(3)])
+    assert [router.pick() for _ in range(7)] == [0, 1, 2, 0, 1, 2, -1]
+    router.release(1)
+    assert router.pick() == 1
+    for r in (0, 0, 1, 1, 2, 2):
+        router.release(r)
+    assert router.busy == [0, 0, 0]
+    prompts = [_prompt(ref, 20 + i, 3 + i) for i in range(8)]                 # more prompts than slots: two waves
+    got = router.generate(prompts, 5)
+    for p, g in zip(prompts, got):
+        want, _ = ref.greedy(p, 5)
+        assert g == want[:len(g)] and (len(g) == 5 or want[len(g)] == 0)
+    assert router.busy == [0, 0, 0]
