@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import subprocess
 import os
 import sys
 import time
@@ -246,33 +247,44 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.decode_only:
-        # the oracle ("port") on the host cores: the SAME batch in lock step (RwkvRefBatch: one pass over the weights per
-        # step for all B slots), bounded sample.  fp32 arithmetic on the fp16-rounded weights; the Int8/NF4 storage formats
-        # are a GPU-side layout (quantising 3 G weights in numpy would take minutes and the CPU arithmetic is the same).
-        ref = R.RwkvRefBatch(tensors)
-        st_cpu = ref.init_states(B)
+        # CPU leg ("port"): the SAME configuration on the host cores — the same slots in lock step, the same (fake-)quantised fp16
+        # weight values the GPU dequantises to — through the compiled restatement oracle/cpu_backend.c (C + OpenMP: threaded fp16
+        # GEMM with fp32 accumulation; tests/test_oracle.py holds it against the numpy restatement).  V7 has no compiled form: numpy.
+        # It is a baseline to stand next to the GPU number, never the target.
         cur = [int(x) for x in first]
+        try:
+            from oracle.cpu_backend import CpuBackend
+            ref = CpuBackend(tensors, ql, qt)
+            how = (f"C/OpenMP restatement (oracle/cpu_backend.c), fp16 weights ({'fake-quantised ' + args.quant if qt else 'unquantised'}), "
+                   f"fp32 accumulate, {ref.threads} threads")
+            cores = ref.threads
+        except (NotImplementedError, OSError, subprocess.CalledProcessError):
+            ref = R.RwkvRefBatch(tensors)
+            how, cores = "numpy/BLAS fp32 oracle on all host cores, weights fp16-rounded (unquantised on the CPU side)", os.cpu_count()
+        st_cpu = ref.init_states(B)
         ref.step(cur, st_cpu, want_logits=False)       # warm
         n_step, t1 = 0, time.time()
-        while time.time() - t1 < 15.0 and n_step < 64:
+        while time.time() - t1 < 12.0 and n_step < 256:
             lg = ref.step(cur, st_cpu)
             cur = [int(x) for x in np.argmax(lg, axis=1)]
             n_step += 1
         cdt = time.time() - t1
-        cpu = {"value": B * n_step / cdt, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
-               "sample": f"{n_step} lock-step decode steps of {B} slots ({B * n_step} tokens), numpy/BLAS fp32 oracle on all host cores, "
-                         f"weights fp16-rounded (unquantised on the CPU side), {args.workload}"}
+        cpu = {"value": B * n_step / cdt, "unit": "tokens/s", "cores": cores, "kind": "port",
+               "sample": f"{n_step} lock-step decode steps of {B} slots ({B * n_step} tokens), {how}, {args.workload}"}
         del ref, st_cpu
         # BASELINE config #1: RWKV-V5-World-0.4B fp16, batch 1, greedy, on the CPU path (the reference has no CPU backend,
-        # lib.rs:339-368; this is the oracle port)
+        # lib.rs:339-368; this is the port)
         try:
             _, t5 = R.synth_st("v5-0.4b", fast=True)
-            r5 = R.RwkvRef(t5)
-            s5 = r5.init_state()
-            lg = r5.forward([int(first[0]) % r5.info.num_vocab], s5)[-1]
+            try:
+                r5 = CpuBackend(t5)
+            except (NameError, NotImplementedError, OSError, subprocess.CalledProcessError):
+                r5 = R.RwkvRefBatch(t5)
+            s5 = r5.init_states(1)
+            lg = r5.step([int(first[0]) % r5.info.num_vocab], s5)
             n5, t1 = 0, time.time()
-            while time.time() - t1 < 6.0 and n5 < 256:
-                lg = r5.forward([int(np.argmax(lg))], s5)[-1]
+            while time.time() - t1 < 5.0 and n5 < 1024:
+                lg = r5.step([int(np.argmax(lg[0]))], s5)
                 n5 += 1
             cpu["config1_v5_0.4b_b1_tokens_per_s"] = n5 / (time.time() - t1)
             del r5, t5

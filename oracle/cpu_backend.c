@@ -1,0 +1,273 @@
+/* oracle/cpu_backend.c — TEST INFRASTRUCTURE (a second, compiled restatement of the oracle; never linked into the product).
+ *
+ * The lock-step decode step of oracle/rwkv_ref.py (`RwkvRefBatch.step`: B independent slots advance one token each, run.rs:1121-1132)
+ * for RWKV V5.2 and V6, in plain C with OpenMP: fp16 weights (exactly the values the oracle holds: checkpoint tensors rounded through
+ * fp16, quantised layers fake-quantised to the fp16 value the GPU dequantises to), fp32 activations and accumulation.  It exists for
+ * two reasons: (1) a CPU baseline on the SAME configuration as the GPU line (`bench.py` `cpu_baseline`, SURVEY 8d "CPU reference
+ * timing": threaded fp16 GEMV over the fake-quantised weights), (2) an independent implementation of the same published formulas
+ * that tests/test_oracle.py holds against the numpy restatement (two codes, one arithmetic).  Formula references: SURVEY Appendix A
+ * (BlinkDL's RWKV-5.2 / RWKV-6 inference), data contract as in rwkv_ref.py (state slab [L][N+2][C]: row 0 att shift, rows 1..N the
+ * WKV matrices with slab[1+i][h*N+j] = S_h[i][j], row N+1 ffn shift; V5 lerp `xx*mu + sx*(1-mu)`, V6 `xx + (sx-xx)*mu`).
+ *
+ * Build: gcc -O3 -mavx2 -mfma -mf16c -fopenmp -shared -fPIC oracle/cpu_backend.c -o oracle/_build/libcpu_backend.so -lm
+ */
+#include <immintrin.h>
+#include <math.h>
+#include <omp.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    const float *ln1w, *ln1b, *ln2w, *ln2b;
+    const float *mix_x, *mix_w, *mix_k, *mix_v, *mix_r, *mix_g;   /* V5: mix_k/v/r/g only */
+    const uint16_t *mix_w1, *mix_w2;                               /* V6: [5*Dm][C], [5][C][Dm] */
+    const float *decay, *first;                                    /* [C] */
+    const uint16_t *decay_w1, *decay_w2;                           /* V6: [Dd][C], [C][Dd] */
+    const uint16_t *Wr, *Wk, *Wv, *Wg, *Wo;                        /* [C][C] */
+    const float *lnxw, *lnxb;
+    const float *fmix_k, *fmix_r;
+    const uint16_t *Fk, *Fv, *Fr;                                  /* [F][C], [C][F], [C][C] */
+} CpuLayer;
+
+typedef struct {
+    int32_t version, L, C, F, V, H, Dm, Dd;
+    const uint16_t *emb, *head;                                    /* [V][C] */
+    const float *ln0w, *ln0b, *lnow, *lnob;
+    const CpuLayer *layers;
+} CpuModel;
+
+#define N_HEAD 64
+#define LN_EPS 1e-5f
+#define GN_EPS 64e-5f   /* GroupNorm eps of the reference models: 1e-5 * head_size_divisor^2 (8^2), as in rwkv_ref.GN_EPS */
+
+/* Y[b][r] = sum_k W[r][k] X[b][k];  W fp16 row-major [rows][K], K % 8 == 0;  slots in groups of 8 so the accumulators stay in registers */
+static void gemm_f16(const uint16_t *W, long rows, long K, const float *X, long ldx, float *Y, long ldy, int B) {
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < rows; ++r) {
+        const uint16_t *w = W + r * K;
+        for (int b0 = 0; b0 < B; b0 += 8) {
+            const int nb = B - b0 < 8 ? B - b0 : 8;
+            __m256 acc[8];
+            for (int i = 0; i < 8; ++i) acc[i] = _mm256_setzero_ps();
+            for (long k = 0; k < K; k += 8) {
+                const __m256 wv = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(w + k)));
+                for (int i = 0; i < nb; ++i) acc[i] = _mm256_fmadd_ps(wv, _mm256_loadu_ps(X + (long)(b0 + i) * ldx + k), acc[i]);
+            }
+            for (int i = 0; i < nb; ++i) {
+                __m128 s = _mm_add_ps(_mm256_castps256_ps128(acc[i]), _mm256_extractf128_ps(acc[i], 1));
+                s = _mm_add_ps(s, _mm_movehl_ps(s, s));
+                s = _mm_add_ss(s, _mm_shuffle_ps(s, s, 1));
+                Y[(long)(b0 + i) * ldy + r] = _mm_cvtss_f32(s);
+            }
+        }
+    }
+}
+
+static void layernorm(const float *x, const float *w, const float *b, float *y, int n, float eps) {
+    float m = 0.f;
+    for (int i = 0; i < n; ++i) m += x[i];
+    m /= (float)n;
+    float v = 0.f;
+    for (int i = 0; i < n; ++i) v += (x[i] - m) * (x[i] - m);
+    v /= (float)n;
+    const float inv = 1.0f / sqrtf(v + eps);
+    for (int i = 0; i < n; ++i) y[i] = (x[i] - m) * inv * w[i] + b[i];
+}
+static inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+static inline float h2f(uint16_t h) { return _cvtsh_ss(h); }
+
+/* one decode step: tokens[B]; states [B][L][N+2][C] updated in place; logits [B][V] or NULL.  Returns 0, or -1 on bad arguments / no memory. */
+int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states, float *logits) {
+    if (!m || !tokens || !states || B <= 0 || m->C != m->H * N_HEAD || (m->version != 5 && m->version != 6)) return -1;
+    const int C = m->C, F = m->F, H = m->H, N = N_HEAD, L = m->L, Dm = m->Dm, Dd = m->Dd;
+    const long slab = (long)L * (N + 2) * C;
+    const long big = F > C ? F : C;
+    float *buf = (float *)malloc(sizeof(float) * (size_t)B * (size_t)(12 * (long)C + 2 * big + 5L * (Dm > 0 ? Dm : 1) + (Dd > 0 ? Dd : 1)));
+    if (!buf) return -1;
+    float *x = buf, *xx = x + (long)B * C, *sx = xx + (long)B * C, *t0 = sx + (long)B * C, *t1 = t0 + (long)B * C, *t2 = t1 + (long)B * C,
+          *t3 = t2 + (long)B * C, *t4 = t3 + (long)B * C, *r = t4 + (long)B * C, *k = r + (long)B * C, *v = k + (long)B * C, *g = v + (long)B * C,
+          *hid = g + (long)B * C, *hid2 = hid + (long)B * big, *mm = hid2 + (long)B * big, *td = mm + (long)B * 5 * (Dm > 0 ? Dm : 1);
+#pragma omp parallel for
+    for (int b = 0; b < B; ++b) {
+        float *xb = x + (long)b * C;
+        const uint16_t *e = m->emb + (long)tokens[b] * C;
+        for (int c = 0; c < C; ++c) xb[c] = h2f(e[c]);
+        layernorm(xb, m->ln0w, m->ln0b, xb, C, LN_EPS);
+    }
+    for (int l = 0; l < L; ++l) {
+        const CpuLayer *p = &m->layers[l];
+        /* ---- time mix */
+#pragma omp parallel for
+        for (int b = 0; b < B; ++b) {
+            float *st = states + (long)b * slab + (long)l * (N + 2) * C;
+            layernorm(x + (long)b * C, p->ln1w, p->ln1b, xx + (long)b * C, C, LN_EPS);
+            memcpy(sx + (long)b * C, st, sizeof(float) * C);
+            memcpy(st, xx + (long)b * C, sizeof(float) * C);
+        }
+        float *xr = t0, *xk = t1, *xv = t2, *xg = t3, *xw = t4;
+        if (m->version == 5) {
+#pragma omp parallel for
+            for (int b = 0; b < B; ++b)
+                for (int c = 0; c < C; ++c) {
+                    const long i = (long)b * C + c;
+                    xr[i] = xx[i] * p->mix_r[c] + sx[i] * (1.0f - p->mix_r[c]);
+                    xk[i] = xx[i] * p->mix_k[c] + sx[i] * (1.0f - p->mix_k[c]);
+                    xv[i] = xx[i] * p->mix_v[c] + sx[i] * (1.0f - p->mix_v[c]);
+                    xg[i] = xx[i] * p->mix_g[c] + sx[i] * (1.0f - p->mix_g[c]);
+                }
+        } else {
+            /* z = xx + dx*mix_x;  m = tanh(W1 z) [5*Dm];  x_c = xx + dx*(mix_c + W2_c m_c), c in (w,k,v,r,g) */
+#pragma omp parallel for
+            for (int b = 0; b < B; ++b)
+                for (int c = 0; c < C; ++c) {
+                    const long i = (long)b * C + c;
+                    hid[i] = xx[i] + (sx[i] - xx[i]) * p->mix_x[c];
+                }
+            gemm_f16(p->mix_w1, 5L * Dm, C, hid, C, mm, 5L * Dm, B);
+            for (long i = 0; i < (long)B * 5 * Dm; ++i) mm[i] = tanhf(mm[i]);
+            float *dst[5] = {xw, xk, xv, xr, xg};
+            const float *mu[5] = {p->mix_w, p->mix_k, p->mix_v, p->mix_r, p->mix_g};
+            for (int c5 = 0; c5 < 5; ++c5) {
+                gemm_f16(p->mix_w2 + (long)c5 * C * Dm, C, Dm, mm + (long)c5 * Dm, 5L * Dm, hid, C, B);
+#pragma omp parallel for
+                for (int b = 0; b < B; ++b)
+                    for (int c = 0; c < C; ++c) {
+                        const long i = (long)b * C + c;
+                        dst[c5][i] = xx[i] + (sx[i] - xx[i]) * (mu[c5][c] + hid[i]);
+                    }
+            }
+        }
+        gemm_f16(p->Wr, C, C, xr, C, r, C, B);
+        gemm_f16(p->Wk, C, C, xk, C, k, C, B);
+        gemm_f16(p->Wv, C, C, xv, C, v, C, B);
+        gemm_f16(p->Wg, C, C, xg, C, g, C, B);
+        float *wdec = hid2;                                         /* [B][C] */
+        if (m->version == 5) {
+#pragma omp parallel for
+            for (int b = 0; b < B; ++b)
+                for (int c = 0; c < C; ++c) wdec[(long)b * C + c] = expf(-expf(p->decay[c]));
+        } else {
+            gemm_f16(p->decay_w1, Dd, C, xw, C, td, Dd, B);
+            for (long i = 0; i < (long)B * Dd; ++i) td[i] = tanhf(td[i]);
+            gemm_f16(p->decay_w2, C, Dd, td, Dd, wdec, C, B);
+#pragma omp parallel for
+            for (int b = 0; b < B; ++b)
+                for (int c = 0; c < C; ++c) wdec[(long)b * C + c] = expf(-expf(p->decay[c] + wdec[(long)b * C + c]));
+        }
+        /* WKV: out_j = sum_i r_i (u_i k_i v_j + S_ij);  S_ij = k_i v_j + w_i S_ij */
+        float *out = t0;                                            /* xr is dead */
+#pragma omp parallel for collapse(2)
+        for (int b = 0; b < B; ++b)
+            for (int h = 0; h < H; ++h) {
+                float *S = states + (long)b * slab + (long)l * (N + 2) * C + (long)C + (long)h * N;   /* row 1, column h*N; row stride C */
+                const float *rb = r + (long)b * C + h * N, *kb = k + (long)b * C + h * N, *vb = v + (long)b * C + h * N;
+                const float *wb = wdec + (long)b * C + h * N, *u = p->first + h * N;
+                float o[N_HEAD];
+                for (int j = 0; j < N; ++j) o[j] = 0.f;
+                for (int i = 0; i < N; ++i) {
+                    float *Si = S + (long)i * C;
+                    const float ri = rb[i], ki = kb[i], ui = u[i], wi = wb[i];
+                    for (int j = 0; j < N; ++j) {
+                        const float a = ki * vb[j];
+                        o[j] += ri * (ui * a + Si[j]);
+                        Si[j] = a + wi * Si[j];
+                    }
+                }
+                /* GroupNorm over the head, then the gate */
+                float mean = 0.f, var = 0.f;
+                for (int j = 0; j < N; ++j) mean += o[j];
+                mean /= (float)N;
+                for (int j = 0; j < N; ++j) var += (o[j] - mean) * (o[j] - mean);
+                var /= (float)N;
+                const float inv = 1.0f / sqrtf(var + GN_EPS);
+                for (int j = 0; j < N; ++j) {
+                    const int c = h * N + j;
+                    const float gg = g[(long)b * C + c];
+                    out[(long)b * C + c] = ((o[j] - mean) * inv * p->lnxw[c] + p->lnxb[c]) * (gg * sigmoidf(gg));
+                }
+            }
+        gemm_f16(p->Wo, C, C, out, C, t1, C, B);
+        /* ---- channel mix */
+#pragma omp parallel for
+        for (int b = 0; b < B; ++b) {
+            float *st = states + (long)b * slab + (long)l * (N + 2) * C + (long)(N + 1) * C;
+            float *xb = x + (long)b * C;
+            for (int c = 0; c < C; ++c) xb[c] += t1[(long)b * C + c];
+            layernorm(xb, p->ln2w, p->ln2b, xx + (long)b * C, C, LN_EPS);
+            memcpy(sx + (long)b * C, st, sizeof(float) * C);
+            memcpy(st, xx + (long)b * C, sizeof(float) * C);
+            for (int c = 0; c < C; ++c) {
+                const long i = (long)b * C + c;
+                if (m->version == 5) {
+                    t2[i] = xx[i] * p->fmix_k[c] + sx[i] * (1.0f - p->fmix_k[c]);
+                    t3[i] = xx[i] * p->fmix_r[c] + sx[i] * (1.0f - p->fmix_r[c]);
+                } else {
+                    t2[i] = xx[i] + (sx[i] - xx[i]) * p->fmix_k[c];
+                    t3[i] = xx[i] + (sx[i] - xx[i]) * p->fmix_r[c];
+                }
+            }
+        }
+        gemm_f16(p->Fk, F, C, t2, C, hid, F, B);
+        for (long i = 0; i < (long)B * F; ++i) { const float a = hid[i] > 0.f ? hid[i] : 0.f; hid[i] = a * a; }
+        gemm_f16(p->Fv, C, F, hid, F, t4, C, B);
+        gemm_f16(p->Fr, C, C, t3, C, r, C, B);
+#pragma omp parallel for
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < C; ++c) x[(long)b * C + c] += sigmoidf(r[(long)b * C + c]) * t4[(long)b * C + c];
+    }
+    if (logits) {
+#pragma omp parallel for
+        for (int b = 0; b < B; ++b) layernorm(x + (long)b * C, m->lnow, m->lnob, xx + (long)b * C, C, LN_EPS);
+        gemm_f16(m->head, m->V, C, xx, C, logits, m->V, B);
+    }
+    free(buf);
+    return 0;
+}
+
+/* ---- Int8 fake-quantisation in place, bit for bit what rwkv_ref.fake_quant(w, QUANT_INT8) returns (rwkv_ref.quant_int8 /
+ * dequant_int8): per 128-block a = f16((max-min)/255), b = f16(min), q = clip(rint((x-b)/a)), value = f16(double(a)*q + double(b)). */
+static uint16_t f64_to_f16(double d) {                             /* round to nearest even, like numpy's float64 -> float16 */
+    if (d != d) return 0x7e00;
+    const uint16_t sign = d < 0 ? 0x8000 : 0;
+    double a = fabs(d);
+    if (a == 0.0) return sign;
+    if (a >= 65520.0) return (uint16_t)(sign | 0x7c00);             /* rounds to infinity */
+    int e;
+    (void)frexp(a, &e);                                            /* a = f * 2^e, f in [0.5, 1) -> a in [2^(e-1), 2^e) */
+    int exp = e - 1;                                               /* floor(log2 a) */
+    if (exp < -14) exp = -14;                                      /* subnormal quantum 2^-24 */
+    const double q = ldexp(1.0, exp - 10);                         /* spacing of halfs in this binade */
+    double mant = nearbyint(a / q);                                /* exact division by a power of two; ties to even (default mode) */
+    if (mant >= 2048.0) { mant /= 2.0; exp += 1; }                 /* rounded up into the next binade */
+    if (exp > 15) return (uint16_t)(sign | 0x7c00);
+    if (mant < 1024.0) return (uint16_t)(sign | (uint16_t)mant);   /* subnormal (exp == -14, no implicit bit) */
+    return (uint16_t)(sign | ((uint16_t)(exp + 15) << 10) | ((uint16_t)mant & 0x3ff));
+}
+static uint16_t f32_to_f16(float f) { return f64_to_f16((double)f); }   /* exact widening, one rounding */
+
+void rwkv_cpu_fake_quant_int8(uint16_t *w, long rows, long K) {
+#pragma omp parallel for schedule(static)
+    for (long rr = 0; rr < rows; ++rr)
+        for (long k0 = 0; k0 < K; k0 += 128) {
+            uint16_t *blk = w + rr * K + k0;
+            float x[128], mn = 0.f, mx = 0.f;
+            for (int i = 0; i < 128; ++i) { x[i] = h2f(blk[i]); if (i == 0 || x[i] < mn) mn = x[i]; if (i == 0 || x[i] > mx) mx = x[i]; }
+            const uint16_t ah = f32_to_f16((mx - mn) / 255.0f), bh = f32_to_f16(mn);
+            const float a32 = h2f(ah), b32 = h2f(bh), safe = a32 > 0.f ? a32 : 1.0f;
+            for (int i = 0; i < 128; ++i) {
+                float q = nearbyintf((x[i] - b32) / safe);
+                q = q < 0.f ? 0.f : q > 255.f ? 255.f : q;
+                blk[i] = f64_to_f16((double)a32 * (double)q + (double)b32);
+            }
+        }
+}
+int rwkv_cpu_threads(void) {
+    int n = 1;
+#pragma omp parallel
+    {
+#pragma omp master
+        n = omp_get_num_threads();
+    }
+    return n;
+}

@@ -1,0 +1,135 @@
+"""oracle/cpu_backend.py — TEST INFRASTRUCTURE: ctypes front of oracle/cpu_backend.c, the compiled (C + OpenMP) second restatement of
+the lock-step decode step for RWKV V5.2 / V6.  Same surface as `rwkv_ref.RwkvRefBatch` (`step`, `init_states`, `greedy_batch`), same
+weights (checkpoint tensors rounded through fp16; quantised layers fake-quantised to the fp16 value the GPU dequantises to — Int8 in C,
+bit for bit `rwkv_ref.fake_quant`; NF4 through the numpy routine).  Used by tests/test_oracle.py (cross-check of the two restatements)
+and by bench.py's `cpu_baseline` leg.  The product never imports this."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import rwkv_ref as R
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "cpu_backend.c")
+LIB = os.path.join(HERE, "_build", "libcpu_backend.so")
+
+
+def build(force: bool = False) -> str:
+    """gcc -O3 -mavx2 -mfma -mf16c -fopenmp (a baseline every x86 server of the last decade has; not -march=native: the library built
+    in one container also runs on the GPU box's host)."""
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        subprocess.check_call(["gcc", "-O3", "-mavx2", "-mfma", "-mf16c", "-fopenmp", "-shared", "-fPIC", "-Wall", "-Wextra", "-Werror",
+                               SRC, "-o", LIB, "-lm"])
+    return LIB
+
+
+_u16p, _f32p = C.POINTER(C.c_uint16), C.POINTER(C.c_float)
+
+
+class _Layer(C.Structure):
+    _fields_ = [(n, _f32p) for n in ("ln1w", "ln1b", "ln2w", "ln2b", "mix_x", "mix_w", "mix_k", "mix_v", "mix_r", "mix_g")] + \
+               [("mix_w1", _u16p), ("mix_w2", _u16p), ("decay", _f32p), ("first", _f32p), ("decay_w1", _u16p), ("decay_w2", _u16p)] + \
+               [(n, _u16p) for n in ("Wr", "Wk", "Wv", "Wg", "Wo")] + [("lnxw", _f32p), ("lnxb", _f32p), ("fmix_k", _f32p), ("fmix_r", _f32p)] + \
+               [(n, _u16p) for n in ("Fk", "Fv", "Fr")]
+
+
+class _Model(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("version", "L", "C", "F", "V", "H", "Dm", "Dd")] + \
+               [("emb", _u16p), ("head", _u16p), ("ln0w", _f32p), ("ln0b", _f32p), ("lnow", _f32p), ("lnob", _f32p), ("layers", C.POINTER(_Layer))]
+
+
+class CpuBackend:
+    def __init__(self, tensors: dict, quant_layers: int = 0, quant_type: int = R.QUANT_NONE):
+        self.lib = C.CDLL(build())
+        self.lib.rwkv_cpu_step.restype = C.c_int
+        self.lib.rwkv_cpu_step.argtypes = [C.POINTER(_Model), C.POINTER(C.c_int32), C.c_int, _f32p, _f32p]
+        self.lib.rwkv_cpu_fake_quant_int8.argtypes = [_u16p, C.c_long, C.c_long]
+        self.lib.rwkv_cpu_threads.restype = C.c_int
+        self.info = i = R.model_info(tensors)
+        if i.version not in (5, 6):
+            raise NotImplementedError("the compiled restatement covers V5.2 and V6")
+        qn = set()
+        if quant_type != R.QUANT_NONE:
+            for l in range(min(quant_layers, i.num_layer)):
+                qn.update(f"blocks.{l}.{n}" for n in R.quantised_matrix_names(i.version))
+        self._keep = []
+
+        def mat(name):                                   # fp16 matrix, row-major, (fake-)quantised if the layer is
+            a = np.ascontiguousarray(np.asarray(tensors[name], dtype=np.float16))
+            if name in qn:
+                a = a.copy()
+                if quant_type == R.QUANT_INT8:
+                    a2 = a.reshape(-1, a.shape[-1])
+                    self.lib.rwkv_cpu_fake_quant_int8(a2.view(np.uint16).ctypes.data_as(_u16p), a2.shape[0], a2.shape[1])
+                else:
+                    a = np.ascontiguousarray(R.fake_quant(a, quant_type))
+            self._keep.append(a)
+            return a.view(np.uint16).ctypes.data_as(_u16p)
+
+        def vec(name):                                   # fp32 of the fp16-rounded values, flat
+            a = np.ascontiguousarray(np.asarray(tensors[name], dtype=np.float16).astype(np.float32).reshape(-1))
+            self._keep.append(a)
+            return a.ctypes.data_as(_f32p)
+
+        none16, none32 = C.cast(None, _u16p), C.cast(None, _f32p)
+        Dm = Dd = 0
+        if i.version == 6:
+            Dm = int(np.asarray(tensors["blocks.0.att.time_mix_w2"]).shape[2])
+            Dd = int(np.asarray(tensors["blocks.0.att.time_decay_w1"]).shape[0])
+        self._layers = (_Layer * i.num_layer)()
+        for l in range(i.num_layer):
+            p = f"blocks.{l}."
+            y = self._layers[l]
+            y.ln1w, y.ln1b, y.ln2w, y.ln2b = vec(p + "ln1.weight"), vec(p + "ln1.bias"), vec(p + "ln2.weight"), vec(p + "ln2.bias")
+            for n in "kvrg":
+                setattr(y, "mix_" + n, vec(p + "att.time_mix_" + n))
+            if i.version == 6:
+                y.mix_x, y.mix_w = vec(p + "att.time_mix_x"), vec(p + "att.time_mix_w")
+                y.mix_w1, y.mix_w2 = mat(p + "att.time_mix_w1"), mat(p + "att.time_mix_w2")
+                y.decay_w1, y.decay_w2 = mat(p + "att.time_decay_w1"), mat(p + "att.time_decay_w2")
+            else:
+                y.mix_x, y.mix_w, y.mix_w1, y.mix_w2, y.decay_w1, y.decay_w2 = none32, none32, none16, none16, none16, none16
+            y.decay, y.first = vec(p + "att.time_decay"), vec(p + "att.time_first")
+            y.Wr, y.Wk, y.Wv = mat(p + "att.receptance.weight"), mat(p + "att.key.weight"), mat(p + "att.value.weight")
+            y.Wg, y.Wo = mat(p + "att.gate.weight"), mat(p + "att.output.weight")
+            y.lnxw, y.lnxb = vec(p + "att.ln_x.weight"), vec(p + "att.ln_x.bias")
+            y.fmix_k, y.fmix_r = vec(p + "ffn.time_mix_k"), vec(p + "ffn.time_mix_r")
+            y.Fk, y.Fv, y.Fr = mat(p + "ffn.key.weight"), mat(p + "ffn.value.weight"), mat(p + "ffn.receptance.weight")
+        self._model = _Model(i.version, i.num_layer, i.num_emb, i.num_hidden, i.num_vocab, i.num_head, Dm, Dd,
+                             mat("emb.weight"), mat("head.weight"), vec("blocks.0.ln0.weight"), vec("blocks.0.ln0.bias"),
+                             vec("ln_out.weight"), vec("ln_out.bias"), self._layers)
+
+    @property
+    def threads(self) -> int:
+        return int(self.lib.rwkv_cpu_threads())
+
+    def init_states(self, B: int) -> np.ndarray:
+        i = self.info
+        return np.zeros((B, i.num_layer, i.head_size + 2, i.num_emb), dtype=np.float32)
+
+    def step(self, tokens, states: np.ndarray, want_logits: bool = True):
+        """One token per slot; `states` [B, L, N+2, C] float32 C-contiguous, updated in place; returns logits [B, V] or None."""
+        B = len(tokens)
+        assert states.dtype == np.float32 and states.flags.c_contiguous and states.shape[0] == B
+        tok = np.ascontiguousarray(tokens, dtype=np.int32)
+        logits = np.empty((B, self.info.num_vocab), np.float32) if want_logits else None
+        rc = self.lib.rwkv_cpu_step(C.byref(self._model), tok.ctypes.data_as(C.POINTER(C.c_int32)), B, states.ctypes.data_as(_f32p),
+                                    logits.ctypes.data_as(_f32p) if want_logits else C.cast(None, _f32p))
+        if rc != 0:
+            raise RuntimeError("rwkv_cpu_step failed")
+        return logits
+
+    def greedy_batch(self, first_tokens, n_steps: int, states: np.ndarray):
+        cur = [int(t) for t in first_tokens]
+        ids = np.zeros((n_steps, len(cur)), np.int64)
+        lg = None
+        for s in range(n_steps):
+            lg = self.step(cur, states)
+            cur = [int(x) for x in np.argmax(lg, axis=1)]
+            ids[s] = cur
+        return ids, lg

@@ -245,3 +245,41 @@ def test_lockstep_batch_form_agrees_with_the_per_token_restatement(name, quant):
         assert np.abs(want - lg[b]).max() <= 5e-6 * max(1.0, float(np.abs(want).max()))
         g, s2 = ref.greedy(ps[b], 13)
         assert g[0] == int(np.argmax(lg[b])) and g[1:] == [int(x) for x in ids[:, b]]
+
+
+@pytest.mark.parametrize("name,quant", [("v5-tiny", (0, 0)), ("v6-tiny", (0, 0)), ("v5-small", (2, 1)), ("v6-small", (3, 1)), ("v6-small", (2, 2))])
+def test_compiled_restatement_agrees_with_the_numpy_one(name, quant):
+    """oracle/cpu_backend.c (C + OpenMP, the CPU baseline of bench.py) against RwkvRefBatch: two independent codes of the same
+    formulas, the same fp16 / fake-quantised weights — logits and state slabs to fp32 round-off, arg-max identical, over 16 lock-step
+    steps of five slots."""
+    from oracle.cpu_backend import CpuBackend
+    t = R.synth_named(name)
+    rb, cb = R.RwkvRefBatch(t, *quant), CpuBackend(t, *quant)
+    B, V = 5, rb.info.num_vocab
+    s1, s2 = rb.init_states(B), cb.init_states(B)
+    rng = np.random.default_rng(3)
+    for step in range(16):
+        toks = [int(x) for x in rng.integers(1, V, B)]
+        a, b = rb.step(toks, s1), cb.step(toks, s2)
+        assert np.abs(a - b).max() <= 1e-5 * max(1.0, float(np.abs(a).max())), step
+        assert (np.argmax(a, axis=1) == np.argmax(b, axis=1)).all()
+        assert np.abs(s1 - s2).max() <= 2e-5 * max(1.0, float(np.abs(s1).max()))
+    assert cb.step([1] * B, s2, want_logits=False) is None
+
+
+def test_compiled_int8_fake_quantisation_is_bit_identical_to_the_numpy_one():
+    """`rwkv_cpu_fake_quant_int8` (per 128-block a, b in fp16, one rounding of a*q + b from float64) against rwkv_ref.fake_quant over
+    seven orders of magnitude, constant and zero blocks included."""
+    import ctypes as C
+    from oracle import cpu_backend as cb
+    lib = C.CDLL(cb.build())
+    lib.rwkv_cpu_fake_quant_int8.argtypes = [C.POINTER(C.c_uint16), C.c_long, C.c_long]
+    rng = np.random.default_rng(0)
+    for scale in (1e-6, 1e-3, 0.05, 1.0, 30.0, 3000.0):
+        w = (rng.standard_normal((32, 512)) * scale).astype(np.float16)
+        w[0, :128] = np.float16(0.37)
+        w[1, :128] = 0
+        want = R.fake_quant(w.copy(), R.QUANT_INT8)
+        got = w.copy()
+        lib.rwkv_cpu_fake_quant_int8(got.view(np.uint16).ctypes.data_as(C.POINTER(C.c_uint16)), 32, 512)
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), scale
