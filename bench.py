@@ -249,7 +249,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.decode_only:
         # CPU leg ("port"): the SAME configuration on the host cores — the same slots in lock step, the same (fake-)quantised fp16
         # weight values the GPU dequantises to — through the compiled restatement oracle/cpu_backend.c (C + OpenMP: threaded fp16
-        # GEMM with fp32 accumulation; tests/test_oracle.py holds it against the numpy restatement).  V7 has no compiled form: numpy.
+        # GEMM with fp32 accumulation; tests/test_oracle.py holds it against the numpy restatement; numpy itself if it cannot be built).
         # It is a baseline to stand next to the GPU number, never the target.
         cur = [int(x) for x in first]
         try:

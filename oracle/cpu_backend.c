@@ -1,7 +1,7 @@
 /* oracle/cpu_backend.c — TEST INFRASTRUCTURE (a second, compiled restatement of the oracle; never linked into the product).
  *
  * The lock-step decode step of oracle/rwkv_ref.py (`RwkvRefBatch.step`: B independent slots advance one token each, run.rs:1121-1132)
- * for RWKV V5.2 and V6, in plain C with OpenMP: fp16 weights (exactly the values the oracle holds: checkpoint tensors rounded through
+ * for RWKV V5.2, V6 and V7, in plain C with OpenMP: fp16 weights (exactly the values the oracle holds: checkpoint tensors rounded through
  * fp16, quantised layers fake-quantised to the fp16 value the GPU dequantises to), fp32 activations and accumulation.  It exists for
  * two reasons: (1) a CPU baseline on the SAME configuration as the GPU line (`bench.py` `cpu_baseline`, SURVEY 8d "CPU reference
  * timing": threaded fp16 GEMV over the fake-quantised weights), (2) an independent implementation of the same published formulas
@@ -28,6 +28,10 @@ typedef struct {
     const float *lnxw, *lnxb;
     const float *fmix_k, *fmix_r;
     const uint16_t *Fk, *Fv, *Fr;                                  /* [F][C], [C][F], [C][C] */
+    /* V7 (mix_r/w/k/v/g double as x_r/x_w/x_k/x_v/x_g, fmix_k as ffn.x_k; no Wg, no Fr) */
+    const float *mix_a, *w0, *a0, *v0, *k_k, *k_a, *r_k;           /* [C] */
+    const uint16_t *w1, *w2, *a1, *a2, *v1, *v2, *g1, *g2;         /* x1: [D][C], x2: [C][D] */
+    int32_t Dw, Da, Dv, Dg;
 } CpuLayer;
 
 typedef struct {
@@ -79,15 +83,24 @@ static inline float h2f(uint16_t h) { return _cvtsh_ss(h); }
 
 /* one decode step: tokens[B]; states [B][L][N+2][C] updated in place; logits [B][V] or NULL.  Returns 0, or -1 on bad arguments / no memory. */
 int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states, float *logits) {
-    if (!m || !tokens || !states || B <= 0 || m->C != m->H * N_HEAD || (m->version != 5 && m->version != 6)) return -1;
+    if (!m || !tokens || !states || B <= 0 || m->C != m->H * N_HEAD || (m->version != 5 && m->version != 6 && m->version != 7)) return -1;
     const int C = m->C, F = m->F, H = m->H, N = N_HEAD, L = m->L, Dm = m->Dm, Dd = m->Dd;
     const long slab = (long)L * (N + 2) * C;
     const long big = F > C ? F : C;
-    float *buf = (float *)malloc(sizeof(float) * (size_t)B * (size_t)(12 * (long)C + 2 * big + 5L * (Dm > 0 ? Dm : 1) + (Dd > 0 ? Dd : 1)));
+    long maxD = 8;
+    if (m->version == 7)
+        for (int l = 0; l < L; ++l) {
+            const CpuLayer *q = &m->layers[l];
+            const long d4[4] = {q->Dw, q->Da, q->Dv, q->Dg};
+            for (int i = 0; i < 4; ++i) if (d4[i] > maxD) maxD = d4[i];
+        }
+    float *buf = (float *)malloc(sizeof(float) * (size_t)B * (size_t)(16 * (long)C + 2 * big + 5L * (Dm > 0 ? Dm : 1) + (Dd > 0 ? Dd : 1) + maxD));
     if (!buf) return -1;
     float *x = buf, *xx = x + (long)B * C, *sx = xx + (long)B * C, *t0 = sx + (long)B * C, *t1 = t0 + (long)B * C, *t2 = t1 + (long)B * C,
           *t3 = t2 + (long)B * C, *t4 = t3 + (long)B * C, *r = t4 + (long)B * C, *k = r + (long)B * C, *v = k + (long)B * C, *g = v + (long)B * C,
-          *hid = g + (long)B * C, *hid2 = hid + (long)B * big, *mm = hid2 + (long)B * big, *td = mm + (long)B * 5 * (Dm > 0 ? Dm : 1);
+          *hid = g + (long)B * C, *hid2 = hid + (long)B * big, *mm = hid2 + (long)B * big, *td = mm + (long)B * 5 * (Dm > 0 ? Dm : 1),
+          *vfirst = td + (long)B * (Dd > 0 ? Dd : 1), *aa = vfirst + (long)B * C, *kk = aa + (long)B * C, *xa = kk + (long)B * C,
+          *lora = xa + (long)B * C;                                   /* [B][maxD] */
 #pragma omp parallel for
     for (int b = 0; b < B; ++b) {
         float *xb = x + (long)b * C;
@@ -106,6 +119,86 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
             memcpy(st, xx + (long)b * C, sizeof(float) * C);
         }
         float *xr = t0, *xk = t1, *xv = t2, *xg = t3, *xw = t4;
+        if (m->version == 7) {
+            /* x_n = xx + dx * mu_n, n in (r,w,k,v,a,g);  r,k,v projections;  w/a/g/v LoRAs;  kappa = normalised k*k_k per head;
+             * k <- k (1 + (a-1) k_a);  v <- v + (v_first - v) sigmoid(v0 + V2 V1 x_v) (layers > 0);  decay = exp(-0.606531 sigmoid(w0 + W2 tanh(W1 x_w)));
+             * S <- S diag(decay) + (S (-kappa)) (kappa a)^T + v k^T;  out = S r;  y = GN(out) + (sum_j r_j k_j r_k_j) v;  att = Wo (y g) */
+#pragma omp parallel for
+            for (int b = 0; b < B; ++b)
+                for (int c = 0; c < C; ++c) {
+                    const long i = (long)b * C + c;
+                    const float d = sx[i] - xx[i];
+                    xr[i] = xx[i] + d * p->mix_r[c]; xw[i] = xx[i] + d * p->mix_w[c]; xk[i] = xx[i] + d * p->mix_k[c];
+                    xv[i] = xx[i] + d * p->mix_v[c]; xa[i] = xx[i] + d * p->mix_a[c]; xg[i] = xx[i] + d * p->mix_g[c];
+                }
+            gemm_f16(p->Wr, C, C, xr, C, r, C, B);
+            gemm_f16(p->Wk, C, C, xk, C, k, C, B);
+            gemm_f16(p->Wv, C, C, xv, C, v, C, B);
+            float *wdec = hid2;
+            gemm_f16(p->w1, p->Dw, C, xw, C, lora, p->Dw, B);
+            for (long i = 0; i < (long)B * p->Dw; ++i) lora[i] = tanhf(lora[i]);
+            gemm_f16(p->w2, C, p->Dw, lora, p->Dw, wdec, C, B);
+            gemm_f16(p->a1, p->Da, C, xa, C, lora, p->Da, B);
+            gemm_f16(p->a2, C, p->Da, lora, p->Da, aa, C, B);
+            gemm_f16(p->g1, p->Dg, C, xg, C, lora, p->Dg, B);
+            for (long i = 0; i < (long)B * p->Dg; ++i) lora[i] = sigmoidf(lora[i]);
+            gemm_f16(p->g2, C, p->Dg, lora, p->Dg, g, C, B);
+            float *vgate = hid;                                      /* [B][C] */
+            if (l > 0) {
+                gemm_f16(p->v1, p->Dv, C, xv, C, lora, p->Dv, B);
+                gemm_f16(p->v2, C, p->Dv, lora, p->Dv, vgate, C, B);
+            }
+            float *out = t0;
+#pragma omp parallel for collapse(2)
+            for (int b = 0; b < B; ++b)
+                for (int h = 0; h < H; ++h) {
+                    const long o = (long)b * C + (long)h * N;
+                    float kap[N_HEAD], ka[N_HEAD], kh[N_HEAD], vh[N_HEAD], wh[N_HEAD], oo[N_HEAD];
+                    float nrm = 0.f;
+                    for (int j = 0; j < N; ++j) {
+                        const int c = h * N + j;
+                        const float a = sigmoidf(p->a0[c] + aa[o + j]);
+                        kap[j] = k[o + j] * p->k_k[c];
+                        nrm += kap[j] * kap[j];
+                        kh[j] = k[o + j] * (1.0f + (a - 1.0f) * p->k_a[c]);
+                        ka[j] = a;
+                        float vv = v[o + j];
+                        if (l == 0) vfirst[o + j] = vv;
+                        else vv = vv + (vfirst[o + j] - vv) * sigmoidf(p->v0[c] + vgate[o + j]);
+                        vh[j] = vv;
+                        wh[j] = expf(-0.606531f * sigmoidf(p->w0[c] + wdec[o + j]));
+                    }
+                    nrm = sqrtf(nrm);
+                    if (nrm < 1e-12f) nrm = 1e-12f;
+                    for (int j = 0; j < N; ++j) { kap[j] /= nrm; ka[j] *= kap[j]; }
+                    float *S = states + (long)b * slab + (long)l * (N + 2) * C + (long)C + (long)h * N;   /* S[i][j] at S[i*C + j] */
+                    float dot = 0.f;
+                    for (int j = 0; j < N; ++j) dot += r[o + j] * kh[j] * p->r_k[h * N + j];
+                    for (int i = 0; i < N; ++i) {
+                        float *Si = S + (long)i * C;
+                        float sa = 0.f;
+                        for (int j = 0; j < N; ++j) sa -= Si[j] * kap[j];
+                        float acc = 0.f;
+                        for (int j = 0; j < N; ++j) {
+                            const float sn = Si[j] * wh[j] + sa * ka[j] + vh[i] * kh[j];
+                            Si[j] = sn;
+                            acc += sn * r[o + j];
+                        }
+                        oo[i] = acc;
+                    }
+                    float mean = 0.f, var = 0.f;
+                    for (int j = 0; j < N; ++j) mean += oo[j];
+                    mean /= (float)N;
+                    for (int j = 0; j < N; ++j) var += (oo[j] - mean) * (oo[j] - mean);
+                    var /= (float)N;
+                    const float inv = 1.0f / sqrtf(var + GN_EPS);
+                    for (int j = 0; j < N; ++j) {
+                        const int c = h * N + j;
+                        out[o + j] = ((oo[j] - mean) * inv * p->lnxw[c] + p->lnxb[c] + dot * vh[j]) * g[o + j];
+                    }
+                }
+            gemm_f16(p->Wo, C, C, out, C, t1, C, B);
+        } else {
         if (m->version == 5) {
 #pragma omp parallel for
             for (int b = 0; b < B; ++b)
@@ -188,6 +281,7 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
                 }
             }
         gemm_f16(p->Wo, C, C, out, C, t1, C, B);
+        }
         /* ---- channel mix */
 #pragma omp parallel for
         for (int b = 0; b < B; ++b) {
@@ -199,7 +293,9 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
             memcpy(st, xx + (long)b * C, sizeof(float) * C);
             for (int c = 0; c < C; ++c) {
                 const long i = (long)b * C + c;
-                if (m->version == 5) {
+                if (m->version == 7) {
+                    t2[i] = xx[i] + (sx[i] - xx[i]) * p->fmix_k[c];
+                } else if (m->version == 5) {
                     t2[i] = xx[i] * p->fmix_k[c] + sx[i] * (1.0f - p->fmix_k[c]);
                     t3[i] = xx[i] * p->fmix_r[c] + sx[i] * (1.0f - p->fmix_r[c]);
                 } else {
@@ -211,10 +307,16 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
         gemm_f16(p->Fk, F, C, t2, C, hid, F, B);
         for (long i = 0; i < (long)B * F; ++i) { const float a = hid[i] > 0.f ? hid[i] : 0.f; hid[i] = a * a; }
         gemm_f16(p->Fv, C, F, hid, F, t4, C, B);
-        gemm_f16(p->Fr, C, C, t3, C, r, C, B);
+        if (m->version == 7) {
 #pragma omp parallel for
-        for (int b = 0; b < B; ++b)
-            for (int c = 0; c < C; ++c) x[(long)b * C + c] += sigmoidf(r[(long)b * C + c]) * t4[(long)b * C + c];
+            for (int b = 0; b < B; ++b)
+                for (int c = 0; c < C; ++c) x[(long)b * C + c] += t4[(long)b * C + c];
+        } else {
+            gemm_f16(p->Fr, C, C, t3, C, r, C, B);
+#pragma omp parallel for
+            for (int b = 0; b < B; ++b)
+                for (int c = 0; c < C; ++c) x[(long)b * C + c] += sigmoidf(r[(long)b * C + c]) * t4[(long)b * C + c];
+        }
     }
     if (logits) {
 #pragma omp parallel for
@@ -259,6 +361,25 @@ void rwkv_cpu_fake_quant_int8(uint16_t *w, long rows, long K) {
                 float q = nearbyintf((x[i] - b32) / safe);
                 q = q < 0.f ? 0.f : q > 255.f ? 255.f : q;
                 blk[i] = f64_to_f16((double)a32 * (double)q + (double)b32);
+            }
+        }
+}
+/* NF4 fake-quantisation in place (rwkv_ref.quant_nf4 / dequant_nf4): per 64-block absmax in fp16, index = number of the 15 fp32
+ * midpoints below x / absmax, value = f16(double(absmax) * double(table[index])).  The tables come from rwkv_ref so there is one copy. */
+void rwkv_cpu_fake_quant_nf4(uint16_t *w, long rows, long K, const float *mid15, const uint16_t *table16) {
+#pragma omp parallel for schedule(static)
+    for (long rr = 0; rr < rows; ++rr)
+        for (long k0 = 0; k0 < K; k0 += 64) {
+            uint16_t *blk = w + rr * K + k0;
+            float x[64], am = 0.f;
+            for (int i = 0; i < 64; ++i) { x[i] = h2f(blk[i]); const float a = fabsf(x[i]); if (a > am) am = a; }
+            const uint16_t amh = f32_to_f16(am);
+            const float am32 = h2f(amh), safe = am32 > 0.f ? am32 : 1.0f;
+            for (int i = 0; i < 64; ++i) {
+                const float xn = x[i] / safe;
+                int idx = 0;
+                for (int t = 0; t < 15; ++t) idx += xn > mid15[t];
+                blk[i] = f64_to_f16((double)am32 * (double)h2f(table16[idx]));
             }
         }
 }

@@ -1,7 +1,7 @@
 """oracle/cpu_backend.py — TEST INFRASTRUCTURE: ctypes front of oracle/cpu_backend.c, the compiled (C + OpenMP) second restatement of
-the lock-step decode step for RWKV V5.2 / V6.  Same surface as `rwkv_ref.RwkvRefBatch` (`step`, `init_states`, `greedy_batch`), same
-weights (checkpoint tensors rounded through fp16; quantised layers fake-quantised to the fp16 value the GPU dequantises to — Int8 in C,
-bit for bit `rwkv_ref.fake_quant`; NF4 through the numpy routine).  Used by tests/test_oracle.py (cross-check of the two restatements)
+the lock-step decode step for RWKV V5.2 / V6 / V7.  Same surface as `rwkv_ref.RwkvRefBatch` (`step`, `init_states`, `greedy_batch`), same
+weights (checkpoint tensors rounded through fp16; quantised layers fake-quantised to the fp16 value the GPU dequantises to — Int8 and NF4 in C,
+bit for bit `rwkv_ref.fake_quant`).  Used by tests/test_oracle.py (cross-check of the two restatements)
 and by bench.py's `cpu_baseline` leg.  The product never imports this."""
 from __future__ import annotations
 
@@ -35,7 +35,9 @@ class _Layer(C.Structure):
     _fields_ = [(n, _f32p) for n in ("ln1w", "ln1b", "ln2w", "ln2b", "mix_x", "mix_w", "mix_k", "mix_v", "mix_r", "mix_g")] + \
                [("mix_w1", _u16p), ("mix_w2", _u16p), ("decay", _f32p), ("first", _f32p), ("decay_w1", _u16p), ("decay_w2", _u16p)] + \
                [(n, _u16p) for n in ("Wr", "Wk", "Wv", "Wg", "Wo")] + [("lnxw", _f32p), ("lnxb", _f32p), ("fmix_k", _f32p), ("fmix_r", _f32p)] + \
-               [(n, _u16p) for n in ("Fk", "Fv", "Fr")]
+               [(n, _u16p) for n in ("Fk", "Fv", "Fr")] + \
+               [(n, _f32p) for n in ("mix_a", "w0", "a0", "v0", "k_k", "k_a", "r_k")] + \
+               [(n, _u16p) for n in ("w1", "w2", "a1", "a2", "v1", "v2", "g1", "g2")] + [(n, C.c_int32) for n in ("Dw", "Da", "Dv", "Dg")]
 
 
 class _Model(C.Structure):
@@ -50,9 +52,12 @@ class CpuBackend:
         self.lib.rwkv_cpu_step.argtypes = [C.POINTER(_Model), C.POINTER(C.c_int32), C.c_int, _f32p, _f32p]
         self.lib.rwkv_cpu_fake_quant_int8.argtypes = [_u16p, C.c_long, C.c_long]
         self.lib.rwkv_cpu_threads.restype = C.c_int
+        self.lib.rwkv_cpu_fake_quant_nf4.argtypes = [_u16p, C.c_long, C.c_long, _f32p, _u16p]
+        self._nf4_mid = np.ascontiguousarray(R.NF4_MID, dtype=np.float32)
+        self._nf4_tab = np.ascontiguousarray(R.NF4_TABLE_F16, dtype=np.float16)
         self.info = i = R.model_info(tensors)
-        if i.version not in (5, 6):
-            raise NotImplementedError("the compiled restatement covers V5.2 and V6")
+        if i.version not in (5, 6, 7):
+            raise NotImplementedError("the compiled restatement covers V5.2, V6 and V7")
         qn = set()
         if quant_type != R.QUANT_NONE:
             for l in range(min(quant_layers, i.num_layer)):
@@ -67,7 +72,9 @@ class CpuBackend:
                     a2 = a.reshape(-1, a.shape[-1])
                     self.lib.rwkv_cpu_fake_quant_int8(a2.view(np.uint16).ctypes.data_as(_u16p), a2.shape[0], a2.shape[1])
                 else:
-                    a = np.ascontiguousarray(R.fake_quant(a, quant_type))
+                    a2 = a.reshape(-1, a.shape[-1])
+                    self.lib.rwkv_cpu_fake_quant_nf4(a2.view(np.uint16).ctypes.data_as(_u16p), a2.shape[0], a2.shape[1],
+                                                     self._nf4_mid.ctypes.data_as(_f32p), self._nf4_tab.view(np.uint16).ctypes.data_as(_u16p))
             self._keep.append(a)
             return a.view(np.uint16).ctypes.data_as(_u16p)
 
@@ -86,6 +93,21 @@ class CpuBackend:
             p = f"blocks.{l}."
             y = self._layers[l]
             y.ln1w, y.ln1b, y.ln2w, y.ln2b = vec(p + "ln1.weight"), vec(p + "ln1.bias"), vec(p + "ln2.weight"), vec(p + "ln2.bias")
+            if i.version == 7:
+                for n in "rwkvag":
+                    setattr(y, "mix_" + n, vec(p + "att.x_" + n))
+                y.mix_x, y.mix_w1, y.mix_w2, y.decay_w1, y.decay_w2, y.decay, y.first = none32, none16, none16, none16, none16, none32, none32
+                y.w0, y.a0, y.v0 = vec(p + "att.w0"), vec(p + "att.a0"), vec(p + "att.v0")
+                y.k_k, y.k_a, y.r_k = vec(p + "att.k_k"), vec(p + "att.k_a"), vec(p + "att.r_k")
+                for n in ("w1", "w2", "a1", "a2", "v1", "v2", "g1", "g2"):
+                    setattr(y, n, mat(p + "att." + n))
+                y.Dw, y.Da, y.Dv, y.Dg = (int(np.asarray(tensors[p + "att." + n]).shape[0]) for n in ("w1", "a1", "v1", "g1"))
+                y.Wr, y.Wk, y.Wv = mat(p + "att.receptance.weight"), mat(p + "att.key.weight"), mat(p + "att.value.weight")
+                y.Wg, y.Wo = none16, mat(p + "att.output.weight")
+                y.lnxw, y.lnxb = vec(p + "att.ln_x.weight"), vec(p + "att.ln_x.bias")
+                y.fmix_k, y.fmix_r = vec(p + "ffn.x_k"), none32
+                y.Fk, y.Fv, y.Fr = mat(p + "ffn.key.weight"), mat(p + "ffn.value.weight"), none16
+                continue
             for n in "kvrg":
                 setattr(y, "mix_" + n, vec(p + "att.time_mix_" + n))
             if i.version == 6:

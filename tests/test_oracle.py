@@ -247,7 +247,8 @@ def test_lockstep_batch_form_agrees_with_the_per_token_restatement(name, quant):
         assert g[0] == int(np.argmax(lg[b])) and g[1:] == [int(x) for x in ids[:, b]]
 
 
-@pytest.mark.parametrize("name,quant", [("v5-tiny", (0, 0)), ("v6-tiny", (0, 0)), ("v5-small", (2, 1)), ("v6-small", (3, 1)), ("v6-small", (2, 2))])
+@pytest.mark.parametrize("name,quant", [("v5-tiny", (0, 0)), ("v6-tiny", (0, 0)), ("v7-tiny", (0, 0)), ("v5-small", (2, 1)), ("v6-small", (3, 1)),
+                                        ("v6-small", (2, 2)), ("v7-small", (3, 2)), ("v7-small", (2, 1))])
 def test_compiled_restatement_agrees_with_the_numpy_one(name, quant):
     """oracle/cpu_backend.c (C + OpenMP, the CPU baseline of bench.py) against RwkvRefBatch: two independent codes of the same
     formulas, the same fp16 / fake-quantised weights — logits and state slabs to fp32 round-off, arg-max identical, over 16 lock-step
@@ -267,19 +268,26 @@ def test_compiled_restatement_agrees_with_the_numpy_one(name, quant):
     assert cb.step([1] * B, s2, want_logits=False) is None
 
 
-def test_compiled_int8_fake_quantisation_is_bit_identical_to_the_numpy_one():
-    """`rwkv_cpu_fake_quant_int8` (per 128-block a, b in fp16, one rounding of a*q + b from float64) against rwkv_ref.fake_quant over
-    seven orders of magnitude, constant and zero blocks included."""
+def test_compiled_fake_quantisation_is_bit_identical_to_the_numpy_one():
+    """`rwkv_cpu_fake_quant_int8` (per 128-block a, b in fp16, one rounding of a*q + b from float64) and `rwkv_cpu_fake_quant_nf4`
+    (per 64-block absmax, 15 fp32 midpoints, one rounding of absmax * table[idx]) against rwkv_ref.fake_quant over seven orders of
+    magnitude, constant and zero blocks included."""
     import ctypes as C
     from oracle import cpu_backend as cb
     lib = C.CDLL(cb.build())
-    lib.rwkv_cpu_fake_quant_int8.argtypes = [C.POINTER(C.c_uint16), C.c_long, C.c_long]
+    u16p, f32p = C.POINTER(C.c_uint16), C.POINTER(C.c_float)
+    lib.rwkv_cpu_fake_quant_int8.argtypes = [u16p, C.c_long, C.c_long]
+    lib.rwkv_cpu_fake_quant_nf4.argtypes = [u16p, C.c_long, C.c_long, f32p, u16p]
+    mid = np.ascontiguousarray(R.NF4_MID, dtype=np.float32)
+    tab = np.ascontiguousarray(R.NF4_TABLE_F16, dtype=np.float16)
     rng = np.random.default_rng(0)
     for scale in (1e-6, 1e-3, 0.05, 1.0, 30.0, 3000.0):
         w = (rng.standard_normal((32, 512)) * scale).astype(np.float16)
         w[0, :128] = np.float16(0.37)
         w[1, :128] = 0
-        want = R.fake_quant(w.copy(), R.QUANT_INT8)
         got = w.copy()
-        lib.rwkv_cpu_fake_quant_int8(got.view(np.uint16).ctypes.data_as(C.POINTER(C.c_uint16)), 32, 512)
-        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), scale
+        lib.rwkv_cpu_fake_quant_int8(got.view(np.uint16).ctypes.data_as(u16p), 32, 512)
+        assert np.array_equal(got.view(np.uint16), R.fake_quant(w.copy(), R.QUANT_INT8).view(np.uint16)), scale
+        got = w.copy()
+        lib.rwkv_cpu_fake_quant_nf4(got.view(np.uint16).ctypes.data_as(u16p), 32, 512, mid.ctypes.data_as(f32p), tab.view(np.uint16).ctypes.data_as(u16p))
+        assert np.array_equal(got.view(np.uint16), R.fake_quant(w.copy(), R.QUANT_NF4).view(np.uint16)), scale
