@@ -47,7 +47,7 @@ typedef struct {
 
 /* Y[b][r] = sum_k W[r][k] X[b][k];  W fp16 row-major [rows][K], K % 8 == 0;  slots in groups of 8 so the accumulators stay in registers */
 static void gemm_f16(const uint16_t *W, long rows, long K, const float *X, long ldx, float *Y, long ldy, int B) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (rows * K >= 32768)   /* the LoRA matrices are too small to pay for a fork on a 256-thread host */
     for (long r = 0; r < rows; ++r) {
         const uint16_t *w = W + r * K;
         for (int b0 = 0; b0 < B; b0 += 8) {
@@ -305,6 +305,7 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
             }
         }
         gemm_f16(p->Fk, F, C, t2, C, hid, F, B);
+#pragma omp parallel for schedule(static)
         for (long i = 0; i < (long)B * F; ++i) { const float a = hid[i] > 0.f ? hid[i] : 0.f; hid[i] = a * a; }
         gemm_f16(p->Fv, C, F, hid, F, t4, C, B);
         if (m->version == 7) {
