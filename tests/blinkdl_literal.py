@@ -13,14 +13,19 @@ def _t(a):
 
 
 class Literal:
-    def __init__(self, st: dict):
+    def __init__(self, st: dict, layout: str = "converted"):
+        """`layout="converted"`: `st` is an ai00 `.st` (the converter's renames and transposes are undone here);
+        `layout="blinkdl"`: `st` is a checkpoint as BlinkDL's trainer saves it (`time_maa_*`, `time_faaaa`, nothing
+        transposed) — only the two renames are applied, so the arithmetic below runs on the ORIGINAL tensors."""
+        if layout == "blinkdl":
+            st = {k.replace("time_faaaa", "time_first").replace("time_maa", "time_mix"): a for k, a in st.items()}
         self.v = 7 if "blocks.0.att.x_r" in st else 6 if "blocks.0.att.time_mix_x" in st else 5
         w = {}
         for k, a in st.items():
             t = _t(a)
             # undo the converter: names containing these substrings were transposed on the last two dims
-            if any(s in k for s in ["time_mix_w1", "time_mix_w2", "time_decay_w1", "time_decay_w2", "w1", "w2", "a1",
-                                    "a2", "g1", "g2", "v1", "v2", "time_state", "lora.0"]):
+            if layout == "converted" and any(s in k for s in ["time_mix_w1", "time_mix_w2", "time_decay_w1", "time_decay_w2", "w1", "w2", "a1",
+                                                               "a2", "g1", "g2", "v1", "v2", "time_state", "lora.0"]):
                 t = t.transpose(-1, -2).contiguous()
             if k.endswith(".weight") and t.dim() == 2 and "emb" not in k and "ln" not in k:
                 t = t.t().contiguous()          # BlinkDL inference stores linear weights as [in, out]: x @ w
