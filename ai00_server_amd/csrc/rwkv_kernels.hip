@@ -796,7 +796,7 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     const int c = blockIdx.y;                                     // mix index
     const int sg = blockIdx.x;                                    // strip group (8 strips of W2_c)
     const int C = a.C, Dm = a.Dm, T = a.T;
-    const int t0 = WIDE ? (int)blockIdx.z * NT * 16 : 0;          // first token of this block's tile
+    const int t0 = (int)blockIdx.z * NT * 16;                      // first token of this block's tile (decode form: 17..32 rows run two NT = 1 tiles)
     // DS = Dm/16 strips of W1_c (2 or 4)
     const int KT1 = C >> 5;                                       // k-tiles of W1 per strip
     const int kst = KT1 >> 3;                                     // k-steps per wave in phase 1 (C/8/32)
@@ -827,9 +827,26 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     const int ldl = C + LNP_PAD;
     float *pv_l = xx_l + LNP_MAX_T * ldl, *lred = pv_l + LNP_MAX_T * ldl;
     _Float16 *z_l = (_Float16 *)(lred + 64);
+    const u32x4 *w1 = (const u32x4 *)a.W1;
+    constexpr int KB = DS == 2 ? ((HILO && NT == 2) ? 5 : 10) : 4;                                          // k-steps per batch: all loads of a batch in flight at once
+    u32x4 wt[KB][DS];
+    auto load_wt = [&](int k0) {                                  // this wave's W1_c tiles of k-steps k0 .. k0+KB
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            if (k0 + j < kst) {                                    // wave-uniform
+                const int kt = wave * kst + k0 + j;
+#pragma unroll
+                for (int d = 0; d < DS; ++d) wt[j][d] = w1[((long)(c * DS + d) * KT1 + kt) * 64 + lane];
+            }
+        }
+    };
     if constexpr (LNP) {
         LnCarry carry;
         const bool pub = blockIdx.x == 0 && blockIdx.y == 0;
+        // W1 does not depend on the row: its first batch (the whole slice of this wave at C = 2560) is requested before the
+        // prologue, so the 164 KiB a block pulls from L2 overlap the row loads and the four barriers of the LayerNorm instead
+        // of following them (phase 1 of a single-token step: 5.2 -> ~3 us in the in-kernel timeline)
+        load_wt(0);
         ln_prologue_load(a.lnp, T, xx_l, pv_l, lred, pub, carry);
         ln_prologue_finish<HILO>(a.lnp, T, a.mu_x, xx_l, pv_l, z_l, lred, pub, carry);
 #pragma unroll
@@ -844,7 +861,7 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     } else if constexpr (!WIDE) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            int t = nt * 16 + (lane & 15);
+            int t = t0 + nt * 16 + (lane & 15);
             t = t < T ? t : T - 1;
             xxv[nt] = act_ld4(bxx, (long)t * C + row0);
             dxv[nt] = act_ld4(bdx, (long)t * C + row0);
@@ -856,11 +873,9 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     for (int d = 0; d < DS; ++d)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[d][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const u32x4 *w1 = (const u32x4 *)a.W1;
-    constexpr int KB = DS == 2 ? ((HILO && NT == 2) ? 5 : 10) : 4;                                          // k-steps per batch: all loads of a batch in flight at once
     for (int k0 = 0; k0 < kst; k0 += KB) {
         f16x8 zb[KB][NT], zl[HILO ? KB : 1][HILO ? NT : 1];
-        u32x4 wt[KB][DS];
+        if (!LNP || k0 > 0) load_wt(k0);
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             if (k0 + j < kst) {                                    // wave-uniform
@@ -878,8 +893,6 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
                         if constexpr (HILO) zl[j][nt] = act_ldh8(bzl, zo);
                     }
                 }
-#pragma unroll
-                for (int d = 0; d < DS; ++d) wt[j][d] = w1[((long)(c * DS + d) * KT1 + kt) * 64 + lane];
             }
         }
 #pragma unroll
@@ -987,10 +1000,14 @@ bool v6_mix_wide_supported(int T, int C, int Dm) { return T > 32 && C % 256 == 0
 
 void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
     const bool wide = a.T > 32;                                // v6_mix_wide_supported: one block per (mix, 32-token tile)
-    const int NT = (a.T <= 16 && !wide) ? 1 : 2;
+    // 17..32 rows: two 16-token tiles of NT = 1 blocks (200 workgroups, each pulling W1_c + HALF of z) instead of 100 NT = 2
+    // blocks that each pull W1_c + all of z — phase 1 is bound by what a CU can ingest.  RWKV_V6MIX_NT2=1: the old form.
+    static const int nt2 = std::getenv("RWKV_V6MIX_NT2") ? std::atoi(std::getenv("RWKV_V6MIX_NT2")) : 0;
+    const bool split_tiles = !wide && a.T > 16 && !nt2 && a.lnp.x_in == nullptr;
+    const int NT = ((a.T <= 16 && !wide) || split_tiles) ? 1 : 2;
     const bool lnp = a.lnp.x_in != nullptr;                    // host: T <= LNP_MAX_T, !hilo, C <= 4096 (v6_mix_ln_supported)
     const size_t lds = (size_t)8 * 4 * NT * 64 * 16 + (size_t)2 * NT * 16 * (a.Dm + 8) * 2 + (lnp ? lnp_lds_bytes(LNP_MAX_T, a.C, hilo) : 0);
-    dim3 grid((a.C / 16 + 7) / 8, 5), block(512);
+    dim3 grid((a.C / 16 + 7) / 8, 5, split_tiles ? 2 : 1), block(512);
     if (wide) {
         const int ntile = (a.T + 31) / 32;
         grid = dim3(std::max(1, std::min(8, 256 / (5 * ntile))), 5, ntile);   // fill the chip when the step has few token tiles

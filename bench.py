@@ -5,21 +5,34 @@
 
 A "step" is one decode step of the hot path over a batch of B slots (one token per slot: B tokens),
 inputs (weights, recurrent state, token ids) resident in HBM: the arg-max token is fed back on the device
-(`rwkv_decode_greedy`), so no PCIe traffic sits inside the timed region.  N > 1: one process per GPU
-(launched by torch.distributed.run), every rank is an independent replica with its own weights, slots and
-stream (replicas only, no collective on the data path); weak scaling.
+(`rwkv_decode_greedy`), so no PCIe traffic sits inside the timed region.
+
+N > 1: one process per GPU, every rank an independent replica with its own weights, slots and stream (SURVEY 8e:
+replicas only, no collective on the data path); weak scaling.  Launched either by the driver
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come
+from the environment) or by this file itself: `python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N
+ranks as child processes (gloo rendezvous on 127.0.0.1) and relays rank 0's line.  The barrier and the MAX of the timing go
+over gloo on the host; `n_gpus` in the line is the world size that actually ran, and it must equal `--gpus`.
+
+Legs of the default run (rank 0, N = 1; every leg carries its own roofline fraction and a verification flag):
+  * the headline: BASELINE config #3 (V6-3B Int8, 32 slots) + sweep B = 1, 8, PCIe-inclusive and on-device-sampling rates,
+    embeddings/s (256-token documents, state-only prefill, checked against a `Last` prefill of the same documents);
+  * `configs`: #2 (V6-1.6B fp16, B = 1), V6-3B fp16 at B = 1 / 32, #4 (V7-2.9B NF4: B = 32 decode + `/embeddings` at
+    token_chunk_size 256), #5 (V6-7B fp16: 8 x 4096-token prefill at chunk 2048 / 1024 + B = 8 decode);
+  * `cpu_baseline`: the compiled restatement on the host cores (a reported baseline, never the target).
 
 What this file takes from oracle/ (test infrastructure): the SYNTHETIC CHECKPOINT of the named shapes (`synth_st`,
 `model_info`, `synth_prompt`: there is no network for real weights), the byte accounting of the roofline
-(`algorithmic_bytes`), and the `cpu_baseline` leg (the numpy restatement timed on the host cores).  The measured
-path never touches it: the engine is librwkv_hip.so through ai00_server_amd.runtime.
+(`algorithmic_bytes`), and the `cpu_baseline` leg.  The measured path never touches it: the engine is librwkv_hip.so
+through ai00_server_amd.runtime.
 """
 from __future__ import annotations
 
 import argparse
 import json
-import subprocess
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,10 +41,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK = 8.0e12   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK = 8.0e12    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_PEAK = 2.5e15   # dense fp16 / bf16 MFMA peak
+QT = {"none": 0, "int8": 1, "nf4": 2}
+DTYPE = {"none": "f16", "int8": "u8->f16", "nf4": "nf4->f16"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -41,326 +57,475 @@ def main():
     ap.add_argument("--quant", default="int8", choices=["none", "int8", "nf4"])
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--decode-only", action="store_true", help="skip the embeddings / PCIe / sampling / CPU legs (profiling)")
+    ap.add_argument("--decode-only", action="store_true", help="headline decode + roofline only (profiling runs)")
     ap.add_argument("--sweep", default="1,8", help="extra batch sizes reported under 'sweep' (north_star: batch 1-32)")
     ap.add_argument("--verify-steps", type=int, default=8, help="decode steps re-run through rwkv_infer + host arg-max and compared")
-    ap.add_argument("--config5", action="store_true", help="also run BASELINE config #5 (V6-7B fp16, 8 x 4096-token prefill at chunk 2048, "
-                                                           "then 256 decode steps at batch 8) and report it under 'config5'")
-    args = ap.parse_args()
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (#2, #4, #5, V6-3B fp16)")
+    ap.add_argument("--config5", action="store_true", help="kept for old command lines: config #5 is part of the default run")
+    ap.add_argument("--selftest-dist", action="store_true",
+                    help="exercise launcher + rendezvous + barrier + MAX reduction with a stand-in workload (no GPU, no engine): CPU test of the N > 1 path")
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("BENCH_SHARE_GPU"):       # test hook: all ranks on device 0 (validates the N>1 code path on a 1-GPU box)
-        local_rank = 0
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("gloo")     # replicas only: the barrier and the MAX of the timing are host-side, no RCCL
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves
+# ------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: one child per GPU with the launcher's environment contract
+    (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT).  Rank 0's stdout is ours; a failing rank fails the run."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+class Job:
+    """Rank bookkeeping + the host-side barrier / MAX reduction (gloo; there is no RCCL communicator in this repo)."""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("BENCH_SHARE_GPU"):       # test hook: all ranks on device 0 (the N > 1 code path on a 1-GPU box)
+            self.local_rank = 0
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: the line would report the wrong n_gpus")
+        self.dist = None
+        self.torch = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")         # replicas only (SURVEY 8e)
+            self.dist = dist
+
+    def use_gpu(self):
+        import torch
+        self.torch = torch
+        if torch.cuda.is_available():
+            torch.cuda.set_device(self.local_rank)
+
+    def sync(self):
+        if self.torch is not None and self.torch.cuda.is_available():
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.sync()
+
+    def max_and_all(self, dt: float):
+        """(MAX over ranks, [every rank's value])"""
+        if self.dist is None:
+            return dt, [dt]
+        import torch
+        x = torch.tensor([dt], dtype=torch.float64)
+        xs = [torch.zeros(1, dtype=torch.float64) for _ in range(self.world)]
+        self.dist.all_gather(xs, x)
+        vals = [float(v.item()) for v in xs]
+        return max(vals), vals
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# legs
+# ------------------------------------------------------------------------------------------------
+def build_engine(rt, st, local_rank, ql, qt, B, chunk, precision="fp16"):
+    return (rt.ModelBuilder(st, adapter=local_rank).quant(ql, rt.Quant(qt))
+            .build(max_batch=max(B, 1), token_chunk_size=chunk,
+                   precision=rt.Precision.Fp32 if precision == "fp32" else rt.Precision.Fp16))
+
+
+def first_tokens(R, V, B):
+    return np.array([R.synth_prompt(s, 1)[0] % V for s in range(B)], dtype=np.uint32)
+
+
+def verify_decode(rt, eng, first, n_steps):
+    """The timed call's own output, checked: the same first steps from a zero state through rwkv_infer (logits to the host,
+    arg-max there, run.rs:809-832) must give the ids rwkv_decode_greedy produced on the device, for every slot."""
+    B = len(first)
+    zero = eng.state.init()
+    for b in range(B):
+        eng.state.load(zero, b)
+    dev_ids, _ = eng.decode_greedy(first, n_steps)
+    for b in range(B):
+        eng.state.load(zero, b)
+    cur = [int(x) for x in first]
+    host_ids = np.zeros((n_steps, B), dtype=np.int64)
+    for s_ in range(n_steps):
+        inp = rt.RnnInput([rt.RnnInputBatch([cur[b]] if b < B else [], rt.RnnOption.Last) for b in range(eng.max_batch)])
+        _, outs = eng.infer(inp)
+        cur = [int(np.argmax(outs[b][-1])) for b in range(B)]
+        host_ids[s_] = cur
+    ok = bool(np.array_equal(np.asarray(dev_ids, dtype=np.int64)[:, :B], host_ids))
+    assert ok, "rwkv_decode_greedy ids differ from rwkv_infer + host arg-max"
+    return ok
+
+
+def decode_point(job, eng, first, steps, warmup):
+    """EXACTLY `steps` timed decode steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+    if warmup > 0:
+        eng.decode_greedy(first, warmup)
+    job.barrier()
+    t = time.perf_counter()
+    _, dev_ms = eng.decode_greedy(first, steps)
+    job.sync()
+    dt = time.perf_counter() - t
+    job.barrier()
+    dt_max, dt_all = job.max_and_all(dt)
+    return dt_max, dt_all, dev_ms
+
+
+def embed_leg(rt, R, eng, info, B, doc_len=256):
+    """Second half of BASELINE's metric: documents prefilled state-only (RWKV_OPTION_NONE: no head GEMM, no logits) and read back
+    as one layer's WKV rows (rwkv_state_back_layer, docs/doc-api/openai.md:376-437) per second.  Refuses to report unless the
+    embeddings equal, bit for bit, those of the same documents prefilled with `Last` (the reference-shaped call)."""
+    V, layer = info.num_vocab, info.num_layer - 1
+    docs = [[t % V for t in R.synth_prompt(100 + b, doc_len)] for b in range(B)]
+    zero = eng.state.init()
+
+    def run(option):
+        for b in range(B):
+            eng.state.load(zero, b)
+        t = time.perf_counter()
+        inp = rt.RnnInput([rt.RnnInputBatch(list(docs[b]) if b < B else [], option) for b in range(eng.max_batch)])
+        while inp.num_token() > 0:
+            inp, _ = eng.infer(inp)
+        vecs = [eng.state.embed(layer, b) for b in range(B)]
+        return time.perf_counter() - t, vecs
+
+    best, vecs = None, None
+    for _ in range(3):
+        dt, vecs = run(rt.RnnOption.NoOutput)
+        best = dt if best is None else min(best, dt)
+    _, ref = run(rt.RnnOption.Last)
+    ok = all(np.array_equal(a, b) for a, b in zip(vecs, ref)) and all(np.isfinite(a).all() and np.abs(a).max() > 0 for a in vecs)
+    assert ok, "state-only (RWKV_OPTION_NONE) embeddings differ from a `Last` prefill of the same documents"
+    return {"value": B / best, "unit": "embeddings/s", "doc_tokens": doc_len, "docs": B, "prefill_tokens_per_s": B * doc_len / best,
+            "token_chunk_size": eng.token_chunk_size, "embeddings_verified": ok,
+            "checksum": float(np.sum([np.abs(a).astype(np.float64).sum() for a in vecs])),
+            "embedding": f"layer {layer} WKV rows [64 x {info.num_emb}] via rwkv_state_back_layer"}
+
+
+def roofline_leg(rt, R, eng, info, shapes, first, ms_per_step, workload, quant, step_frac, ab):
+    """Dominant kernel family (the layer GEMMs): per-launch hipEvent timing on the engine's stream (eager step, rwkv_profile_infer),
+    calibrated against the graph-replayed step so that the family times tile the step like rocprofv3's kernel durations."""
+    B, V = len(first), info.num_vocab
+    fam_ms, nprof = {}, 5
+    for it in range(nprof + 1):
+        inp = rt.RnnInput([rt.RnnInputBatch([int(first[b])] if b < B else [], rt.RnnOption.Last) for b in range(eng.max_batch)])
+        _, _, fam = eng.profile_infer(inp)
+        if it == 0:
+            continue        # first pass warms caches / clocks
+        for k, (ms, n) in fam.items():
+            a = fam_ms.setdefault(k, [0.0, 0])
+            a[0] += ms
+            a[1] += n
+    g_ms, g_n = fam_ms["gemm_layers"]
+    h_ms, h_n = fam_ms["gemm_head"]
+    head_bytes = V * info.num_emb * 2
+    vec_bytes = sum(int(np.prod(s)) * 2 for k, s in shapes.items() if len([d for d in s if d > 1]) <= 1)
+    layer_gemm_bytes = eng.weight_bytes - head_bytes - vec_bytes          # weights the layer-GEMM family streams (LoRA matrices included)
+    # An event pair adds marker processing (about 2 us) to what it brackets: the pairs of a step sum to more than the step itself
+    # takes.  The excess over the graph-replayed step, spread evenly over the launches, is subtracted from every launch.
+    n_launch = sum(v[1] for v in fam_ms.values()) / nprof
+    pairs_ms = sum(v[0] for v in fam_ms.values()) / nprof
+    marker_us = max(0.0, (pairs_ms - ms_per_step) / n_launch * 1e3)
+    g_step_ms = g_ms / nprof - marker_us * 1e-3 * (g_n / nprof)
+    achieved = layer_gemm_bytes / (g_step_ms * 1e-3)
+    # HBM traffic per launch from the PMC passes (scripts/collect_pmc.py on the same workload; committed under profiles/).
+    traffic, traffic_src = None, None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_traffic_{workload}_{quant}_b{B}.json"))):
+        try:
+            traffic = json.load(open(f))["layer_gemm"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/" + os.path.basename(f)
+        except Exception:
+            pass
+    per_layer = (g_n // nprof) // max(1, info.num_layer)
+    return {"bound": "hbm",
+            "kernel": f"layer GEMM family: gemm_kernel (time-mix projections + decay LoRA, output, channel-mix key/receptance, channel-mix value)"
+                      f"{' + v6_mix_kernel (token-shift LoRA)' if int(info.version) == 6 else ''}, {per_layer} launches per layer",
+            "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": layer_gemm_bytes / max(1, g_n // nprof),
+            "launches_per_step": g_n // nprof, "avg_launch_us": g_step_ms / (g_n / nprof) * 1e3,
+            "avg_launch_us_raw_event_pairs": g_ms / g_n * 1e3, "event_pair_overhead_us": marker_us,
+            "bytes_per_step": layer_gemm_bytes,
+            "head_gemm_GBps": head_bytes / max(1e-9, (h_ms / nprof - marker_us * 1e-3 * (h_n / nprof)) * 1e-3) / 1e9,
+            "family_ms_per_step": {k: v[0] / nprof - marker_us * 1e-3 * (v[1] / nprof) for k, v in fam_ms.items()},
+            "step": {"bytes": ab["per_step"], "frac_of_peak": step_frac, "W_q": ab["W_q"], "S": ab["S"]}}
+
+
+def config_leg(job, rt, R, name, quant, batches, steps, verify_steps, embed_chunk=None, prefill=None):
+    """One other BASELINE configuration on its own engine: decode at `batches` (each with its whole-step fraction of 8 TB/s), the
+    largest batch verified against rwkv_infer + host arg-max; optionally an embeddings leg at `embed_chunk`; optionally a long
+    prefill (`prefill` = (prompt_tokens, [chunks])) priced against the MFMA peak."""
+    st, tensors = R.synth_st(name, fast=True)
+    info = R.model_info(tensors)
+    shapes = {k: v.shape for k, v in tensors.items()}
+    del tensors
+    qt = QT[quant]
+    ql = info.num_layer if qt else 0
+    B = max(batches)
+    out = {"workload": f"RWKV-{name} {quant}", "dtype": DTYPE[quant] + "/f32acc", "decode": {}}
+    t0 = time.time()
+    eng = build_engine(rt, st, job.local_rank, ql, qt, B, max(2048, B) if prefill is None else max(prefill[1]))
+    out["load_s"] = time.time() - t0
+    V = info.num_vocab
+    first = first_tokens(R, V, B)
+    for nb in batches:
+        dt, _, _ = decode_point(job, eng, first[:nb], steps, min(5, steps))
+        ab = R.algorithmic_bytes(info, shapes, ql, qt, nb)
+        out["decode"][str(nb)] = {"tokens_per_s": nb * steps / dt, "ms_per_step": dt * 1e3 / steps,
+                                  "frac_of_hbm_peak": ab["per_step"] * (steps / dt) / HBM_PEAK}
+    out["tokens_verified"] = verify_decode(rt, eng, first, verify_steps) if verify_steps > 0 else None
+    if prefill is not None:
+        n_tok, chunks = prefill
+        flops_tok = 2.0 * sum(int(np.prod(v)) for k, v in shapes.items() if k != "emb.weight")
+        docs = [[t % V for t in R.synth_prompt(500 + b, n_tok)] for b in range(B)]
+        out["prefill"] = {}
+        for ch in chunks:
+            e = eng if ch == eng.token_chunk_size else build_engine(rt, st, job.local_rank, ql, qt, B, ch)
+            best, last = None, None
+            for rep in range(2):
+                z = e.state.init()
+                for b in range(B):
+                    e.state.load(z, b)
+                job.sync()
+                t = time.perf_counter()
+                inp = rt.RnnInput([rt.RnnInputBatch(list(docs[b]), rt.RnnOption.Last) for b in range(B)])
+                while inp.num_token() > 0:
+                    inp, outs = e.infer(inp)
+                d = time.perf_counter() - t
+                best = d if best is None else min(best, d)
+                ids = [int(np.argmax(outs[b][-1])) for b in range(B)]
+                assert last is None or ids == last, "prefill is not reproducible run to run"
+                last = ids
+            out["prefill"][str(ch)] = {"tokens_per_s": B * n_tok / best, "s": best, "TFLOPs": B * n_tok * flops_tok / best / 1e12,
+                                       "frac_of_mfma_peak": B * n_tok * flops_tok / best / MFMA_PEAK, "last_token_ids": last}
+            if e is not eng:
+                e.close()
+        ids = [v["last_token_ids"] for v in out["prefill"].values()]
+        out["prefill_chunks_agree"] = all(i == ids[0] for i in ids)      # chunking is exact for an RNN up to GEMM summation order
+        out["prefill_workload"] = f"{B} x {n_tok}-token prompts, MFMA-bound: flops = 2 x (params - embedding) per token against {MFMA_PEAK / 1e15} PFLOP/s"
+    eng.close()
+    if embed_chunk is not None:
+        e = build_engine(rt, st, job.local_rank, ql, qt, B, embed_chunk)
+        out["embeddings"] = embed_leg(rt, R, e, info, B)
+        e.close()
+    return out
+
+
+def cpu_leg(R, tensors, ql, qt, first, workload, quant):
+    """CPU leg ("port"): the SAME configuration on the host cores through the compiled restatement oracle/cpu_backend.c (tests/test_oracle.py
+    holds it against the numpy restatement; numpy itself if it cannot be built).  A baseline to stand next to the GPU number, never the target."""
+    B = len(first)
+    cur = [int(x) for x in first]
+    host = host_description()
+    try:
+        from oracle.cpu_backend import CpuBackend
+        ref = CpuBackend(tensors, ql, qt)
+        how = ref.describe() if hasattr(ref, "describe") else f"C/OpenMP restatement (oracle/cpu_backend.c), {ref.threads} threads"
+        cores = ref.threads
+    except (NotImplementedError, OSError, subprocess.CalledProcessError):
+        CpuBackend = None
+        ref = R.RwkvRefBatch(tensors)
+        how, cores = "numpy/BLAS fp32 oracle on all host cores, weights fp16-rounded (unquantised on the CPU side)", os.cpu_count()
+    st_cpu = ref.init_states(B)
+    ref.step(cur, st_cpu, want_logits=False)       # warm
+    n_step, t1 = 0, time.time()
+    while time.time() - t1 < 12.0 and n_step < 256:
+        lg = ref.step(cur, st_cpu)
+        cur = [int(x) for x in np.argmax(lg, axis=1)]
+        n_step += 1
+    cdt = time.time() - t1
+    cpu = {"value": B * n_step / cdt, "unit": "tokens/s", "cores": cores, "kind": "port", "host": host,
+           "sample": f"{n_step} lock-step decode steps of {B} slots ({B * n_step} tokens), {how}, {workload} {quant}"}
+    if hasattr(ref, "stream_gbps"):
+        cpu["effective_weight_stream_GBps"] = ref.stream_gbps(n_step / cdt)
+    del ref, st_cpu
+    # BASELINE config #1: RWKV-V5-World-0.4B fp16, batch 1, greedy, on the CPU path (the reference has no CPU backend,
+    # lib.rs:339-368; this is the port)
+    try:
+        _, t5 = R.synth_st("v5-0.4b", fast=True)
+        r5 = CpuBackend(t5) if CpuBackend is not None else R.RwkvRefBatch(t5)
+        s5 = r5.init_states(1)
+        lg = r5.step([int(first[0]) % r5.info.num_vocab], s5)
+        n5, t1 = 0, time.time()
+        while time.time() - t1 < 5.0 and n5 < 2048:
+            lg = r5.step([int(np.argmax(lg[0]))], s5)
+            n5 += 1
+        d5 = time.time() - t1
+        cpu["config1_v5_0.4b_b1_tokens_per_s"] = n5 / d5
+        if hasattr(r5, "stream_gbps"):
+            cpu["config1_effective_weight_stream_GBps"] = r5.stream_gbps(n5 / d5)
+        del r5, t5
+    except MemoryError:
+        pass
+    return cpu
+
+
+def host_description() -> dict:
+    """CPU model / sockets / cores of the host the CPU leg runs on (SURVEY 8d asks for them next to the number)."""
+    d = {"logical_cpus": os.cpu_count()}
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=5).stdout
+        for line in txt.splitlines():
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "Model name":
+                d["model"] = v
+            elif k == "Socket(s)":
+                d["sockets"] = int(v)
+            elif k == "Core(s) per socket":
+                d["cores_per_socket"] = int(v)
+            elif k == "Thread(s) per core":
+                d["threads_per_core"] = int(v)
+            elif k == "NUMA node(s)":
+                d["numa_nodes"] = int(v)
+    except Exception:
+        pass
+    return d
+
+
+# ------------------------------------------------------------------------------------------------
+def selftest_dist(job, args):
+    """Stand-in workload for the CPU test of the N > 1 path: same barrier / timing / reduction / line, no engine."""
+    job.barrier()
+    t = time.perf_counter()
+    time.sleep(0.002 * args.steps * (1 + job.rank))          # ranks finish at different times: MAX must pick the slowest
+    dt = time.perf_counter() - t
+    job.barrier()
+    dt_max, dt_all = job.max_and_all(dt)
+    if job.rank == 0:
+        B = args.batch
+        print(json.dumps({"metric": "decode tokens/sec (whole job)", "value": B * job.world * args.steps / dt_max, "unit": "tokens/s",
+                          "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max * 1e3 / args.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "selftest", "data": "none",
+                          "config": {"workload": "launcher self-test (sleep)"},
+                          "per_rank_tokens_per_s": [B * args.steps / d for d in dt_all], "selftest": True}), flush=True)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, argv)
+    job = Job(args)
+    if args.selftest_dist:
+        selftest_dist(job, args)
+        job.close()
+        return 0
+    job.use_gpu()
+    rank, world = job.rank, job.world
 
     from ai00_server_amd import runtime as rt
-    from oracle import rwkv_ref as R   # checkpoint synthesis + the cpu_baseline leg only
+    from oracle import rwkv_ref as R   # checkpoint synthesis + byte accounting + the cpu_baseline leg only
 
     t0 = time.time()
     st, tensors = R.synth_st(args.workload, fast=True)
     info = R.model_info(tensors)
     shapes = {k: v.shape for k, v in tensors.items()}
-    qt = {"none": 0, "int8": 1, "nf4": 2}[args.quant]
+    qt = QT[args.quant]
     ql = info.num_layer if qt else 0
     B = args.batch
     t_synth = time.time() - t0
 
     t0 = time.time()
-    eng = (rt.ModelBuilder(st, adapter=local_rank).quant(ql, rt.Quant(qt))
-           .build(max_batch=max(B, 1), token_chunk_size=max(2048, B),
-                  precision=rt.Precision.Fp32 if args.precision == "fp32" else rt.Precision.Fp16))
+    eng = build_engine(rt, st, job.local_rank, ql, qt, B, max(2048, B), args.precision)
     t_load = time.time() - t0
-
     V = info.num_vocab
-    first = np.array([R.synth_prompt(s, 1)[0] % V for s in range(B)], dtype=np.uint32)
+    first = first_tokens(R, V, B)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(nb, steps, warmup):
-        ft = first[:nb]
-        if warmup > 0:
-            eng.decode_greedy(ft, warmup)
-        barrier()
-        t = time.perf_counter()
-        toks, dev_ms = eng.decode_greedy(ft, steps)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t
-        barrier()
-        if dist is not None:
-            x = torch.tensor([dt], dtype=torch.float64, device="cpu")
-            dist.all_reduce(x, op=dist.ReduceOp.MAX)
-            dt = float(x.item())
-        return dt, dev_ms, toks
-
-    dt, dev_ms, toks = timed(B, args.steps, args.warmup)
+    dt, dt_all, dev_ms = decode_point(job, eng, first, args.steps, args.warmup)
     ms_per_step = dt * 1e3 / args.steps
     value = B * world * args.steps / dt
 
-    # ---- the timed call's own output, checked: the same first steps from a zero state through rwkv_infer (logits to the
-    # host, arg-max there, run.rs:809-832) must give the ids rwkv_decode_greedy produced on the device, for every slot
-    tokens_verified = None
-    if rank == 0 and args.verify_steps > 0:
-        zero = eng.state.init()
-        for b in range(B):
-            eng.state.load(zero, b)
-        dev_ids, _ = eng.decode_greedy(first, args.verify_steps)
-        for b in range(B):
-            eng.state.load(zero, b)
-        cur = [int(x) for x in first]
-        host_ids = np.zeros((args.verify_steps, B), dtype=np.int64)
-        for s_ in range(args.verify_steps):
-            inp = rt.RnnInput([rt.RnnInputBatch([cur[b]] if b < B else [], rt.RnnOption.Last) for b in range(eng.max_batch)])
-            _, outs = eng.infer(inp)
-            cur = [int(np.argmax(outs[b][-1])) for b in range(B)]
-            host_ids[s_] = cur
-        tokens_verified = bool(np.array_equal(np.asarray(dev_ids, dtype=np.int64)[:, :B], host_ids))
-        assert tokens_verified, "rwkv_decode_greedy ids differ from rwkv_infer + host arg-max"
-
+    tokens_verified = verify_decode(rt, eng, first, args.verify_steps) if rank == 0 and args.verify_steps > 0 else None
     ab = R.algorithmic_bytes(info, shapes, ql, qt, B)
     step_frac = ab["per_step"] * (args.steps / dt) / HBM_PEAK
-
-    # ---- roofline of the dominant kernel (the layer GEMMs): per-launch hipEvent timing on the engine stream
-    roof = None
-    if rank == 0:
-        inp_tokens = [[int(first[b])] for b in range(B)]
-        fam_ms = {}
-        nprof = 5
-        for it in range(nprof + 1):
-            inp = rt.RnnInput([rt.RnnInputBatch(list(inp_tokens[b]) if b < B else [], rt.RnnOption.Last)
-                               for b in range(eng.max_batch)])
-            _, _, fam = eng.profile_infer(inp)
-            if it == 0:
-                continue        # first pass warms caches / clocks
-            for k, (ms, n) in fam.items():
-                a = fam_ms.setdefault(k, [0.0, 0])
-                a[0] += ms
-                a[1] += n
-        g_ms, g_n = fam_ms["gemm_layers"]
-        h_ms, h_n = fam_ms["gemm_head"]
-        head_bytes = V * info.num_emb * 2
-        vec_bytes = sum(int(np.prod(s)) * 2 for k, s in shapes.items() if len([d for d in s if d > 1]) <= 1)
-        layer_gemm_bytes = eng.weight_bytes - head_bytes - vec_bytes          # weights the layer GEMM launches stream
-        # The event pair around a launch adds marker processing (about 2 us) to what it brackets: the pairs of a step sum to more
-        # than the step itself takes.  Calibration: the excess over the graph-replayed step (`ms_per_step`, the timed region
-        # above), spread evenly over the launches, is subtracted from every launch — rocprofv3's kernel durations tile the step
-        # the same way (profiles/*_kernel_stats_*.csv: their sum equals the step), so the calibrated averages agree with them.
-        n_launch = sum(v[1] for v in fam_ms.values()) / nprof
-        pairs_ms = sum(v[0] for v in fam_ms.values()) / nprof
-        marker_us = max(0.0, (pairs_ms - ms_per_step) / n_launch * 1e3)
-        g_step_ms = g_ms / nprof - marker_us * 1e-3 * (g_n / nprof)           # layer-GEMM family time inside one step
-        achieved = layer_gemm_bytes / (g_step_ms * 1e-3)
-        # HBM traffic per launch from the PMC passes (scripts/collect_pmc.py on the same workload; committed under
-        # profiles/).  Not collectable inside this process: counters need rocprofv3 around the run.
-        traffic, traffic_src = None, None
-        import glob
-        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                               f"*_pmc_traffic_{args.workload}_{args.quant}_b{B}.json"))):
-            try:
-                traffic = json.load(open(f))["layer_gemm"]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/" + os.path.basename(f)
-            except Exception:
-                pass
-        roof = {"bound": "hbm", "kernel": "gemm_kernel (layer projections)", "achieved": achieved / 1e9,
-                "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": layer_gemm_bytes / max(1, g_n // nprof),
-                "launches_per_step": g_n // nprof, "avg_launch_us": g_step_ms / (g_n / nprof) * 1e3,
-                "avg_launch_us_raw_event_pairs": g_ms / g_n * 1e3, "event_pair_overhead_us": marker_us,
-                "bytes_per_step": layer_gemm_bytes,
-                "head_gemm_GBps": head_bytes / max(1e-9, (h_ms / nprof - marker_us * 1e-3 * (h_n / nprof)) * 1e-3) / 1e9,
-                "family_ms_per_step": {k: v[0] / nprof - marker_us * 1e-3 * (v[1] / nprof) for k, v in fam_ms.items()},
-                "step": {"bytes": ab["per_step"], "frac_of_peak": step_frac, "W_q": ab["W_q"], "S": ab["S"]}}
+    single = rank == 0 and world == 1
+    roof = roofline_leg(rt, R, eng, info, shapes, first, ms_per_step, args.workload, args.quant, step_frac, ab) if rank == 0 else None
 
     sweep = {}
-    if rank == 0 and args.sweep:
+    if single and args.sweep:
         for nb in [int(x) for x in args.sweep.split(",") if x]:
             if nb > eng.max_batch:
                 continue
-            d2, _, _ = timed(nb, args.steps, min(args.warmup, 10)) if dist is None else (None, None, None)
-            if d2:
-                abn = R.algorithmic_bytes(info, shapes, ql, qt, nb)
-                sweep[str(nb)] = {"tokens_per_s": nb * args.steps / d2, "ms_per_step": d2 * 1e3 / args.steps,
-                                  "frac_of_peak": abn["per_step"] * (args.steps / d2) / HBM_PEAK}
+            d2, _, _ = decode_point(job, eng, first[:nb], args.steps, min(args.warmup, 10))
+            abn = R.algorithmic_bytes(info, shapes, ql, qt, nb)
+            sweep[str(nb)] = {"tokens_per_s": nb * args.steps / d2, "ms_per_step": d2 * 1e3 / args.steps,
+                              "frac_of_peak": abn["per_step"] * (args.steps / d2) / HBM_PEAK}
 
     # PCIe-inclusive rate through rwkv_infer (logits of every slot D2H every token, as run.rs:809-832 receives them) — never
-    # `value`.  Tight loops (runtime.serve_loop_*): one ABI call per step, nothing else on the host.
-    pcie = None
-    if rank == 0 and world == 1 and not args.decode_only:
+    # `value`; and the serving path with the on-device sampling front-end (rwkv_infer_sample: 8 bytes per slot over PCIe)
+    pcie = sampled = emb = None
+    if single and not args.decode_only:
         nst = max(5, min(40, args.steps))
         pcie = B * nst / eng.serve_loop_logits(first, nst)
-
-    # serving path with the on-device sampling front-end (rwkv_infer_sample: nucleus defaults, 8 bytes/slot over PCIe)
-    sampled = None
-    if rank == 0 and world == 1 and V <= 65536 and not args.decode_only:
-        nst = max(5, min(40, args.steps))
-        sampled = B * nst / eng.serve_loop_sample(first, nst)
-
-    # second half of BASELINE's metric: embeddings/s = documents prefilled (256 tokens each, one per slot) and read
-    # back as one layer's WKV rows (rwkv_state_back_layer) per second, same engine, rank 0 only
-    emb = None
-    if rank == 0 and world == 1 and not args.decode_only:
-        doc_len, layer = 256, info.num_layer - 1
-        docs = [[t % V for t in R.synth_prompt(100 + b, doc_len)] for b in range(B)]
-
-        def embed_rate(e):
-            zero = e.state.init()
-            best = None
-            for rep in range(3):
-                for b in range(B):
-                    e.state.load(zero, b)
-                t = time.perf_counter()
-                inp = rt.RnnInput([rt.RnnInputBatch(list(docs[b]) if b < B else [], rt.RnnOption.NoOutput)   # state-only: no head GEMM, no logits
-                                   for b in range(e.max_batch)])
-                while inp.num_token() > 0:
-                    inp, _ = e.infer(inp)
-                vecs = [e.state.embed(layer, b) for b in range(B)]
-                dt_e = time.perf_counter() - t
-                best = dt_e if best is None else min(best, dt_e)
-            return best
-
-        best = embed_rate(eng)
-        emb = {"value": B / best, "unit": "embeddings/s", "doc_tokens": doc_len, "docs": B,
-               "prefill_tokens_per_s": B * doc_len / best, "token_chunk_size": eng.token_chunk_size,
-               "embedding": f"layer {layer} WKV rows [64 x {info.num_emb}] via rwkv_state_back_layer"}
+        if V <= 65536:
+            sampled = B * nst / eng.serve_loop_sample(first, nst)
+        emb = embed_leg(rt, R, eng, info, B)
         # the same job at SURVEY config #4's token_chunk_size (256 tokens per rwkv_infer call): a second engine over the same
         # checkpoint, since the chunk is a load-time parameter (ReloadRequest::token_chunk_size, lib.rs:221-223)
-        e256 = (rt.ModelBuilder(st, adapter=local_rank).quant(ql, rt.Quant(qt))
-                .build(max_batch=max(B, 1), token_chunk_size=256,
-                       precision=rt.Precision.Fp32 if args.precision == "fp32" else rt.Precision.Fp16))
-        b256 = embed_rate(e256)
+        e256 = build_engine(rt, st, job.local_rank, ql, qt, B, 256, args.precision)
+        e = embed_leg(rt, R, e256, info, B)
         e256.close()
-        emb["at_token_chunk_size_256"] = {"value": B / b256, "prefill_tokens_per_s": B * doc_len / b256}
+        # chunking is exact for an RNN up to the summation order of the GEMM that a chunk size selects
+        assert abs(e["checksum"] - emb["checksum"]) <= 2e-3 * abs(emb["checksum"]), "embeddings depend on token_chunk_size"
+        emb["at_token_chunk_size_256"] = {"value": e["value"], "prefill_tokens_per_s": e["prefill_tokens_per_s"],
+                                          "embeddings_verified": e["embeddings_verified"]}
+    eng.close()
     del st
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.decode_only:
-        # CPU leg ("port"): the SAME configuration on the host cores — the same slots in lock step, the same (fake-)quantised fp16
-        # weight values the GPU dequantises to — through the compiled restatement oracle/cpu_backend.c (C + OpenMP: threaded fp16
-        # GEMM with fp32 accumulation; tests/test_oracle.py holds it against the numpy restatement; numpy itself if it cannot be built).
-        # It is a baseline to stand next to the GPU number, never the target.
-        cur = [int(x) for x in first]
-        try:
-            from oracle.cpu_backend import CpuBackend
-            ref = CpuBackend(tensors, ql, qt)
-            how = (f"C/OpenMP restatement (oracle/cpu_backend.c), fp16 weights ({'fake-quantised ' + args.quant if qt else 'unquantised'}), "
-                   f"fp32 accumulate, {ref.threads} threads")
-            cores = ref.threads
-        except (NotImplementedError, OSError, subprocess.CalledProcessError):
-            ref = R.RwkvRefBatch(tensors)
-            how, cores = "numpy/BLAS fp32 oracle on all host cores, weights fp16-rounded (unquantised on the CPU side)", os.cpu_count()
-        st_cpu = ref.init_states(B)
-        ref.step(cur, st_cpu, want_logits=False)       # warm
-        n_step, t1 = 0, time.time()
-        while time.time() - t1 < 12.0 and n_step < 256:
-            lg = ref.step(cur, st_cpu)
-            cur = [int(x) for x in np.argmax(lg, axis=1)]
-            n_step += 1
-        cdt = time.time() - t1
-        cpu = {"value": B * n_step / cdt, "unit": "tokens/s", "cores": cores, "kind": "port",
-               "sample": f"{n_step} lock-step decode steps of {B} slots ({B * n_step} tokens), {how}, {args.workload}"}
-        del ref, st_cpu
-        # BASELINE config #1: RWKV-V5-World-0.4B fp16, batch 1, greedy, on the CPU path (the reference has no CPU backend,
-        # lib.rs:339-368; this is the port)
-        try:
-            _, t5 = R.synth_st("v5-0.4b", fast=True)
-            try:
-                r5 = CpuBackend(t5)
-            except (NameError, NotImplementedError, OSError, subprocess.CalledProcessError):
-                r5 = R.RwkvRefBatch(t5)
-            s5 = r5.init_states(1)
-            lg = r5.step([int(first[0]) % r5.info.num_vocab], s5)
-            n5, t1 = 0, time.time()
-            while time.time() - t1 < 5.0 and n5 < 1024:
-                lg = r5.step([int(np.argmax(lg[0]))], s5)
-                n5 += 1
-            cpu["config1_v5_0.4b_b1_tokens_per_s"] = n5 / (time.time() - t1)
-            del r5, t5
-        except MemoryError:
-            pass
-    eng.close()
+    if single and not args.no_cpu_baseline and not args.decode_only:
+        cpu = cpu_leg(R, tensors, ql, qt, first, args.workload, args.quant)
+    del tensors
 
-    # BASELINE config #5 (optional leg): RWKV-V6-World-7B fp16, batch 8, 4096-token prompts (token_chunk_size 2048: one 2048-row
-    # step per call), then streamed decode.  Prefill is bounded by the MFMA rate: algorithmic flops = 2 * (params - embedding) per
-    # token against the 2.5 PFLOP/s dense fp16 peak; decode by HBM as above.
-    cfg5 = None
-    if rank == 0 and world == 1 and args.config5:
-        st7, t7 = R.synth_st("v6-7b", fast=True)
-        i7 = R.model_info(t7)
-        sh7 = {k: v.shape for k, v in t7.items()}
-        flops_tok = 2.0 * sum(int(np.prod(v)) for k, v in sh7.items() if k != "emb.weight")
-        e7 = rt.ModelBuilder(st7, adapter=local_rank).build(max_batch=8, token_chunk_size=2048, precision=rt.Precision.Fp16)
-        e7b = rt.ModelBuilder(st7, adapter=local_rank).build(max_batch=8, token_chunk_size=1024, precision=rt.Precision.Fp16)   # SURVEY's chunk for config #5
-        del st7, t7
-        docs = [[t % i7.num_vocab for t in R.synth_prompt(500 + b, 4096)] for b in range(8)]
-        best = None
-        for rep in range(2):
-            z = e7.state.init()
-            for b in range(8):
-                e7.state.load(z, b)
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            inp = rt.RnnInput([rt.RnnInputBatch(list(docs[b]), rt.RnnOption.Last) for b in range(8)])
-            calls = 0
-            while inp.num_token() > 0:
-                inp, outs = e7.infer(inp)
-                calls += 1
-            dt7 = time.perf_counter() - t
-            best = dt7 if best is None else min(best, dt7)
-        def prefill7(e):
-            bst = None
-            for rep in range(2):
-                z = e.state.init()
-                for b in range(8):
-                    e.state.load(z, b)
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                inp = rt.RnnInput([rt.RnnInputBatch(list(docs[b]), rt.RnnOption.Last) for b in range(8)])
-                while inp.num_token() > 0:
-                    inp, _ = e.infer(inp)
-                d = time.perf_counter() - t
-                bst = d if bst is None else min(bst, d)
-            return bst
-        f7 = np.array([int(np.argmax(outs[b][-1])) for b in range(8)], dtype=np.uint32)
-        e7.decode_greedy(f7, 8)
-        _, dms = e7.decode_greedy(f7, 256)
-        ab7 = R.algorithmic_bytes(i7, sh7, 0, 0, 8)
-        cfg5 = {"workload": "RWKV-v6-7b fp16, batch 8, 4096-token prompts, token_chunk_size 2048, then 256 decode steps",
-                "prefill_tokens_per_s": 8 * 4096 / best, "prefill_s": best, "infer_calls": calls,
-                "prefill_TFLOPs": 8 * 4096 * flops_tok / best / 1e12, "prefill_frac_of_mfma_peak": 8 * 4096 * flops_tok / best / 2.5e15,
-                "decode_tokens_per_s": 8 * 256 / (dms * 1e-3), "decode_ms_per_step": dms / 256,
-                "decode_frac_of_hbm_peak": ab7["per_step"] / (dms / 256 * 1e-3) / HBM_PEAK}
-        e7.close()
-        cfg5["prefill_tokens_per_s_at_token_chunk_size_1024"] = 8 * 4096 / prefill7(e7b)
-        e7b.close()
+    configs = None
+    if single and not args.no_configs and not args.decode_only:
+        vs, cs = args.verify_steps, min(args.steps, 50)
+        configs = {}
+        for key, kw in [("config2_v6-1.6b_fp16", dict(name="v6-1.6b", quant="none", batches=[1])),
+                        ("v6-3b_fp16", dict(name="v6-3b", quant="none", batches=[1, 32])),
+                        ("config4_v7-2.9b_nf4", dict(name="v7-2.9b", quant="nf4", batches=[1, 32], embed_chunk=256)),
+                        ("config5_v6-7b_fp16", dict(name="v6-7b", quant="none", batches=[8], prefill=(4096, [2048, 1024])))]:
+            configs[key] = config_leg(job, rt, R, steps=cs, verify_steps=vs, **kw)
 
     if rank == 0:
         line = {"metric": "decode tokens/sec (whole job)", "value": value, "unit": "tokens/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": {"none": "f16", "int8": "u8->f16", "nf4": "nf4->f16"}[args.quant] + "/f32acc",
-                "data": "synthetic",
+                "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.quant] + "/f32acc", "data": "synthetic",
                 "config": {"workload": f"RWKV-{args.workload} {args.quant} decode, batch={B}/GPU, greedy, state+tokens resident in HBM",
                            "quant": args.quant, "batch_per_gpu": B, "precision": args.precision,
                            "parallelism": f"replicas x{world} (no collective)"},
-                "tokens_per_s_per_gpu": value / world, "device_ms_per_step": dev_ms / args.steps,
-                "roofline": roof, "cpu_baseline": cpu, "embeddings": emb, "pcie_inclusive_tokens_per_s": pcie, "on_device_sampling_tokens_per_s": sampled, "sweep": sweep or None, "tokens_verified": tokens_verified, "config5": cfg5,
-                "load_s": t_load, "synth_s": t_synth}
+                "tokens_per_s_per_gpu": value / world, "per_rank_tokens_per_s": [B * args.steps / d for d in dt_all],
+                "device_ms_per_step": dev_ms / args.steps,
+                "roofline": roof, "cpu_baseline": cpu, "embeddings": emb, "pcie_inclusive_tokens_per_s": pcie,
+                "on_device_sampling_tokens_per_s": sampled, "sweep": sweep or None, "tokens_verified": tokens_verified,
+                "configs": configs, "load_s": t_load, "synth_s": t_synth}
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    job.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

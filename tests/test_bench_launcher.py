@@ -1,0 +1,59 @@
+"""`bench.py --gpus N` must really run N ranks (replicas only, one process per GPU, gloo barrier + MAX of the
+timing on the host).  CPU: the launcher, rendezvous, barrier, reduction and the JSON line with a stand-in workload
+(`--selftest-dist`), started both ways the driver may start it.  GPU (-m gpu): the real bench as two ranks sharing the
+one device of the test box (`BENCH_SHARE_GPU=1`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def last_json(out: str) -> dict:
+    return json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
+
+
+def test_gpus_2_without_a_launcher_spawns_two_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "10", "--selftest-dist"], env=clean_env(),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and len(d["per_rank_tokens_per_s"]) == 2
+    # MAX over ranks: rank 1 sleeps twice as long, so the aggregate is priced at the slower rank's time
+    assert d["per_rank_tokens_per_s"][1] < d["per_rank_tokens_per_s"][0]
+    assert abs(d["value"] - 2 * min(d["per_rank_tokens_per_s"])) <= 1e-6 * d["value"]
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1          # ONE line, from rank 0
+
+
+def test_under_torch_distributed_run_as_the_driver_launches_it():
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29631", BENCH, "--gpus", "2", "--steps", "10", "--selftest-dist"], env=clean_env(),
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert last_json(r.stdout)["n_gpus"] == 2
+
+
+def test_world_size_and_gpus_flag_must_agree():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-dist"], env=clean_env(WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_real_bench_as_two_ranks_on_one_device():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "10", "--warmup", "3", "--decode-only", "--sweep", "", "--verify-steps", "4"],
+                       env=clean_env(BENCH_SHARE_GPU="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and len(d["per_rank_tokens_per_s"]) == 2 and d["tokens_verified"] is True
+    assert d["value"] > 0 and d["config"]["parallelism"].startswith("replicas x2")
