@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librwkv_hip.so")
 SOURCES = ["rwkv_kernels.hip", "rwkv_engine.cpp", "tokenizer.cpp"]
-DEPS = SOURCES + ["rwkv_kernels.h", "safetensors.hpp", os.path.join("..", "..", "include", "rwkv_abi.h"),
+DEPS = SOURCES + ["rwkv_kernels.h", "safetensors.hpp", "rwkv_abi.map", os.path.join("..", "..", "include", "rwkv_abi.h"),
                os.path.join("..", "..", "include", "rwkv_runtime.hpp"), os.path.join("..", "..", "include", "rwkv_scheduler.hpp"),
                os.path.join("..", "..", "include", "rwkv_router.hpp"),
                os.path.join("..", "..", "harness", "decode_loop.cpp"), os.path.join("..", "..", "harness", "serve_loop.cpp"),
@@ -76,7 +76,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(run, jobs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "rwkv_abi.map"), "-o", LIB] + objs
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

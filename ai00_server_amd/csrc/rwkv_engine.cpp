@@ -295,6 +295,7 @@ struct rwkv_engine {
     std::map<int, hipGraphExec_t> greedy_graphs;               // rwkv_decode_greedy: step + arg-max feedback, keyed by slot count
     std::set<uint64_t> graph_seen;
     bool use_graphs = true;
+    Knobs kn;                                                    // experiment switches, frozen at creation (rwkv_kernels.h)
 
     template <class T>
     T *dalloc(size_t n) {
@@ -461,6 +462,8 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
     const int L = info.num_layer, C = info.num_emb, F = info.num_hidden, V = info.num_vocab, H = info.num_head;
     max_batch = d.max_batch > 0 ? d.max_batch : 8;
     chunk = d.token_chunk_size > 0 ? d.token_chunk_size : 128;
+    kn = Knobs::from_env();                                  // frozen for the engine's lifetime (and for every graph it captures)
+    use_knobs(kn);
     hilo = d.precision == RWKV_PRECISION_FP32;
     quant_layers = std::max(0, std::min(d.quant_layers, L));
     quant_type = d.quant_type;
@@ -764,10 +767,6 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
 // ------------------------------------------------------------------------------------------------
 // GEMM planning: choose the K split per problem, the X chunk and launch
 // ------------------------------------------------------------------------------------------------
-static int env_int(const char *name) {
-    const char *v = std::getenv(name);
-    return v ? std::atoi(v) : 0;
-}
 
 // Decomposition of one launch (DESIGN.md "GEMM planning"): every wave owns KW = KSW*32 k of the block's K range;
 // linear ("partial") problems may split K across `ksb` blocks (the consumer row kernel sums the partials);
@@ -780,7 +779,7 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
     int NT, KSW;
     gemm_variant(T, hilo, NT, KSW);
     const int KW = KSW * 32;
-    static const int f_spb = env_int("RWKV_SPB"), f_ksb = env_int("RWKV_KSB");
+    const int f_spb = knobs().spb, f_ksb = knobs().ksb;
     long total_strips = 0;
     for (auto &s : ps) total_strips += s.W->rows / 16;
     int blocks = 0, np = 1, max_nw = 1, lds_items = 1;
@@ -849,7 +848,7 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
 // Fp16 mode whose every problem walks K = C with one slice per wave and the same wave count (the prologue is a
 // block-wide cooperative pass), with room in LDS for the rows.
 bool rwkv_engine::ln_fusable(std::vector<ProbSpec> &ps, int T, int np) {
-    static const int off = env_int("RWKV_NO_LN_FUSE");
+    const int off = kn.no_ln_fuse;
     if (off || hilo || T > LNP_MAX_T || np > LNP_MAX_NP) return false;
     int NT, KSW;
     gemm_variant(T, hilo, NT, KSW);
@@ -868,7 +867,7 @@ bool rwkv_engine::ln_fusable(std::vector<ProbSpec> &ps, int T, int np) {
 
 int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs *lnp, const ShiftCommit *commit) {
     GemmLaunch Lh;
-    static const int no_tile = env_int("RWKV_NO_TILE");
+    const int no_tile = kn.no_tile;
     if (T >= GEMM_TILE_MIN_T && !no_tile) {
         // prefill: LDS-tiled MFMA GEMM, no K split (partial problems write one slab)
         if (ps.empty() || ps.size() > GEMM_MAXP) throw RwkvError(RWKV_ERR_INVALID, "gemm: bad problem count");
@@ -878,8 +877,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         // 64x64 tiles measured best everywhere (tile_bench): with 256-k chunks while the launch is latency-bound
         // (few blocks: one L2 round trip per chunk dominates), with 128-k chunks (more blocks per CU) once it is
         // throughput-bound.  RWKV_TILE_SHAPE overrides (0..10) for experiments.
-        const char *ev_shape = std::getenv("RWKV_TILE_SHAPE");     // read per call: the parity tests force every shape in one process
-        const int f_shape = (ev_shape && *ev_shape) ? std::atoi(ev_shape) : -1;
+        const int f_shape = kn.tile_shape;                          // the parity tests force every shape (one engine per shape)
         long tot64 = 0;
         for (auto &s : ps) tot64 += gemm_tile_blocks(3, s.W->rows, T);
         int shape = tot64 <= 1536 ? 4 : 3;
@@ -900,8 +898,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         {
             long t3 = 0;
             for (auto &sp : ps) { t3 += gemm_tile_blocks(GEMM_TILE3, sp.W->rows, T); ok3 = ok3 && gemm_tile3_supported(hilo, sp.W->K); }
-            const char *ev_fill = std::getenv("RWKV_TILE3_FILL");
-            const long fill_min = (ev_fill && *ev_fill) ? std::atol(ev_fill) : 65;
+            const long fill_min = kn.tile3_fill;
             const long rounds = (t3 + 511) / 512;
             if (ok3 && fill_min > 0 && t3 >= 400 && t3 * 100 >= fill_min * rounds * 512) shape = GEMM_TILE3;
         }
@@ -920,7 +917,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
             g.out_hi = s.oh.hi; g.out_lo = s.oh.lo; g.ldh = s.oh.ld;
         }
         Lh.total_blocks = blocks;
-        { const char *ev = std::getenv("RWKV_TILE_XCD"); Lh.xcd_map = (ev && *ev) ? std::atoi(ev) : 1; }   // A/B switch, read per call
+        Lh.xcd_map = kn.tile_xcd;                                   // A/B switch
         launch(fam, [&] { launch_gemm_tile(Lh, shape, hilo, s_main); });
         return 1;
     }
@@ -997,7 +994,7 @@ void rwkv_engine::plan_step(const rwkv_slot_input *in, StepPlan &pl) {
     pl.T = (int)pl.token.size();
     pl.n_seq = (int)pl.seq_slot.size();
     pl.n_out = (int)pl.out_rows.size();
-    static const int no_dense = std::getenv("RWKV_NO_DENSE") ? std::atoi(std::getenv("RWKV_NO_DENSE")) : 0;   // A/B switch
+    const int no_dense = kn.no_dense;                           // A/B switch
     pl.dense = !no_dense && pl.T > 0 && pl.n_seq == pl.T && pl.n_out == pl.T;
     for (int i = 0; i < pl.n_seq && pl.dense; ++i) pl.dense = pl.seq_slot[i] == i;
     pl.id = ++plan_counter;
@@ -1092,10 +1089,10 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
         } else if (info.version == 6) {
             a.mode = 1; a.nmix = 1; a.mu[0] = w.mu[0]; a.ohi[0] = opA[0].hi; a.olo[0] = opA[0].lo;
             a.xx_out = xx; a.dx_out = dx;
-            static const int no_fuse = env_int("RWKV_NO_V6_FUSE"), no_ln_fuse = env_int("RWKV_NO_LN_FUSE");
+            const int no_fuse = kn.no_v6_fuse, no_ln_fuse = kn.no_ln_fuse;
             att_fused = !no_fuse && !no_ln_fuse && v6_mix_ln_supported(T, C, Dm, hilo, np);
             if (!att_fused) launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
-            static const int no_wide = env_int("RWKV_NO_V6_WIDE");     // A/B: two tile-GEMM launches instead of the wide fused form
+            const int no_wide = kn.no_v6_wide;                      // A/B: two tile-GEMM launches instead of the wide fused form
             if ((v6_mix_supported(T, C, Dm) || (v6_mix_wide_supported(T, C, Dm) && !no_wide)) && !no_fuse) {
                 // fused: x_c = xx + dx * (mu_c + W2_c tanh(W1_c z)) in one launch
                 V6MixArgs m{};
@@ -1472,6 +1469,7 @@ rwkv_status rwkv_engine_info(const rwkv_engine *e, rwkv_model_info *out) {
 }
 int32_t rwkv_engine_device(const rwkv_engine *e) { return e ? e->device : -1; }
 int32_t rwkv_engine_max_batch(const rwkv_engine *e) { return e ? e->max_batch : 0; }
+int32_t rwkv_engine_token_chunk_size(const rwkv_engine *e) { return e ? e->chunk : 0; }
 uint64_t rwkv_engine_weight_bytes(const rwkv_engine *e) { return e ? e->weight_bytes : 0; }
 
 rwkv_status rwkv_host_alloc(size_t bytes, void **out) {
@@ -1487,6 +1485,7 @@ void rwkv_host_free(void *p) { if (p) (void)hipHostFree(p); }
 rwkv_status rwkv_infer(rwkv_engine *e, const rwkv_slot_input *in, rwkv_slot_output *out) {
     return guard([&] {
         if (!e || !in || !out) throw RwkvError(RWKV_ERR_INVALID, "null argument");
+        use_knobs(e->kn);
         e->infer(in, out);
     });
 }
@@ -1495,6 +1494,7 @@ rwkv_status rwkv_infer_sample(rwkv_engine *e, const rwkv_slot_input *in, const r
                               float *out_probs, uint8_t *emitted, size_t *n_consumed) {
     return guard([&] {
         if (!e || !in || !sp || !out_tokens || !emitted) throw RwkvError(RWKV_ERR_INVALID, "null argument");
+        use_knobs(e->kn);
         e->infer_sample(in, sp, out_tokens, out_probs, emitted, n_consumed);
     });
 }
@@ -1514,6 +1514,7 @@ const char *rwkv_profile_family_name(int32_t f) { return f >= 0 && f < RWKV_PROF
 rwkv_status rwkv_profile_infer(rwkv_engine *e, const rwkv_slot_input *in, rwkv_slot_output *out, float *ms, int32_t *launches) {
     return guard([&] {
         if (!e || !in || !out || !ms) throw RwkvError(RWKV_ERR_INVALID, "null argument");
+        use_knobs(e->kn);
         std::fill(e->prof_ms, e->prof_ms + RWKV_PROFILE_FAMILIES, 0.f);
         std::fill(e->prof_n, e->prof_n + RWKV_PROFILE_FAMILIES, 0);
         e->profiling = true;
@@ -1684,6 +1685,7 @@ rwkv_status rwkv_decode_greedy(rwkv_engine *e, int32_t n_slots, const uint32_t *
         if (!e || !first_tokens || !out_tokens || n_slots <= 0 || n_slots > e->max_batch || n_slots > e->chunk || n_steps <= 0)
             throw RwkvError(RWKV_ERR_INVALID, "bad arguments");
         HIP_CHECK(hipSetDevice(e->device));
+        use_knobs(e->kn);
         StepPlan pl;
         std::vector<rwkv_slot_input> in(e->max_batch);
         std::vector<uint32_t> tk(first_tokens, first_tokens + n_slots);
@@ -1746,6 +1748,7 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
                             int32_t iters, float *us_per_launch, float *lds_kib) {
     return guard([&] {
         if (rows % 16 || K % 256 || T < 1 || nmat < 1 || iters < 1 || iters > 2000) throw RwkvError(RWKV_ERR_INVALID, "bad args");
+        use_knobs(Knobs::from_env());                            // no engine here: the microbenchmark reads the environment per call
         hipStream_t st;
         HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         const size_t wbytes = fmt == W_F16 ? (size_t)rows * K * 2 : fmt == W_INT8 ? (size_t)rows * K : (size_t)rows * K / 2;
@@ -1788,7 +1791,7 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
                     g.xhi = x.hi; g.xlo = x.lo; g.ldx = K; g.ksb = 1; g.block_begin = 0;
                     g.out_f32 = out; g.ldo = rows;
                     Lh.total_blocks = gemm_tile_blocks(shape, rows, T);
-                    { const char *ev = std::getenv("RWKV_TILE_XCD"); Lh.xcd_map = (ev && *ev) ? std::atoi(ev) : 1; }
+                    Lh.xcd_map = knobs().tile_xcd;
                     if (lds_kib) *lds_kib = (float)Lh.total_blocks;
                     launch_gemm_tile(Lh, shape, hilo != 0, st);
                     continue;

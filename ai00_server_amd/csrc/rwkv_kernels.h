@@ -10,6 +10,22 @@ enum WFmt : int { W_F16 = 0, W_INT8 = 1, W_NF4 = 2 };
 enum Act : int { ACT_NONE = 0, ACT_TANH = 1, ACT_SIGMOID = 2, ACT_RELU2 = 3, ACT_SILU = 4, ACT_DECAY7 = 5 };
 enum Post : int { POST_NONE = 0, POST_MUL = 1, POST_MIX = 2 };
 
+// Experiment switches (A/B runs and the parity tests of the non-default paths).  Read from the environment ONCE PER ENGINE, when it
+// is created, and installed for the thread that drives the engine (`use_knobs`): every step of an engine, and every graph it
+// captured, sees the same choices whatever the environment does later.  Defaults are the product.  DESIGN.md 4.1.
+struct Knobs {
+    int spb = 0, ksb = 0;            // RWKV_SPB / RWKV_KSB: strips per block, K split of the decode GEMM planner (0 = planner's choice)
+    int ksw8 = 1;                    // RWKV_KSW8: T <= 16 steps run 256-k waves (ten per block); 0 = 512-k waves (five)
+    int no_ln_fuse = 0;              // RWKV_NO_LN_FUSE: row kernels instead of the LayerNorm prologue on single-token steps
+    int no_v6_fuse = 0, no_v6_wide = 0, v6mix_split = 0;   // RWKV_NO_V6_FUSE / RWKV_NO_V6_WIDE / RWKV_V6MIX_SPLIT
+    int no_tile = 0, tile_shape = -1, tile3_fill = 65, tile_xcd = 1;   // RWKV_NO_TILE / RWKV_TILE_SHAPE / RWKV_TILE3_FILL / RWKV_TILE_XCD
+    int no_dense = 0;                // RWKV_NO_DENSE: general row metadata on dense decode steps
+    int ln_256 = 0;                  // RWKV_LN_256: 256-thread ln_shift everywhere
+    static Knobs from_env();
+};
+const Knobs &knobs();                // the calling thread's current set
+void use_knobs(const Knobs &k);
+
 constexpr int TILE_ROWS = 16;        // output rows per strip (MFMA 16x16x32 M)
 constexpr int KSTEP = 32;            // K per MFMA
 constexpr int GEMM_MAX_WAVES = 10;    // 640-thread blocks: <= 168 VGPRs per lane (KSW = 8 variants)

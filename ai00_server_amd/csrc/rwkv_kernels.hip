@@ -466,6 +466,24 @@ __device__ __forceinline__ void ln_prologue_finish(const LnProArgs &a, int T, co
 }
 __device__ __forceinline__ size_t lnp_op_off(int T, int k, int tl) { return (size_t)((k >> 3) * T + tl) * 8; }   // k multiple of 8
 #if RWKV_PART_ON(0)
+static int knob_env(const char *name, int dflt) {
+    const char *v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : dflt;
+}
+Knobs Knobs::from_env() {
+    Knobs k;
+    k.spb = knob_env("RWKV_SPB", 0); k.ksb = knob_env("RWKV_KSB", 0); k.ksw8 = knob_env("RWKV_KSW8", 1);
+    k.no_ln_fuse = knob_env("RWKV_NO_LN_FUSE", 0); k.no_v6_fuse = knob_env("RWKV_NO_V6_FUSE", 0);
+    k.no_v6_wide = knob_env("RWKV_NO_V6_WIDE", 0); k.v6mix_split = knob_env("RWKV_V6MIX_SPLIT", 0);
+    k.no_tile = knob_env("RWKV_NO_TILE", 0); k.tile_shape = knob_env("RWKV_TILE_SHAPE", -1);
+    k.tile3_fill = knob_env("RWKV_TILE3_FILL", 65); k.tile_xcd = knob_env("RWKV_TILE_XCD", 1);
+    k.no_dense = knob_env("RWKV_NO_DENSE", 0); k.ln_256 = knob_env("RWKV_LN_256", 0);
+    return k;
+}
+static thread_local Knobs t_knobs;
+const Knobs &knobs() { return t_knobs; }
+void use_knobs(const Knobs &k) { t_knobs = k; }
+
 size_t lnp_lds_bytes(int T, int C, bool hilo) { return (size_t)(2 * T * (C + LNP_PAD) + 64) * 4 + (size_t)T * C * 2 * (hilo ? 2 : 1); }
 #endif
 
@@ -737,7 +755,11 @@ __global__ __launch_bounds__(((KSW == 16 || NT == 4) ? GEMM_MAX_WAVES_K16 : GEMM
 int gemm_variant_max_waves(int NT, int KSW) { return (KSW == 16 || NT == 4) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES; }
 
 void gemm_variant(int T, bool hilo, int &NT, int &KSW) {
-    static const int ksw8 = std::getenv("RWKV_KSW8") ? std::atoi(std::getenv("RWKV_KSW8")) : 0;
+    // T <= 16: ten waves of 256 k per block rather than five of 512 k — a wave's loads return in order and what a CU can pull from
+    // HBM grows with its waves, not with the loads each keeps in flight (profiles/r3_exp_stream_waves_x_loads.log: 27 MB over 256
+    // workgroups: 5 waves 8.6-10.8 us, 10 waves 6.9-8.0, 16 waves 6.8-7.1 whatever the depth); on the real launches 9.09 -> 8.85 us
+    // (r/k/v/g Int8, T = 1), one-slot step 1.707 -> 1.696 ms, eight slots 1.851 -> 1.827.  Knobs::ksw8 = 0 restores 512-k waves.
+    const int ksw8 = knobs().ksw8;
     if (hilo) { NT = 1; KSW = 8; }
     else if (T <= 16) { NT = 1; KSW = ksw8 ? 8 : 16; }
     else if (T <= 32) { NT = 2; KSW = 8; }
@@ -1000,10 +1022,11 @@ bool v6_mix_wide_supported(int T, int C, int Dm) { return T > 32 && C % 256 == 0
 
 void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
     const bool wide = a.T > 32;                                // v6_mix_wide_supported: one block per (mix, 32-token tile)
-    // 17..32 rows: two 16-token tiles of NT = 1 blocks (200 workgroups, each pulling W1_c + HALF of z) instead of 100 NT = 2
-    // blocks that each pull W1_c + all of z — phase 1 is bound by what a CU can ingest.  RWKV_V6MIX_NT2=1: the old form.
-    static const int nt2 = std::getenv("RWKV_V6MIX_NT2") ? std::atoi(std::getenv("RWKV_V6MIX_NT2")) : 0;
-    const bool split_tiles = !wide && a.T > 16 && !nt2 && a.lnp.x_in == nullptr;
+    // (17..32 rows as two NT = 1 token tiles — 200 workgroups that each pull W1_c + half of z — was measured and dropped: every
+    // workgroup still pulls all of W1_c, so the launch's L2 traffic grows by half: 2.250 -> 2.267 ms per 32-slot step,
+    // profiles/r3_exp_ab_v6mix_ksw8.log.  Knobs::v6mix_split selects it.)
+    const int split = knobs().v6mix_split;
+    const bool split_tiles = !wide && a.T > 16 && split && a.lnp.x_in == nullptr;
     const int NT = ((a.T <= 16 && !wide) || split_tiles) ? 1 : 2;
     const bool lnp = a.lnp.x_in != nullptr;                    // host: T <= LNP_MAX_T, !hilo, C <= 4096 (v6_mix_ln_supported)
     const size_t lds = (size_t)8 * 4 * NT * 64 * 16 + (size_t)2 * NT * 16 * (a.Dm + 8) * 2 + (lnp ? lnp_lds_bytes(LNP_MAX_T, a.C, hilo) : 0);
@@ -1718,7 +1741,7 @@ __global__ __launch_bounds__(NTHR) void ln_shift_kernel(const LnShiftArgs a) {
     } while (0)
 
 void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s) {
-    static const int wide_off = std::getenv("RWKV_LN_256") ? std::atoi(std::getenv("RWKV_LN_256")) : 0;   // A/B switch
+    const int wide_off = knobs().ln_256;                         // A/B switch
     if (T <= 64 && !wide_off) {                                   // few rows: 1024 threads per row
         if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<1, 1024>), dim3(T), dim3(1024), 0, s, a);
         else hipLaunchKernelGGL((ln_shift_kernel<2, 1024>), dim3(T), dim3(1024), 0, s, a);

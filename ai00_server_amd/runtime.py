@@ -77,6 +77,7 @@ ABI_SYMBOLS = {
     "rwkv_engine_info": (C.c_int32, [C.c_void_p, C.POINTER(_ModelInfoC)]),
     "rwkv_engine_device": (C.c_int32, [C.c_void_p]),
     "rwkv_engine_max_batch": (C.c_int32, [C.c_void_p]),
+    "rwkv_engine_token_chunk_size": (C.c_int32, [C.c_void_p]),
     "rwkv_engine_weight_bytes": (C.c_uint64, [C.c_void_p]),
     "rwkv_infer": (C.c_int32, [C.c_void_p, C.POINTER(_SlotInC), C.POINTER(_SlotOutC)]),
     "rwkv_host_alloc": (C.c_int32, [C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -335,8 +336,8 @@ class Runtime:
         h = C.c_void_p()
         _check(l.rwkv_engine_create(C.byref(d), C.byref(h)))
         self._h = h
-        self.max_batch = max_batch
-        self.token_chunk_size = token_chunk_size
+        self.max_batch = int(l.rwkv_engine_max_batch(h))
+        self.token_chunk_size = int(l.rwkv_engine_token_chunk_size(h))    # what the engine was really built with
         ic = _ModelInfoC()
         _check(l.rwkv_engine_info(h, C.byref(ic)))
         self.info = _info_from_c(ic)

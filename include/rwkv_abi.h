@@ -24,8 +24,9 @@
 extern "C" {
 #endif
 
-#define RWKV_ABI_VERSION 3   /* 2: rwkv_sample_params gained kind/tau; rwkv_engine_save_prefab
-                              * 3: rwkv_sample_params gained allow (formatter mask); rwkv_host_alloc/free; RWKV_OPTION_NONE */
+#define RWKV_ABI_VERSION 4   /* 2: rwkv_sample_params gained kind/tau; rwkv_engine_save_prefab
+                              * 3: rwkv_sample_params gained allow (formatter mask); rwkv_host_alloc/free; RWKV_OPTION_NONE
+                              * 4: rwkv_engine_token_chunk_size */
 
 typedef int32_t rwkv_status;
 enum {
@@ -97,6 +98,7 @@ rwkv_status rwkv_engine_save_prefab(rwkv_engine *e, const char *path);
 rwkv_status rwkv_engine_info(const rwkv_engine *e, rwkv_model_info *out);
 int32_t rwkv_engine_device(const rwkv_engine *e);               /* HIP device ordinal in use */
 int32_t rwkv_engine_max_batch(const rwkv_engine *e);
+int32_t rwkv_engine_token_chunk_size(const rwkv_engine *e);     /* the load-time `token_chunk_size` (lib.rs:221-223): rows one rwkv_infer call emits at most per Full slot */
 /* bytes of weights resident in HBM at their storage width (fp16 / int8+scales / nf4+absmax),
  * embedding table excluded: the W_q of SURVEY 8(d).  For roofline accounting. */
 uint64_t rwkv_engine_weight_bytes(const rwkv_engine *e);

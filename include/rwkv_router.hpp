@@ -19,6 +19,7 @@
 #include <deque>
 #include <functional>
 #include <mutex>
+#include <string>
 #include <thread>
 
 #include "rwkv_scheduler.hpp"
@@ -34,6 +35,8 @@ struct RoutedRequest {
     std::vector<float> last_output;
     int replica = -1;
     bool done = false;
+    bool failed = false;                          // the replica's engine (or the sample callback) threw while this request was in flight
+    std::string error;                            // what it threw
 };
 
 template <class Engine>
@@ -56,7 +59,7 @@ class ReplicaRouter {
         for (size_t i = 0; i < reps_.size(); ++i) {                      // 1. prefix affinity
             std::lock_guard<std::mutex> g(reps_[i]->mu);
             if (reps_[i]->load() >= reps_[i]->capacity) continue;
-            const size_t len = reps_[i]->sched.cache().match_len(tokens);
+            const size_t len = reps_[i]->sched.match_len(tokens);          // thread-safe probe: never inserts, see Scheduler::match_len
             if (len > best_len) { best_len = len; best = (int)i; }
         }
         if (best >= 0) return {best, best_len};
@@ -73,17 +76,23 @@ class ReplicaRouter {
     // Hand a request to a replica; returns the replica index, or -1 when every replica is full (the caller queues it, as the
     // reference's `enqueue` task does with `SlotResult::Failure`, run.rs:1030-1062).  `req` must outlive its completion.
     int submit(RoutedRequest *req) {
-        const auto where = route(req->tokens);
-        if (where.first < 0) return -1;
-        Replica &r = *reps_[(size_t)where.first];
-        {
-            std::lock_guard<std::mutex> g(r.mu);
-            req->replica = where.first;
-            r.inbox.push_back(req);
-            ++r.inflight;
+        // Any number of threads may submit: the capacity test is repeated under the lock that appends to the inbox, so two callers
+        // racing for the last free slot cannot both get it (the loser re-routes; -1 when nobody has room).
+        for (size_t attempt = 0; attempt <= reps_.size(); ++attempt) {
+            const auto where = route(req->tokens);
+            if (where.first < 0) return -1;
+            Replica &r = *reps_[(size_t)where.first];
+            {
+                std::lock_guard<std::mutex> g(r.mu);
+                if (r.inflight >= r.capacity || r.stop) continue;
+                req->replica = where.first;
+                r.inbox.push_back(req);
+                ++r.inflight;
+            }
+            r.cv.notify_all();
+            return where.first;
         }
-        r.cv.notify_all();
-        return where.first;
+        return -1;
     }
     // Block until every submitted request has completed.
     void drain() {
@@ -113,47 +122,69 @@ class ReplicaRouter {
         // device step over every slot with tokens pending, sample the slots whose prompt / token has been consumed.
         void run() {
             std::vector<RoutedRequest *> owner((size_t)capacity, nullptr);
+            std::deque<RoutedRequest *> parked;                                    // admitted by submit() but no slot yet: retried after a step
             for (;;) {
                 std::deque<RoutedRequest *> fresh;
                 {
                     std::unique_lock<std::mutex> g(mu);
-                    cv.wait(g, [&] { return stop || !inbox.empty() || active(owner); });
-                    if (stop && inbox.empty() && !active(owner)) return;
+                    cv.wait(g, [&] { return stop || !inbox.empty() || !parked.empty() || active(owner); });
+                    if (stop && inbox.empty() && parked.empty() && !active(owner)) return;
                     fresh.swap(inbox);
                 }
-                for (RoutedRequest *rq : fresh) {
-                    int b = -1;
-                    if (sched.queue(rq->tokens, b) == SlotResult::Failure) {     // cannot happen while inflight <= capacity
-                        std::lock_guard<std::mutex> g(mu);
-                        inbox.push_front(rq);
-                        continue;
+                fresh.insert(fresh.begin(), parked.begin(), parked.end());
+                parked.clear();
+                // One replica's failure (a device error, a throwing sample callback, a malformed request) must not take the process
+                // down (an exception leaving a std::thread is std::terminate) nor wedge drain(): everything this replica holds is
+                // failed with the message, its slots are given up, and the thread goes on serving.
+                try {
+                    while (!fresh.empty()) {
+                        RoutedRequest *rq = fresh.front();
+                        int b = -1;
+                        if (sched.queue(rq->tokens, b) == SlotResult::Failure) break;   // every slot busy: park the rest until one frees
+                        fresh.pop_front();
+                        owner[(size_t)b] = rq;
                     }
-                    owner[(size_t)b] = rq;
-                }
-                if (sched.pending()) { sched.step(); ++steps; }
-                for (int b = 0; b < capacity; ++b) {
-                    RoutedRequest *rq = owner[(size_t)b];
-                    if (!rq) continue;
-                    auto &r = sched.request(b);
-                    if (!r.suffix.empty() || r.output.empty()) continue;           // still reading tokens in
-                    if ((int)rq->generated.size() < rq->max_new) {
-                        const uint32_t t = rq->sample ? rq->sample(r.output)
-                                                      : (uint32_t)(std::max_element(r.output.begin(), r.output.end()) - r.output.begin());
-                        rq->generated.push_back(t);
-                        sched.push(b, t);
-                        continue;
+                    parked.swap(fresh);
+                    if (sched.pending()) { sched.step(); ++steps; }
+                    for (int b = 0; b < capacity; ++b) {
+                        RoutedRequest *rq = owner[(size_t)b];
+                        if (!rq) continue;
+                        auto &r = sched.request(b);
+                        if (!r.suffix.empty() || r.output.empty()) continue;           // still reading tokens in
+                        if ((int)rq->generated.size() < rq->max_new) {
+                            const uint32_t t = rq->sample ? rq->sample(r.output)
+                                                          : (uint32_t)(std::max_element(r.output.begin(), r.output.end()) - r.output.begin());
+                            rq->generated.push_back(t);
+                            sched.push(b, t);
+                            continue;
+                        }
+                        rq->last_output = r.output;
+                        sched.finish(b);
+                        owner[(size_t)b] = nullptr;
+                        complete(rq, nullptr);
                     }
-                    rq->last_output = r.output;
-                    sched.finish(b);
-                    owner[(size_t)b] = nullptr;
-                    {
-                        std::lock_guard<std::mutex> g(mu);
-                        rq->done = true;
-                        --inflight;
-                    }
-                    idle_cv.notify_all();
+                } catch (const std::exception &ex) {
+                    fail_all(owner, fresh, parked, ex.what());
+                } catch (...) {
+                    fail_all(owner, fresh, parked, "unknown exception in the replica thread");
                 }
             }
+        }
+        void complete(RoutedRequest *rq, const char *err) {
+            {
+                std::lock_guard<std::mutex> g(mu);
+                if (err) { rq->failed = true; rq->error = err; }
+                rq->done = true;
+                --inflight;
+            }
+            idle_cv.notify_all();
+        }
+        void fail_all(std::vector<RoutedRequest *> &owner, std::deque<RoutedRequest *> &fresh, std::deque<RoutedRequest *> &parked, const char *what) {
+            for (int b = 0; b < capacity; ++b) {
+                sched.abort(b);                                                    // Idle, nothing cached from a step that failed
+                if (owner[(size_t)b]) { complete(owner[(size_t)b], what); owner[(size_t)b] = nullptr; }
+            }
+            for (auto *q : {&fresh, &parked}) { for (RoutedRequest *rq : *q) complete(rq, what); q->clear(); }
         }
         static bool active(const std::vector<RoutedRequest *> &o) { for (auto *p : o) if (p) return true; return false; }
     };

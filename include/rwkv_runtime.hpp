@@ -68,10 +68,10 @@ class State {
 
 class Runtime {
    public:
-    explicit Runtime(rwkv_engine *e, int chunk = 128) : e_(e, rwkv_engine_destroy), state(e) {
+    explicit Runtime(rwkv_engine *e) : e_(e, rwkv_engine_destroy), state(e) {
         check(rwkv_engine_info(e, &info));
         max_batch = rwkv_engine_max_batch(e);
-        token_chunk_size = chunk > 0 ? chunk : 128;
+        token_chunk_size = rwkv_engine_token_chunk_size(e);      // what the engine was built with: sizes the buffers of Full requests
     }
     // runtime.infer(input) -> output; `input` is consumed in place (tokens drained by n_consumed)
     std::vector<RnnOutputBatch> infer(RnnInput &input) {
@@ -141,7 +141,7 @@ class ModelBuilder {
         d_.lora = lora_.empty() ? nullptr : lora_.data(); d_.n_lora = lora_.size();
         rwkv_engine *e = nullptr;
         check(rwkv_engine_create(&d_, &e));
-        return Runtime(e, token_chunk_size);
+        return Runtime(e);
     }
    private:
     rwkv_load_desc d_{};

@@ -224,7 +224,9 @@ class Scheduler {
     };
 
     static constexpr size_t kMinPromptCacheTokens = 32;                          // MIN_PROMPT_CACHE_TOKENS, run.rs:40
-    explicit Scheduler(Engine &e, size_t max_cached = 256) : e_(e), slots_(e.max_batch), reqs_(e.max_batch), max_cached_(max_cached) {}
+    explicit Scheduler(Engine &e, size_t max_cached = 256) : e_(e), slots_(e.max_batch), reqs_(e.max_batch), max_cached_(max_cached) {
+        cache_of(0);                                                               // the default cache exists from the start
+    }
 
     // `check_in_state` (run.rs:376-437): a state-tuned initial state registered under an id gets its OWN prefix cache
     // (`Cache { state: Some(state), cache: Trie::new() }`); requests that name the id start from it instead of the zero state.
@@ -232,6 +234,7 @@ class Scheduler {
     void check_in_state(uint64_t id, std::vector<float> slab) {
         if (id == 0) throw std::invalid_argument("state id 0 is the default state");
         init_states_[id] = std::move(slab);
+        std::lock_guard<std::mutex> g(cache_mu_);
         caches_.erase(id);
     }
 
@@ -262,8 +265,14 @@ class Scheduler {
         // (The reference does this for all three choices, Continue included: run.rs:548-626.)
         // A request that is cached whole starts with an empty suffix and the cached output row: the process loop samples from
         // it without touching the engine (`(0, Some(output)) => output`, run.rs:809-811).
-        PrefixCache &cache = cache_of(state_id);
-        PrefixCache::Checkout co = cache.checkout(tokens, clock_);
+        PrefixCache::Checkout co;
+        bool cached_whole = false;
+        {
+            std::lock_guard<std::mutex> g(cache_mu_);
+            PrefixCache &cache = cache_of(state_id);
+            co = cache.checkout(tokens, clock_);
+            cached_whole = cache.contains(tokens);
+        }
         const size_t len = co.hit ? co.prefix_len : 0;
         if (co.hit) e_.state.load(co.state, batch);
         else if (state_id != 0) e_.state.load(init_states_[state_id], batch);       // `state.unwrap_or_else(|| self.state.init())`, run.rs:476-477
@@ -277,7 +286,7 @@ class Scheduler {
         r.prompt_len = tokens.size();
         // run.rs:794-803: prompts longer than MIN_PROMPT_CACHE_TOKENS that are not cached yet get a cache entry as soon as
         // they have been read in (so a second request with the same long prompt skips its prefill even while this one decodes)
-        r.cache_prompt = tokens.size() > kMinPromptCacheTokens && !cache.contains(tokens);
+        r.cache_prompt = tokens.size() > kMinPromptCacheTokens && !cached_whole;
         reqs_[batch] = std::move(r);
         const bool back = best.kind == SlotChoice::Back;
         slots_[batch].kind = SlotKind::Busy;
@@ -366,14 +375,35 @@ class Scheduler {
         Request &r = reqs_[batch];
         if (!r.suffix.empty()) throw std::logic_error("finish(): tokens still pending");
         ++clock_;
-        if (!r.prefix.empty() && !r.output.empty()) cache_of(r.state_id).insert(r.prefix, e_.state.back(batch), r.output, clock_);
+        if (!r.prefix.empty() && !r.output.empty()) {
+            auto slab = e_.state.back(batch);                                      // device round trip OUTSIDE the cache lock
+            std::lock_guard<std::mutex> g(cache_mu_);
+            cache_of(r.state_id).insert(r.prefix, std::move(slab), r.output, clock_);
+        }
         slots_[batch].kind = SlotKind::Idle;
         slots_[batch].content = r.prefix;
         slots_[batch].since = clock_;
     }
 
+    // give a busy slot up without caching anything (its engine call failed, or the request was cancelled): Idle, no content
+    void abort(int batch) {
+        if (batch < 0 || batch >= (int)slots_.size()) return;
+        reqs_[(size_t)batch] = Request();
+        slots_[(size_t)batch].kind = SlotKind::Idle;
+        slots_[(size_t)batch].content.clear();
+        slots_[(size_t)batch].since = ++clock_;
+    }
+
     const SlotState &slot(int batch) const { return slots_.at((size_t)batch); }
+    // single-threaded access (tests, serve_loop); other threads ask through match_len()
     PrefixCache &cache(uint64_t state_id = 0) { return cache_of(state_id); }
+    // length of the longest cached prefix of `tokens` — the router's affinity query.  Safe from any thread while the scheduler's
+    // own thread runs: never inserts a cache, and every mutation of the tries happens under the same mutex.
+    size_t match_len(const Tokens &tokens, uint64_t state_id = 0) const {
+        std::lock_guard<std::mutex> g(cache_mu_);
+        auto it = caches_.find(state_id);
+        return it == caches_.end() ? 0 : it->second.match_len(tokens);
+    }
 
    private:
     struct Probe {                                // a Full run on one slot that is not part of its request (perplexity)
@@ -424,7 +454,9 @@ class Scheduler {
                 r.output = std::move(lg);
             }
             if (r.cache_prompt && r.suffix.empty() && r.prefix.size() == r.prompt_len && !r.output.empty()) {   // run.rs:829-838
-                cache_of(r.state_id).insert(r.prefix, e_.state.back((int)b), r.output, ++clock_);
+                auto slab = e_.state.back((int)b);
+                std::lock_guard<std::mutex> g(cache_mu_);
+                cache_of(r.state_id).insert(r.prefix, std::move(slab), r.output, ++clock_);
                 r.cache_prompt = false;
             }
         }
@@ -447,6 +479,7 @@ class Scheduler {
         return it->second;
     }
     size_t max_cached_;
+    mutable std::mutex cache_mu_;                    // guards caches_ and the tries inside (held for host work only, never across a device call)
     std::map<uint64_t, PrefixCache> caches_;
     std::map<uint64_t, std::vector<float>> init_states_;
     uint64_t clock_ = 0;

@@ -11,6 +11,7 @@
  *
  * Build: gcc -O3 -mavx2 -mfma -mf16c -fopenmp -shared -fPIC oracle/cpu_backend.c -o oracle/_build/libcpu_backend.so -lm
  */
+#define _GNU_SOURCE
 #include <immintrin.h>
 #include <math.h>
 #include <omp.h>
@@ -41,13 +42,18 @@ typedef struct {
     const CpuLayer *layers;
 } CpuModel;
 
+static void master_enter(void);
+static void master_leave(void);
 #define N_HEAD 64
 #define LN_EPS 1e-5f
 #define GN_EPS 64e-5f   /* GroupNorm eps of the reference models: 1e-5 * head_size_divisor^2 (8^2), as in rwkv_ref.GN_EPS */
 
 /* Y[b][r] = sum_k W[r][k] X[b][k];  W fp16 row-major [rows][K], K % 8 == 0;  slots in groups of 8 so the accumulators stay in registers */
+/* Called by EVERY thread of the step's team (orphaned worksharing loop, implicit barrier at its end): one persistent team per step
+ * instead of a fork per GEMM.  The static schedule over rows is the one rwkv_cpu_place used to first-touch W, so a thread reads the
+ * rows that live on its own NUMA node. */
 static void gemm_f16(const uint16_t *W, long rows, long K, const float *X, long ldx, float *Y, long ldy, int B) {
-#pragma omp parallel for schedule(static) if (rows * K >= 32768)   /* the LoRA matrices are too small to pay for a fork on a 256-thread host */
+#pragma omp for schedule(static)
     for (long r = 0; r < rows; ++r) {
         const uint16_t *w = W + r * K;
         for (int b0 = 0; b0 < B; b0 += 8) {
@@ -101,7 +107,10 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
           *hid = g + (long)B * C, *hid2 = hid + (long)B * big, *mm = hid2 + (long)B * big, *td = mm + (long)B * 5 * (Dm > 0 ? Dm : 1),
           *vfirst = td + (long)B * (Dd > 0 ? Dd : 1), *aa = vfirst + (long)B * C, *kk = aa + (long)B * C, *xa = kk + (long)B * C,
           *lora = xa + (long)B * C;                                   /* [B][maxD] */
-#pragma omp parallel for
+    master_enter();
+#pragma omp parallel
+    {
+#pragma omp for
     for (int b = 0; b < B; ++b) {
         float *xb = x + (long)b * C;
         const uint16_t *e = m->emb + (long)tokens[b] * C;
@@ -111,7 +120,7 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
     for (int l = 0; l < L; ++l) {
         const CpuLayer *p = &m->layers[l];
         /* ---- time mix */
-#pragma omp parallel for
+#pragma omp for
         for (int b = 0; b < B; ++b) {
             float *st = states + (long)b * slab + (long)l * (N + 2) * C;
             layernorm(x + (long)b * C, p->ln1w, p->ln1b, xx + (long)b * C, C, LN_EPS);
@@ -123,7 +132,7 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
             /* x_n = xx + dx * mu_n, n in (r,w,k,v,a,g);  r,k,v projections;  w/a/g/v LoRAs;  kappa = normalised k*k_k per head;
              * k <- k (1 + (a-1) k_a);  v <- v + (v_first - v) sigmoid(v0 + V2 V1 x_v) (layers > 0);  decay = exp(-0.606531 sigmoid(w0 + W2 tanh(W1 x_w)));
              * S <- S diag(decay) + (S (-kappa)) (kappa a)^T + v k^T;  out = S r;  y = GN(out) + (sum_j r_j k_j r_k_j) v;  att = Wo (y g) */
-#pragma omp parallel for
+#pragma omp for
             for (int b = 0; b < B; ++b)
                 for (int c = 0; c < C; ++c) {
                     const long i = (long)b * C + c;
@@ -136,11 +145,13 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
             gemm_f16(p->Wv, C, C, xv, C, v, C, B);
             float *wdec = hid2;
             gemm_f16(p->w1, p->Dw, C, xw, C, lora, p->Dw, B);
+#pragma omp for
             for (long i = 0; i < (long)B * p->Dw; ++i) lora[i] = tanhf(lora[i]);
             gemm_f16(p->w2, C, p->Dw, lora, p->Dw, wdec, C, B);
             gemm_f16(p->a1, p->Da, C, xa, C, lora, p->Da, B);
             gemm_f16(p->a2, C, p->Da, lora, p->Da, aa, C, B);
             gemm_f16(p->g1, p->Dg, C, xg, C, lora, p->Dg, B);
+#pragma omp for
             for (long i = 0; i < (long)B * p->Dg; ++i) lora[i] = sigmoidf(lora[i]);
             gemm_f16(p->g2, C, p->Dg, lora, p->Dg, g, C, B);
             float *vgate = hid;                                      /* [B][C] */
@@ -149,7 +160,7 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
                 gemm_f16(p->v2, C, p->Dv, lora, p->Dv, vgate, C, B);
             }
             float *out = t0;
-#pragma omp parallel for collapse(2)
+#pragma omp for collapse(2)
             for (int b = 0; b < B; ++b)
                 for (int h = 0; h < H; ++h) {
                     const long o = (long)b * C + (long)h * N;
@@ -200,7 +211,7 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
             gemm_f16(p->Wo, C, C, out, C, t1, C, B);
         } else {
         if (m->version == 5) {
-#pragma omp parallel for
+#pragma omp for
             for (int b = 0; b < B; ++b)
                 for (int c = 0; c < C; ++c) {
                     const long i = (long)b * C + c;
@@ -211,19 +222,20 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
                 }
         } else {
             /* z = xx + dx*mix_x;  m = tanh(W1 z) [5*Dm];  x_c = xx + dx*(mix_c + W2_c m_c), c in (w,k,v,r,g) */
-#pragma omp parallel for
+#pragma omp for
             for (int b = 0; b < B; ++b)
                 for (int c = 0; c < C; ++c) {
                     const long i = (long)b * C + c;
                     hid[i] = xx[i] + (sx[i] - xx[i]) * p->mix_x[c];
                 }
             gemm_f16(p->mix_w1, 5L * Dm, C, hid, C, mm, 5L * Dm, B);
+#pragma omp for
             for (long i = 0; i < (long)B * 5 * Dm; ++i) mm[i] = tanhf(mm[i]);
             float *dst[5] = {xw, xk, xv, xr, xg};
             const float *mu[5] = {p->mix_w, p->mix_k, p->mix_v, p->mix_r, p->mix_g};
             for (int c5 = 0; c5 < 5; ++c5) {
                 gemm_f16(p->mix_w2 + (long)c5 * C * Dm, C, Dm, mm + (long)c5 * Dm, 5L * Dm, hid, C, B);
-#pragma omp parallel for
+#pragma omp for
                 for (int b = 0; b < B; ++b)
                     for (int c = 0; c < C; ++c) {
                         const long i = (long)b * C + c;
@@ -237,20 +249,21 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
         gemm_f16(p->Wg, C, C, xg, C, g, C, B);
         float *wdec = hid2;                                         /* [B][C] */
         if (m->version == 5) {
-#pragma omp parallel for
+#pragma omp for
             for (int b = 0; b < B; ++b)
                 for (int c = 0; c < C; ++c) wdec[(long)b * C + c] = expf(-expf(p->decay[c]));
         } else {
             gemm_f16(p->decay_w1, Dd, C, xw, C, td, Dd, B);
+#pragma omp for
             for (long i = 0; i < (long)B * Dd; ++i) td[i] = tanhf(td[i]);
             gemm_f16(p->decay_w2, C, Dd, td, Dd, wdec, C, B);
-#pragma omp parallel for
+#pragma omp for
             for (int b = 0; b < B; ++b)
                 for (int c = 0; c < C; ++c) wdec[(long)b * C + c] = expf(-expf(p->decay[c] + wdec[(long)b * C + c]));
         }
         /* WKV: out_j = sum_i r_i (u_i k_i v_j + S_ij);  S_ij = k_i v_j + w_i S_ij */
         float *out = t0;                                            /* xr is dead */
-#pragma omp parallel for collapse(2)
+#pragma omp for collapse(2)
         for (int b = 0; b < B; ++b)
             for (int h = 0; h < H; ++h) {
                 float *S = states + (long)b * slab + (long)l * (N + 2) * C + (long)C + (long)h * N;   /* row 1, column h*N; row stride C */
@@ -283,7 +296,7 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
         gemm_f16(p->Wo, C, C, out, C, t1, C, B);
         }
         /* ---- channel mix */
-#pragma omp parallel for
+#pragma omp for
         for (int b = 0; b < B; ++b) {
             float *st = states + (long)b * slab + (long)l * (N + 2) * C + (long)(N + 1) * C;
             float *xb = x + (long)b * C;
@@ -305,25 +318,27 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
             }
         }
         gemm_f16(p->Fk, F, C, t2, C, hid, F, B);
-#pragma omp parallel for schedule(static)
+#pragma omp for schedule(static)
         for (long i = 0; i < (long)B * F; ++i) { const float a = hid[i] > 0.f ? hid[i] : 0.f; hid[i] = a * a; }
         gemm_f16(p->Fv, C, F, hid, F, t4, C, B);
         if (m->version == 7) {
-#pragma omp parallel for
+#pragma omp for
             for (int b = 0; b < B; ++b)
                 for (int c = 0; c < C; ++c) x[(long)b * C + c] += t4[(long)b * C + c];
         } else {
             gemm_f16(p->Fr, C, C, t3, C, r, C, B);
-#pragma omp parallel for
+#pragma omp for
             for (int b = 0; b < B; ++b)
                 for (int c = 0; c < C; ++c) x[(long)b * C + c] += sigmoidf(r[(long)b * C + c]) * t4[(long)b * C + c];
         }
     }
     if (logits) {
-#pragma omp parallel for
+#pragma omp for
         for (int b = 0; b < B; ++b) layernorm(x + (long)b * C, m->lnow, m->lnob, xx + (long)b * C, C, LN_EPS);
         gemm_f16(m->head, m->V, C, xx, C, logits, m->V, B);
     }
+    }   /* omp parallel */
+    master_leave();
     free(buf);
     return 0;
 }
@@ -384,6 +399,57 @@ void rwkv_cpu_fake_quant_nf4(uint16_t *w, long rows, long K, const float *mid15,
             }
         }
 }
+/* ---- threads and memory placement (the baseline should be limited by the host's DRAM, not by where its pages happen to live).
+ * rwkv_cpu_pin: team size = n, thread t pinned to logical CPU cpus[t] (the caller passes one CPU per physical core, socket by socket);
+ * libgomp keeps its pool, so the pinning holds for every later parallel region of this process.
+ * rwkv_cpu_place: a copy of a weight matrix whose pages are FIRST TOUCHED by the thread that gemm_f16's static row schedule will hand
+ * those rows to — on a multi-socket host every thread then streams from its own NUMA node.  (numpy had first-touched every page from
+ * one thread: all weights on one node.) */
+#include <sched.h>
+#include <pthread.h>
+static int g_master_cpu = -1;                                      /* the caller's thread is pinned only while it works in the team */
+static cpu_set_t g_master_saved;
+static void master_enter(void) {
+    if (g_master_cpu < 0) return;
+    cpu_set_t set;
+    (void)pthread_getaffinity_np(pthread_self(), sizeof(g_master_saved), &g_master_saved);
+    CPU_ZERO(&set);
+    CPU_SET(g_master_cpu, &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+}
+static void master_leave(void) {
+    if (g_master_cpu >= 0) (void)pthread_setaffinity_np(pthread_self(), sizeof(g_master_saved), &g_master_saved);
+}
+int rwkv_cpu_pin(const int32_t *cpus, int n) {
+    if (n <= 0) return -1;
+    omp_set_dynamic(0);
+    omp_set_num_threads(n);
+    g_master_cpu = cpus ? cpus[0] : -1;
+    int bad = 0;
+#pragma omp parallel num_threads(n) reduction(+ : bad)
+    {
+        const int t = omp_get_thread_num();
+        if (cpus && t > 0) {                                       /* pool threads stay where they are put; the caller's thread: master_enter */
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            CPU_SET(cpus[t], &set);
+            if (pthread_setaffinity_np(pthread_self(), sizeof(set), &set) != 0) bad += 1;
+        }
+    }
+    return bad;
+}
+uint16_t *rwkv_cpu_place(const uint16_t *src, long rows, long K) {
+    void *mem = NULL;
+    if (posix_memalign(&mem, 4096, (size_t)rows * (size_t)K * 2 + 64) != 0) return NULL;
+    uint16_t *dst = (uint16_t *)mem;
+    master_enter();
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < rows; ++r) memcpy(dst + r * K, src + r * K, (size_t)K * 2);
+    master_leave();
+    return dst;
+}
+void rwkv_cpu_free(void *p) { free(p); }
+
 int rwkv_cpu_threads(void) {
     int n = 1;
 #pragma omp parallel

@@ -45,9 +45,56 @@ class _Model(C.Structure):
                [("emb", _u16p), ("head", _u16p), ("ln0w", _f32p), ("ln0b", _f32p), ("lnow", _f32p), ("lnob", _f32p), ("layers", C.POINTER(_Layer))]
 
 
+def usable_cores() -> list[int]:
+    """One logical CPU per physical core this process may run on, socket by socket (hyper-thread siblings dropped: a memory-bound
+    GEMV gains nothing from them), capped by the cgroup CPU quota when the container has one."""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, picked = set(), []
+    try:
+        cur = {}
+        topo = {}
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k in ("processor", "physical id", "core id"):
+                cur[k] = int(v)
+            if not line.strip() and "processor" in cur:
+                topo[cur["processor"]] = (cur.get("physical id", 0), cur.get("core id", cur["processor"]))
+                cur = {}
+        if "processor" in cur:
+            topo[cur["processor"]] = (cur.get("physical id", 0), cur.get("core id", cur["processor"]))
+        for cpu in sorted(allowed, key=lambda c: (topo.get(c, (0, c)), c)):
+            key = topo.get(cpu, (0, cpu))
+            if key not in seen:
+                seen.add(key)
+                picked.append(cpu)
+    except OSError:
+        picked = allowed
+    try:                                                           # cgroup v2 quota: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            picked = picked[:max(1, int(int(q) / int(per)))]
+    except (OSError, ValueError):
+        pass
+    return picked or allowed
+
+
 class CpuBackend:
-    def __init__(self, tensors: dict, quant_layers: int = 0, quant_type: int = R.QUANT_NONE):
+    def __init__(self, tensors: dict, quant_layers: int = 0, quant_type: int = R.QUANT_NONE, threads: int | None = None):
         self.lib = C.CDLL(build())
+        self.lib.rwkv_cpu_pin.argtypes = [C.POINTER(C.c_int32), C.c_int]
+        self.lib.rwkv_cpu_pin.restype = C.c_int
+        self.lib.rwkv_cpu_place.argtypes = [_u16p, C.c_long, C.c_long]
+        self.lib.rwkv_cpu_place.restype = C.c_void_p
+        self.lib.rwkv_cpu_free.argtypes = [C.c_void_p]
+        # team = one thread per physical core, pinned (RWKV_CPU_THREADS overrides the count: scaling experiments)
+        cores = usable_cores()
+        n = threads or int(os.environ.get("RWKV_CPU_THREADS", "0")) or len(cores)
+        n = max(1, min(n, len(cores)))
+        arr = (C.c_int32 * n)(*cores[:n])
+        self.pin_failures = int(self.lib.rwkv_cpu_pin(arr, n))
+        self._placed = []
+        self.weight_bytes = 0
         self.lib.rwkv_cpu_step.restype = C.c_int
         self.lib.rwkv_cpu_step.argtypes = [C.POINTER(_Model), C.POINTER(C.c_int32), C.c_int, _f32p, _f32p]
         self.lib.rwkv_cpu_fake_quant_int8.argtypes = [_u16p, C.c_long, C.c_long]
@@ -75,8 +122,15 @@ class CpuBackend:
                     a2 = a.reshape(-1, a.shape[-1])
                     self.lib.rwkv_cpu_fake_quant_nf4(a2.view(np.uint16).ctypes.data_as(_u16p), a2.shape[0], a2.shape[1],
                                                      self._nf4_mid.ctypes.data_as(_f32p), self._nf4_tab.view(np.uint16).ctypes.data_as(_u16p))
-            self._keep.append(a)
-            return a.view(np.uint16).ctypes.data_as(_u16p)
+            # NUMA placement: the matrix the step reads is a copy first-touched by the threads that will stream it (rwkv_cpu_place)
+            a2 = a.reshape(-1, a.shape[-1])
+            ptr = self.lib.rwkv_cpu_place(a2.view(np.uint16).ctypes.data_as(_u16p), a2.shape[0], a2.shape[1])
+            if not ptr:
+                raise MemoryError(name)
+            self._placed.append(ptr)
+            if name != "emb.weight":
+                self.weight_bytes += a.nbytes
+            return C.cast(ptr, _u16p)
 
         def vec(name):                                   # fp32 of the fp16-rounded values, flat
             a = np.ascontiguousarray(np.asarray(tensors[name], dtype=np.float16).astype(np.float32).reshape(-1))
@@ -126,9 +180,25 @@ class CpuBackend:
                              mat("emb.weight"), mat("head.weight"), vec("blocks.0.ln0.weight"), vec("blocks.0.ln0.bias"),
                              vec("ln_out.weight"), vec("ln_out.bias"), self._layers)
 
+    def __del__(self):
+        for p in getattr(self, "_placed", []):
+            try:
+                self.lib.rwkv_cpu_free(p)
+            except Exception:
+                pass
+        self._placed = []
+
     @property
     def threads(self) -> int:
         return int(self.lib.rwkv_cpu_threads())
+
+    def describe(self) -> str:
+        return (f"C/OpenMP restatement (oracle/cpu_backend.c): fp16 weights as the GPU dequantises them, fp32 accumulate, one persistent team of "
+                f"{self.threads} threads pinned one per physical core, weights first-touched by the threads that stream them")
+
+    def stream_gbps(self, steps_per_s: float) -> float:
+        """Weight bytes one step streams (every matrix once, the embedding row excluded) x steps/s: what the host's DRAM delivered."""
+        return self.weight_bytes * steps_per_s / 1e9
 
     def init_states(self, B: int) -> np.ndarray:
         i = self.info

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "ai00_server_amd")
 name, flags = sys.argv[1], sys.argv[2:]
 cs = os.path.join(PKG, "csrc")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *flags, "-o", os.path.join(PKG, f"librwkv_hip_{name}.so")]
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wl,--version-script=" + os.path.join(cs, "rwkv_abi.map"), *flags, "-o", os.path.join(PKG, f"librwkv_hip_{name}.so")]
 for s in ["rwkv_kernels.hip", "rwkv_engine.cpp", "tokenizer.cpp"]:
     cmd += (["-x", "hip"] if s.endswith(".cpp") else []) + [os.path.join(cs, s)]
 subprocess.check_call(cmd)

@@ -97,9 +97,15 @@ static void run(const char *label, size_t total, int G, int waves, int R, int xk
     CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); CK(hipFree(W)); CK(hipFree(X)); CK(hipFree(out));
 }
 
-int main() {
+int main(int argc, char **argv) {
     hipStream_t st; CK(hipStreamCreate(&st));
     const size_t MB = 1000000;
+    if (argc > 1 && argv[1][0] == 'w') {      // waves x loads-in-flight matrix at one workgroup per CU
+        for (int w : {2, 4, 5, 8, 10, 16})
+            for (int r : {2, 4, 8, 16}) run("wxr", 27400 * 1000, 256, w, r, 0, 1, false, st);
+        for (int w : {4, 8}) for (int r : {4, 8}) run("wxr-512", 27400 * 1000, 512, w, r, 0, 1, false, st);
+        return 0;
+    }
     // (0) floor: near-empty launches
     run("empty", 256 * 1024, 256, 4, 4, 0, 0, false, st);
     // (1) per-CU cap: fixed 100 KB per block, fewer and fewer blocks

@@ -13,7 +13,7 @@ LIB = os.path.join(PKG, "librwkv_hip_trace.so")
 def build(level):
     cs = os.path.join(PKG, "csrc")
     srcs = ["rwkv_kernels.hip", "rwkv_engine.cpp", "tokenizer.cpp"]
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-DRWKV_TRACE={level}", "-o", LIB] + os.environ.get("XFLAGS", "").split()
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wl,--version-script=" + os.path.join(cs, "rwkv_abi.map"), f"-DRWKV_TRACE={level}", "-o", LIB] + os.environ.get("XFLAGS", "").split()
     for s in srcs:
         cmd += (["-x", "hip"] if s.endswith(".cpp") else []) + [os.path.join(cs, s)]
     subprocess.check_call(cmd)

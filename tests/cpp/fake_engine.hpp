@@ -2,6 +2,7 @@
 #pragma once
 #include <atomic>
 #include <cmath>
+#include <stdexcept>
 
 #include "../../include/rwkv_scheduler.hpp"
 
@@ -19,9 +20,10 @@ struct FakeEngine {
     int chunk;            // tokens a slot may consume per infer call (like token_chunk_size / active slots)
     std::atomic<int> calls{0};   // read by the test thread while a replica thread may be stepping
     std::vector<int> riders;
+    std::atomic<int> fail_at{-1};   // infer call number that throws (a device error in the middle of a serving loop); -1: never
     FakeEngine(int B, int chunk_) : max_batch(B), chunk(chunk_) { info.num_vocab = 8; state.slots.assign((size_t)B, state.init()); }
     std::vector<rwkv::RnnOutputBatch> infer(rwkv::RnnInput &in) {
-        ++calls;
+        if (++calls == fail_at.load()) throw std::runtime_error("fake device error");
         int n = 0;
         std::vector<rwkv::RnnOutputBatch> out((size_t)max_batch);
         for (int b = 0; b < max_batch; ++b) {

@@ -90,6 +90,52 @@ int main() {
         CHECK(router.submit(&a) == 0 && router.submit(&b) == 1);
         CHECK(router.submit(&c) == -1);
     }   // the router's destructor stops the replica threads with requests still running
+    // --- a replica whose engine throws fails ITS requests with the message and keeps serving; the process survives, drain()
+    //     returns, the other replica is untouched
+    {
+        FakeEngine e0(2, 100), e1(2, 100);
+        e0.fail_at = 3;                                                  // third infer call of replica 0 throws
+        std::vector<FakeEngine *> es{&e0, &e1};
+        RoutedRequest a, b, c, d;
+        a.tokens = {1, 2, 3}; a.max_new = 50; b.tokens = {4, 5}; b.max_new = 50; c.tokens = {6}; c.max_new = 10; d.tokens = {7, 7}; d.max_new = 4;
+        ReplicaRouter<FakeEngine> router(es);
+        CHECK(router.submit(&a) == 0 && router.submit(&b) == 1 && router.submit(&c) >= 0);
+        router.drain();
+        CHECK(a.done && a.failed && a.error.find("fake device error") != std::string::npos);
+        CHECK(b.done && !b.failed && b.generated == greedy_alone(b.tokens, 50));
+        CHECK(c.done && (c.failed || c.generated == greedy_alone(c.tokens, 10)));     // failed only if it rode replica 0's bad step
+        CHECK(router.busy(0) == 0 && router.busy(1) == 0);
+        CHECK(router.submit(&d) == 0);                                   // replica 0 serves again (its slots were given up, not leaked)
+        router.drain();
+        CHECK(d.done && !d.failed && d.generated == greedy_alone(d.tokens, 4));
+        RoutedRequest t;                                                 // a throwing sample callback is contained the same way
+        t.tokens = {9}; t.max_new = 3; t.sample = [](const std::vector<float> &) -> uint32_t { throw std::runtime_error("sampler blew up"); };
+        CHECK(router.submit(&t) >= 0);
+        router.drain();
+        CHECK(t.done && t.failed && t.error == "sampler blew up");
+    }
+    // --- many threads submitting at once: nobody gets a slot twice, in-flight never exceeds capacity, everything completes
+    {
+        std::vector<std::unique_ptr<FakeEngine>> engines;
+        std::vector<FakeEngine *> es;
+        for (int i = 0; i < 4; ++i) { engines.emplace_back(new FakeEngine(2, 5)); es.push_back(engines.back().get()); }
+        std::vector<RoutedRequest> reqs(96);
+        for (int i = 0; i < 96; ++i) { reqs[(size_t)i].tokens = Tokens{(uint32_t)(i + 1), (uint32_t)(i % 3)}; reqs[(size_t)i].max_new = 3 + i % 4; }
+        ReplicaRouter<FakeEngine> router(es);
+        std::atomic<int> over{0};
+        std::vector<std::thread> subs;
+        for (int t = 0; t < 6; ++t)
+            subs.emplace_back([&, t] {
+                for (int i = t; i < 96; i += 6) {
+                    while (router.submit(&reqs[(size_t)i]) < 0) std::this_thread::yield();
+                    for (int r = 0; r < 4; ++r) if (router.busy(r) > 2) ++over;
+                }
+            });
+        for (auto &th : subs) th.join();
+        router.drain();
+        CHECK(over.load() == 0);
+        for (auto &q : reqs) CHECK(q.done && !q.failed && q.generated == greedy_alone(q.tokens, q.max_new));
+    }
     std::printf("router_test: ok\n");
     return 0;
 }

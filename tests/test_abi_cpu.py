@@ -193,16 +193,63 @@ def test_graft_entry_build_is_green(built_lib):
     g.build()
 
 
-def test_integration_md_lists_every_export():
-    """The Rust `extern "C"` block of INTEGRATION.md (the binding a maintainer would add) names every function include/rwkv_abi.h declares."""
+def _header_functions():
+    """name -> number of parameters, from include/rwkv_abi.h"""
     import re
     hdr = open(os.path.join(ROOT, "include", "rwkv_abi.h")).read()
-    names = set(re.findall(r"^\s*(?:const\s+char\s*\*|rwkv_status|int32_t|int64_t|uint64_t|size_t|void)\s*\*?\s*(rwkv_\w+)\s*\(", hdr, re.M))
-    assert len(names) >= 38
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    out = {}
+    for m in re.finditer(r"(?:const\s+char\s*\*|rwkv_status|int32_t|int64_t|uint64_t|size_t|void)\s*\*?\s*(rwkv_\w+)\s*\(([^;]*?)\)\s*;", hdr, re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_rust_sys_crate_declares_every_export_with_the_headers_arity():
+    """integration/rwkv-hip-sys/src/lib.rs (the FFI a maintainer links ai00-core against) against include/rwkv_abi.h: same
+    function names, same number of arguments, same ABI version; and every one of them is exported by the built library."""
+    import re
+    want = _header_functions()
+    assert len(want) >= 39 and set(want) == set(rt.ABI_SYMBOLS), sorted(set(want) ^ set(rt.ABI_SYMBOLS))
+    rs = open(os.path.join(ROOT, "integration", "rwkv-hip-sys", "src", "lib.rs")).read()
+    got = {}
+    for m in re.finditer(r"pub fn (rwkv_\w+)\(([^)]*)\)", rs, re.S):
+        args = m.group(2).strip()
+        got[m.group(1)] = 0 if not args else len([a for a in args.split(",") if a.strip()])
+    assert got == want, {k: (got.get(k), want.get(k)) for k in set(got) | set(want) if got.get(k) != want.get(k)}
+    hv = int(re.search(r"#define\s+RWKV_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "rwkv_abi.h")).read()).group(1))
+    assert int(re.search(r"RWKV_ABI_VERSION: i32 = (\d+)", rs).group(1)) == hv
+    for name, (res, argt) in rt.ABI_SYMBOLS.items():                     # the ctypes mirror agrees on the arity too
+        assert len(argt) == want[name], name
     md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    missing = sorted(n for n in names if f"pub fn {n}(" not in md)
-    assert not missing, missing
-    assert names == set(rt.ABI_SYMBOLS), sorted(names ^ set(rt.ABI_SYMBOLS))
+    assert "integration/rwkv-hip-sys" in md and "integration/ai00-core.patch" in md
+
+
+def test_library_exports_only_the_c_abi(built_lib):
+    """Linked with csrc/rwkv_abi.map: no C++ symbol of the engine or of the kernel launchers leaves the library."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", built_lib], capture_output=True, text=True, check=True).stdout
+    names = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert names and all(n.startswith("rwkv_") for n in names), [n for n in names if not n.startswith("rwkv_")][:10]
+    assert set(names) >= set(rt.ABI_SYMBOLS)
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 with no extensions."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "rwkv_abi.h"\nint main(void) { rwkv_load_desc d; rwkv_sample_params p; (void)d; (void)p; return RWKV_ABI_VERSION > 0 ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(src)], check=True)
+
+
+def test_reference_patch_still_applies():
+    """integration/ai00-core.patch against the reference checkout (only where it is present)."""
+    import subprocess
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "crates", "ai00-core")):
+        pytest.skip("the reference checkout is not on this machine")
+    r = subprocess.run(["git", "apply", "--check", os.path.join(ROOT, "integration", "ai00-core.patch")], cwd=ref, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
 
 
 def test_mutated_inputs_never_abort(built_lib, tmp_path):
