@@ -515,7 +515,20 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
         if (want && (size_t)t.numel() != want) throw RwkvError(RWKV_ERR_FORMAT, name + ": unexpected size");
         upload_raw(t);
         float *v = dalloc<float>((size_t)t.numel());
-        launch_f16_to_f32(raw, v, t.numel(), op, s_main);
+        // `LoraBlend::full(alpha)` (lib.rs:466-482) matches EVERY tensor: a LoRA file that holds a tensor of this name (time_mix_*,
+        // time_decay, time_first, LayerNorm weights ...) is blended in whole, v += alpha * l, before the load-time transform
+        bool blended = false;
+        for (auto &lp : loras) {
+            const StTensor *l = lp.first.find(name);
+            if (!l) continue;
+            if (l->dtype != "F16" || l->numel() != t.numel()) throw RwkvError(RWKV_ERR_FORMAT, name + ": LoRA tensor does not match the model's");
+            if (!blended) { launch_f16_to_f32(raw, v, t.numel(), 0, s_main); blended = true; }
+            HIP_CHECK(hipStreamSynchronize(s_main));                                // `raw` is free again
+            HIP_CHECK(hipMemcpyAsync(raw, l->data, l->nbytes, hipMemcpyHostToDevice, s_main));
+            launch_vec_blend(v, raw, t.numel(), lp.second, s_main);
+        }
+        if (blended) { if (op) launch_vec_op(v, t.numel(), op, s_main); }
+        else launch_f16_to_f32(raw, v, t.numel(), op, s_main);
         HIP_CHECK(hipStreamSynchronize(s_main));
         vecs[name] = v; vec_meta[name] = {(size_t)t.numel(), true};
         weight_bytes += (uint64_t)t.numel() * 2;
@@ -1410,6 +1423,9 @@ int32_t rwkv_device_count(void) {
 rwkv_status rwkv_device_name(int32_t index, char *buf, size_t buf_len) {
     return guard([&] {
         if (!buf || !buf_len) throw RwkvError(RWKV_ERR_INVALID, "null buffer");
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+        if (index < 0 || index >= n) throw RwkvError(RWKV_ERR_DEVICE, "adapter index out of range (ContextError::RequestAdapterFailed)");
         hipDeviceProp_t p;
         HIP_CHECK(hipGetDeviceProperties(&p, index));
         std::snprintf(buf, buf_len, "%s (%s, HIP)", p.name, p.gcnArchName);
@@ -1445,6 +1461,7 @@ rwkv_status rwkv_engine_create(const rwkv_load_desc *desc, rwkv_engine **out) {
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
             throw RwkvError(RWKV_ERR_DEVICE, "no HIP device: librwkv_hip has no CPU fallback");
+        if (desc->adapter < RWKV_ADAPTER_ECONOMICAL) throw RwkvError(RWKV_ERR_INVALID, "adapter must be RWKV_ADAPTER_AUTO, RWKV_ADAPTER_ECONOMICAL or a device index");
         int dev = desc->adapter >= 0 ? desc->adapter : 0;   // Auto / Economical: every MI355X is identical -> device 0
         if (dev >= n) throw RwkvError(RWKV_ERR_DEVICE, "adapter index out of range (ContextError::RequestAdapterFailed)");
         HIP_CHECK(hipSetDevice(dev));

@@ -15,6 +15,7 @@
 #include "rwkv_kernels.h"
 #include <type_traits>
 #include <cstdlib>
+#include <algorithm>
 
 
 // Build parts: the product build compiles this file once per part (-DRWKV_PART=k, k = 0..4, in parallel: one pass takes
@@ -2688,6 +2689,24 @@ void launch_f16_to_f32(const _Float16 *in, float *out, long n, int op, hipStream
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(f16_to_f32_kernel, dim3(blocks), dim3(256), 0, s, in, out, n, op);
+}
+
+// LoRA on a non-matrix tensor (`LoraBlend::full(alpha)` matches every tensor, lib.rs:466-482): a LoRA file that carries a tensor of
+// the SAME name blends it in whole, v += alpha * l, on the fp32 copy and BEFORE any load-time transform (op 1: exp(-exp(v))).
+__global__ void vec_blend_kernel(float *v, const _Float16 *l, long n, float alpha) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) v[i] += alpha * (float)l[i];
+}
+__global__ void vec_op_kernel(float *v, long n, int op) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        if (op == 1) v[i] = expf(-expf(v[i]));
+}
+void launch_vec_blend(float *v, const _Float16 *l, long n, float alpha, hipStream_t s) {
+    const int blocks = (int)std::max<long>(1, std::min<long>(1024, (n + 255) / 256));
+    hipLaunchKernelGGL(vec_blend_kernel, dim3(blocks), dim3(256), 0, s, v, l, n, alpha);
+}
+void launch_vec_op(float *v, long n, int op, hipStream_t s) {
+    const int blocks = (int)std::max<long>(1, std::min<long>(1024, (n + 255) / 256));
+    hipLaunchKernelGGL(vec_op_kernel, dim3(blocks), dim3(256), 0, s, v, n, op);
 }
 
 __global__ void lora_blend_kernel(_Float16 *W, const _Float16 *B, const _Float16 *A, int rows, int K, int r, float alpha) {

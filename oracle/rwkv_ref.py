@@ -245,7 +245,12 @@ class RwkvRef:
     run.rs:1121-1130, so a batch is just this applied per slot)."""
 
     def __init__(self, tensors: dict[str, np.ndarray], quant_layers: int = 0,
-                 quant_type: int = QUANT_NONE):
+                 quant_type: int = QUANT_NONE, lora: list | None = None):
+        """`lora`: [(lora_tensors, alpha), ...] blended at load like `ModelBuilder::lora(Lora { data, blend: LoraBlend::full(alpha) })`
+        (lib.rs:466-482).  `full(alpha)` matches every tensor name.  As published in web-rwkv's loader (0.10, not vendored in the
+        reference tree — restated, unpinned): a matrix `X.weight` with `X.lora.0` [in, r] / `X.lora.1` [out, r] in the file gets
+        W += alpha * B A^T; any other tensor the file holds under the model's own name is blended whole, v += alpha * l.  Matrices are
+        blended on the fp16 values in fp32 and rounded back once (then quantised, if their layer is); vectors stay fp32."""
         self.info = model_info(tensors)
         self.quant_layers = quant_layers
         self.quant_type = quant_type
@@ -257,10 +262,20 @@ class RwkvRef:
         self.w: dict[str, np.ndarray] = {}
         for k, v in tensors.items():
             v16 = np.asarray(v, dtype=np.float16)
+            vec32 = None
+            for lt, alpha in (lora or []):
+                stem = k[:-len(".weight")] if k.endswith(".weight") else k
+                if stem + ".lora.0" in lt and stem + ".lora.1" in lt and v16.ndim == 2:
+                    A = np.asarray(lt[stem + ".lora.0"], np.float16).astype(np.float32)
+                    B = np.asarray(lt[stem + ".lora.1"], np.float16).astype(np.float32)
+                    v16 = (v16.astype(np.float32) + np.float32(alpha) * (B @ A.T)).astype(np.float16)
+                elif k in lt:
+                    base = v16.astype(np.float32) if vec32 is None else vec32
+                    vec32 = base + np.float32(alpha) * np.asarray(lt[k], np.float16).astype(np.float32).reshape(base.shape)
             if k in qn:
                 v16 = fake_quant(v16, quant_type)
             dst = big_empty(v16.shape, np.float32)
-            dst[...] = v16
+            dst[...] = v16 if vec32 is None else vec32
             self.w[k] = dst
 
     # ---- state slab: [L][N+2][C] fp32 == shape [C, N+2, L, 1] fastest-dim-first (run.rs:987)

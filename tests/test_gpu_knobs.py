@@ -1,0 +1,118 @@
+"""GPU (-m gpu): every experiment switch of DESIGN.md 4.1 selects a code path of the PRODUCT library, so each is a configuration
+that has to give the oracle's answers too.  The switches are read once per engine, at creation (`rwkv::Knobs`), which is what
+lets one process walk them: set the variable, build an engine, drop the variable.
+
+Per switch: a two-layer V6 model at a width where the switched path is really taken (C = 512: v6_mix needs C % 256 == 0), fp16
+and Int8, prefill of ragged prompts (a 300-row step: tile GEMM / wide mix) then decode at 1, 3 and 20 slots (LayerNorm prologue,
+NT = 1 and NT = 2 GEMMs), logits + state against the oracle; V5 / V7 for the switches that touch their paths."""
+import os
+
+import numpy as np
+import pytest
+
+from ai00_server_amd import runtime as rt
+from oracle import rwkv_ref as R
+
+pytestmark = pytest.mark.gpu
+FP16_TOL = 1e-3
+
+SWITCHES = [("RWKV_KSW8", "0"), ("RWKV_NO_LN_FUSE", "1"), ("RWKV_NO_V6_FUSE", "1"), ("RWKV_NO_V6_WIDE", "1"), ("RWKV_V6MIX_SPLIT", "1"),
+            ("RWKV_NO_TILE", "1"), ("RWKV_TILE_XCD", "0"), ("RWKV_TILE3_FILL", "0"), ("RWKV_NO_DENSE", "1"), ("RWKV_LN_256", "1"),
+            ("RWKV_SPB", "2"), ("RWKV_KSB", "2"), ("RWKV_KSW8+RWKV_NO_LN_FUSE", "0+1")]
+
+
+def tol(want):
+    return FP16_TOL * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.fixture(scope="module")
+def models():
+    out = {}
+    for ver, F in ((6, 1792), (5, 1792), (7, 2048)):
+        tens = R.synth_checkpoint(ver, 2, 512, F, 1024, seed=70 + ver)
+        out[ver] = (tens, R.st_serialize(tens))
+    return out
+
+
+def run_case(st, tens, quant):
+    """prefill 20 ragged prompts (300 rows in one step), then 6 decode steps at 20, 3 and 1 active slots; returns max |err| / tol."""
+    ql = 2 if quant else 0
+    rb = R.RwkvRefBatch(tens, ql, quant)
+    B = 20
+    eng = rt.ModelBuilder(st).quant(ql, rt.Quant(quant)).build(max_batch=B, token_chunk_size=512, precision=rt.Precision.Fp16)
+    lens = [25, 7, 19, 13, 11]
+    ps = [[t % 1024 for t in R.synth_prompt(40 + b, lens[b % 5])] for b in range(B)]
+    states = rb.init_states(B)
+    want = rb.prefill(ps, states)
+    inp = rt.RnnInput([rt.RnnInputBatch(list(ps[b]), rt.RnnOption.Last) for b in range(B)])
+    got = [None] * B
+    while inp.num_token() > 0:
+        inp, outs = eng.infer(inp)
+        for b, o in enumerate(outs):
+            if len(o):
+                got[b] = o[-1]
+    worst = 0.0
+    for b in range(B):
+        worst = max(worst, float(np.abs(got[b] - want[b]).max()) / tol(want[b]))
+    cur = [int(np.argmax(want[b])) for b in range(B)]
+    for nact in (20, 20, 3, 3, 1, 1):
+        act = list(range(nact))
+        sub = states[act].copy()
+        lg = rb.step([cur[b] for b in act], sub)
+        states[act] = sub
+        _, outs = eng.infer(rt.RnnInput([rt.RnnInputBatch([cur[b]] if b < nact else [], rt.RnnOption.Last) for b in range(B)]))
+        for j, b in enumerate(act):
+            worst = max(worst, float(np.abs(outs[b][-1] - lg[j]).max()) / tol(lg[j]))
+            assert int(np.argmax(outs[b][-1])) == int(np.argmax(lg[j]))
+            cur[b] = int(np.argmax(lg[j]))
+    for b in range(B):
+        back = eng.state.back(b)
+        worst = max(worst, float(np.abs(back - states[b]).max()) / tol(states[b]))
+    eng.close()
+    return worst
+
+
+@pytest.mark.parametrize("switch,value", SWITCHES, ids=[f"{k}={v}" for k, v in SWITCHES])
+def test_every_switch_gives_the_oracles_answers(models, switch, value):
+    names, values = switch.split("+"), value.split("+")
+    old = {k: os.environ.get(k) for k in names}
+    try:
+        for k, v in zip(names, values):
+            os.environ[k] = v
+        vers = (6, 5, 7) if any(k in ("RWKV_KSW8", "RWKV_NO_LN_FUSE", "RWKV_NO_TILE", "RWKV_NO_DENSE", "RWKV_LN_256", "RWKV_SPB", "RWKV_KSB") for k in names) else (6,)
+        for ver in vers:
+            tens, st = models[ver]
+            for quant in (0, 1):
+                assert run_case(st, tens, quant) <= 1.0, f"V{ver} quant {quant}"
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_switches_are_frozen_per_engine(models):
+    """An engine keeps the choices it was created with: flipping the environment afterwards changes nothing for it (its captured
+    graphs stay valid), while the next engine picks the new value up."""
+    tens, st = models[6]
+    os.environ["RWKV_NO_V6_FUSE"] = "1"
+    try:
+        e1 = rt.ModelBuilder(st).build(max_batch=2, token_chunk_size=64)
+    finally:
+        os.environ.pop("RWKV_NO_V6_FUSE", None)
+    e2 = rt.ModelBuilder(st).build(max_batch=2, token_chunk_size=64)
+    p = [t % 1024 for t in R.synth_prompt(3, 9)]
+
+    def fams(e):
+        inp = rt.RnnInput([rt.RnnInputBatch(list(p)), rt.RnnInputBatch()])
+        _, _, fam = e.profile_infer(inp)
+        return fam["gemm_layers"][1]
+    a, b = fams(e1), fams(e2)
+    assert a > b, (a, b)                       # the unfused engine launches two GEMMs where the fused one launches one mix kernel
+    os.environ["RWKV_NO_V6_FUSE"] = "1"
+    try:
+        assert fams(e2) == b                   # e2 was created fused and stays fused
+    finally:
+        os.environ.pop("RWKV_NO_V6_FUSE", None)
+    e1.close(); e2.close()

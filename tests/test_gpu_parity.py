@@ -234,6 +234,72 @@ def test_lora_blend_at_load():
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["v5-tiny", "v6-tiny", "v7-tiny"])
+def test_lora_blends_vectors_as_well_as_matrices(name):
+    """`LoraBlend::full(alpha)` (lib.rs:466-482) matches EVERY tensor: the engine blends the projection matrices (W += alpha B A^T)
+    and whatever other tensor the LoRA file holds under the model's own name (token-shift mixes, decay, LayerNorm weights:
+    v += alpha l, before the load-time transform of the V5 decay).  Two LoRA files stack.  Against the oracle loaded the same way."""
+    t = R.synth_named(name)
+    rng = np.random.default_rng(13)
+    C, r = 128, 8
+    ver = R.model_info(t).version
+    mixk = {5: "att.time_mix_k", 6: "att.time_mix_k", 7: "att.x_k"}[ver]
+    l1 = {"blocks.0.att.key.lora.0": (rng.standard_normal((C, r)) * 0.05).astype(np.float16),
+          "blocks.0.att.key.lora.1": (rng.standard_normal((C, r)) * 0.05).astype(np.float16),
+          f"blocks.0.{mixk}": (rng.standard_normal(t[f"blocks.0.{mixk}"].shape) * 0.2).astype(np.float16),
+          "blocks.1.ln1.weight": (rng.standard_normal(C) * 0.2).astype(np.float16),
+          "ln_out.bias": (rng.standard_normal(C) * 0.2).astype(np.float16)}
+    if ver != 7:
+        l1["blocks.1.att.time_decay"] = (rng.standard_normal(t["blocks.1.att.time_decay"].shape) * 0.2).astype(np.float16)   # V5: blended BEFORE exp(-exp(.))
+        l1["blocks.0.att.time_first"] = (rng.standard_normal(t["blocks.0.att.time_first"].shape) * 0.2).astype(np.float16)
+    else:
+        l1["blocks.1.att.w0"] = (rng.standard_normal(t["blocks.1.att.w0"].shape) * 0.2).astype(np.float16)
+        l1["blocks.0.att.k_k"] = (rng.standard_normal(t["blocks.0.att.k_k"].shape) * 0.2).astype(np.float16)
+    l2 = {"blocks.1.ffn.value.lora.0": (rng.standard_normal((t["blocks.1.ffn.value.weight"].shape[1], r)) * 0.05).astype(np.float16),
+          "blocks.1.ffn.value.lora.1": (rng.standard_normal((C, r)) * 0.05).astype(np.float16),
+          "blocks.1.ln1.weight": (rng.standard_normal(C) * 0.2).astype(np.float16)}            # the same vector again: blends stack
+    b = rt.ModelBuilder(R.st_serialize(t)).lora(R.st_serialize(l1), 0.5).lora(R.st_serialize(l2), -0.75)
+    eng = b.build(max_batch=1, token_chunk_size=16, precision=rt.Precision.Fp32)
+    ref = R.RwkvRef(t, lora=[(l1, 0.5), (l2, -0.75)])
+    p = prompt(ref, 14, 21)
+    s = ref.init_state()
+    want = ref.forward(p, s)[-1]
+    got = run_prompts(eng, [p])[0][0]
+    assert np.abs(got - want).max() <= 5e-4 * max(1.0, np.abs(want).max())      # the blend's fp32 dot order differs before the fp16 rounding
+    s0 = R.RwkvRef(t).init_state()
+    assert np.abs(got - R.RwkvRef(t).forward(p, s0)[-1]).max() > 1e-3           # the adapters did something
+    eng.close()
+    with pytest.raises(rt.RwkvError) as e:                                      # a vector of the wrong size fails the load, not a kernel
+        rt.ModelBuilder(R.st_serialize(t)).lora(R.st_serialize({"blocks.0.ln1.weight": np.zeros(C // 2, np.float16)}), 1.0).build(max_batch=1)
+    assert e.value.code == -2
+
+
+def test_adapter_selection_and_device_names():
+    """lib.rs:339-368: `list_adapters` names every device; `AdapterOption::Auto / Economical / Manual(n)` pick one; Manual(n) beyond
+    the list fails like `ContextError::RequestAdapterFailed` (RWKV_ERR_DEVICE), it does not fall back."""
+    names = rt.list_adapters()
+    n = rt.lib().rwkv_device_count()
+    assert n >= 1 and len(names) == n
+    for nm in names:
+        assert "MI3" in nm or "gfx950" in nm or "AMD" in nm or "Instinct" in nm, nm
+    import ctypes as C
+    small = C.create_string_buffer(4)
+    assert rt.lib().rwkv_device_name(0, small, 4) == 0 and len(small.value) <= 3            # truncated, NUL-terminated
+    assert rt.lib().rwkv_device_name(n, small, 4) == -4 and rt.lib().rwkv_device_name(-1, small, 4) != 0
+    st = R.st_serialize(R.synth_named("v6-tiny"))
+    for adapter in (-1, -2, 0, n - 1):                                          # Auto, Economical, Manual(0), Manual(last)
+        eng = rt.ModelBuilder(st, adapter=adapter).build(max_batch=1, token_chunk_size=8)
+        assert eng.device == (adapter if adapter >= 0 else 0)
+        assert eng.max_batch == 1 and eng.token_chunk_size == 8                 # read back from the engine (rwkv_engine_token_chunk_size)
+        eng.close()
+    for bad in (n, n + 7):
+        with pytest.raises(rt.RwkvError) as e:
+            rt.ModelBuilder(st, adapter=bad).build(max_batch=1)
+        assert e.value.code == -4
+    with pytest.raises(rt.RwkvError):
+        rt.ModelBuilder(st, adapter=-3).build(max_batch=1)                      # not an AdapterOption
+
+
 def test_error_codes_never_abort():
     t, eng = build("v6-tiny", B=2, chunk=4)
     with pytest.raises(rt.RwkvError) as e:
