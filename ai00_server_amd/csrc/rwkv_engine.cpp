@@ -916,15 +916,32 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
             if (ok3 && fill_min > 0 && t3 >= 400 && t3 * 100 >= fill_min * rounds * 512) shape = GEMM_TILE3;
         }
         if (f_shape >= 0 && f_shape < GEMM_TILE_SHAPES && (f_shape != GEMM_TILE3 || ok3)) shape = f_shape;
+        // K split of a linear launch on the pipelined kernel (Wo, Fv: one `partial` problem whose output the next row kernel sums
+        // anyway): a grid of fewer than 512 tiles costs a whole round of the kernel, so the tiles are replicated over `ksb` K ranges
+        // until the rounds are full — 3 x 320 tiles (V6-3B at 2048 rows) fill 94 % of two rounds a third as long (tg3_body).
+        int ksplit = 1;
+        if (ok3 && kn.tile_ksplit && ps.size() == 1 && ps[0].partial && ps[0].post != POST_MIX && ps[0].act == ACT_NONE && !ps[0].bias &&
+            !ps[0].oh.hi && (f_shape < 0 || f_shape == GEMM_TILE3) && kn.tile3_fill > 0) {
+            const long t3 = gemm_tile_blocks(GEMM_TILE3, ps[0].W->rows, T);
+            const int G = ps[0].W->K / 128;
+            double best = shape == GEMM_TILE3 ? (double)t3 / (((t3 + 511) / 512) * 512) : 0.0;
+            if (t3 >= 128) {
+                for (int b = 2; b <= 4 && G / b >= 6; ++b) {                    // >= 6 groups of 128 k per copy keep the pipeline's ramp small
+                    const double fill = (double)(t3 * b) / (((t3 * b + 511) / 512) * 512);
+                    if (fill > best + 0.10 && fill >= 0.80) { best = fill; ksplit = b; }
+                }
+            }
+            if (ksplit > 1) shape = GEMM_TILE3;
+        }
         int blocks = 0;
         for (size_t i = 0; i < ps.size(); ++i) {
             const ProbSpec &s = ps[i];
             GemmProb &g = Lh.p[i];
             g.W = s.W->data; g.S = s.W->scales; g.fmt = s.W->fmt; g.rows = s.W->rows; g.K = s.W->K;
             g.xhi = s.x.hi + (s.xoff >> 5) * 512; g.xlo = s.x.lo ? s.x.lo + (s.xoff >> 5) * 512 : nullptr; g.ldx = s.x.ld;   // column offset = whole k-tiles
-            g.spb = 16; g.nw = 8; g.ksb = 1; g.nblk_strip = 0;
+            g.spb = 16; g.nw = 8; g.ksb = ksplit; g.nblk_strip = 0;
             g.block_begin = blocks;
-            blocks += gemm_tile_blocks(shape, s.W->rows, T);
+            blocks += gemm_tile_blocks(shape, s.W->rows, T) * ksplit;
             g.act = s.act; g.post = s.post; g.bias = s.bias; g.m0 = s.m0; g.m1 = s.m1; g.ldm = s.ldm;
             g.out_f32 = s.out; g.ldo = s.ldo; g.partial_stride = pstride;
             g.out_hi = s.oh.hi; g.out_lo = s.oh.lo; g.ldh = s.oh.ld;
@@ -932,7 +949,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         Lh.total_blocks = blocks;
         Lh.xcd_map = kn.tile_xcd;                                   // A/B switch
         launch(fam, [&] { launch_gemm_tile(Lh, shape, hilo, s_main); });
-        return 1;
+        return ksplit;
     }
     const int np = plan_gemm(Lh, ps, T, hilo, pstride);
     if (lnp) Lh.lnp = *lnp;

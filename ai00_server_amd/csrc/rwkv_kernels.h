@@ -19,6 +19,7 @@ struct Knobs {
     int no_ln_fuse = 0;              // RWKV_NO_LN_FUSE: row kernels instead of the LayerNorm prologue on single-token steps
     int no_v6_fuse = 0, no_v6_wide = 0, v6mix_split = 0;   // RWKV_NO_V6_FUSE / RWKV_NO_V6_WIDE / RWKV_V6MIX_SPLIT
     int no_tile = 0, tile_shape = -1, tile3_fill = 65, tile_xcd = 1;   // RWKV_NO_TILE / RWKV_TILE_SHAPE / RWKV_TILE3_FILL / RWKV_TILE_XCD
+    int tile_ksplit = 1;             // RWKV_TILE_KSPLIT: K split of linear launches on the pipelined prefill kernel (0 = off)
     int no_dense = 0;                // RWKV_NO_DENSE: general row metadata on dense decode steps
     int ln_256 = 0;                  // RWKV_LN_256: 256-thread ln_shift everywhere
     static Knobs from_env();

@@ -478,6 +478,7 @@ Knobs Knobs::from_env() {
     k.no_v6_wide = knob_env("RWKV_NO_V6_WIDE", 0); k.v6mix_split = knob_env("RWKV_V6MIX_SPLIT", 0);
     k.no_tile = knob_env("RWKV_NO_TILE", 0); k.tile_shape = knob_env("RWKV_TILE_SHAPE", -1);
     k.tile3_fill = knob_env("RWKV_TILE3_FILL", 65); k.tile_xcd = knob_env("RWKV_TILE_XCD", 1);
+    k.tile_ksplit = knob_env("RWKV_TILE_KSPLIT", 1);
     k.no_dense = knob_env("RWKV_NO_DENSE", 0); k.ln_256 = knob_env("RWKV_LN_256", 0);
     return k;
 }
@@ -1457,8 +1458,14 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
     const int nstrips = P.rows >> 4;
     const int ntt = (L.T + BT - 1) / BT;
     int lb = (int)blockIdx.x - P.block_begin;
+    // K split (linear epilogues only, P.ksb > 1): the launch's tiles are replicated ksb times, copy kb walks the 128-k groups
+    // [kb G / ksb, (kb+1) G / ksb) of the G = K / 128 and writes partial slab kb, which the next row kernel sums — a launch of 320
+    // tiles (Wo, Fv of the 3 B model at 2048 rows) leaves 192 of the kernel's 512 slots empty and costs a whole round anyway; as
+    // 3 x 320 it fills 94 % of two rounds that are a third as long.
+    const int nb = ((nstrips + STRIPS - 1) / STRIPS) * ntt;       // tiles of one copy
+    const int kb = lb / nb;
+    lb -= kb * nb;
     if (L.xcd_map) {                                              // XCD-banded tile numbering, as in tg_body
-        const int nb = ((nstrips + STRIPS - 1) / STRIPS) * ntt;
         const int k = lb & 7, j = lb >> 3;
         int start = 0;
         for (int m = 0; m < k; ++m) start += (nb - m + 7) >> 3;
@@ -1467,7 +1474,9 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
     const int rb = lb / ntt, tt = lb - rb * ntt;
     const int strip = rb * STRIPS + wave * SPW;
     const int t0 = tt * BT;
-    const int nst = P.K >> 6, nsc = P.K >> 7;
+    const int G = P.K >> 7, g0 = (int)((long)kb * G / P.ksb), g1 = (int)((long)(kb + 1) * G / P.ksb);
+    const int kofs = g0 * 128;                                    // first k of this copy
+    const int nsc = g1 - g0, nst = nsc * 2;
     const _Float16 *xs = (const _Float16 *)smem;                  // [T3_NB][token tile 0..7][k-step 0..1][lane][8]
     const unsigned xs_byte = (unsigned)(uintptr_t)smem;           // LDS byte address of the ring (dynamic LDS starts at 0 here, kept general)
     const int last_tile = (L.T - 1) >> 4;
@@ -1487,7 +1496,7 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
     for (int m = 0; m < 4; ++m) {
         const int i = m * 4 + wave;
         const int ttile = min((t0 >> 4) + (i >> 1), last_tile);
-        xsrc[m] = P.xhi + ((long)ttile * (P.ldx >> 5) + (i & 1)) * 512 + lane * 8;
+        xsrc[m] = P.xhi + ((long)ttile * (P.ldx >> 5) + (kofs >> 5) + (i & 1)) * 512 + lane * 8;
     }
     auto dma = [&](int s) {
         const unsigned dst = xs_byte + (unsigned)(((s & (T3_NB - 1)) * T3_STAGE_HALFS + wave * 512) * 2);
@@ -1497,7 +1506,7 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
     auto stage = [&](const Set &w, int s, auto half) {
         constexpr int H = decltype(half)::value;
         const _Float16 *bh = xs + (s & (T3_NB - 1)) * T3_STAGE_HALFS + lane * 8;
-        const int k0 = (s >> 1) * 128;
+        const int k0 = kofs + (s >> 1) * 128;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             f16x8 xv[NTL];
@@ -1522,7 +1531,7 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
     auto super = [&](Set &cur, Set &refill, int sc) {
         int s = 2 * sc;
         t3_arrived<FMT>(cur);
-        if (sc + 2 < nsc) t3_load<FMT>(refill, P, strip, nstrips, (sc + 2) * 128, lane);
+        if (sc + 2 < nsc) t3_load<FMT>(refill, P, strip, nstrips, kofs + (sc + 2) * 128, lane);
         if (s + 3 < nst) dma(s + 3);
         stage(cur, s, std::integral_constant<int, 0>{});
         publish(s);
@@ -1533,9 +1542,9 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
     };
 
     Set a0, a1, a2;
-    t3_load<FMT>(a0, P, strip, nstrips, 0, lane);
-    t3_load<FMT>(a1, P, strip, nstrips, nsc > 1 ? 128 : 0, lane);
-    t3_load<FMT>(a2, P, strip, nstrips, 0, lane);                 // placeholder contents (every register defined); refilled at sc = 0
+    t3_load<FMT>(a0, P, strip, nstrips, kofs, lane);
+    t3_load<FMT>(a1, P, strip, nstrips, kofs + (nsc > 1 ? 128 : 0), lane);
+    t3_load<FMT>(a2, P, strip, nstrips, kofs, lane);              // placeholder contents (every register defined); refilled at sc = 0
     dma(0);
     if (nst > 1) dma(1);
     if (nst > 2) dma(2);
@@ -1545,7 +1554,13 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
         if (sc + 1 < nsc) super(a1, a0, sc + 1);
         if (sc + 2 < nsc) super(a2, a1, sc + 2);
     }
-    tg_epilogue<SPW, NTL>(L, P, acc, strip, nstrips, t0, lane);
+    if (P.ksb > 1) {                                              // partial slab kb (host: out_f32 only, linear epilogue)
+        GemmProb Q = P;
+        Q.out_f32 = P.out_f32 + (long)kb * P.partial_stride;
+        tg_epilogue<SPW, NTL>(L, Q, acc, strip, nstrips, t0, lane);
+    } else {
+        tg_epilogue<SPW, NTL>(L, P, acc, strip, nstrips, t0, lane);
+    }
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_tile3_kernel(const GemmLaunch L) {

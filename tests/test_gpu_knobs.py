@@ -18,7 +18,7 @@ FP16_TOL = 1e-3
 
 SWITCHES = [("RWKV_KSW8", "0"), ("RWKV_NO_LN_FUSE", "1"), ("RWKV_NO_V6_FUSE", "1"), ("RWKV_NO_V6_WIDE", "1"), ("RWKV_V6MIX_SPLIT", "1"),
             ("RWKV_NO_TILE", "1"), ("RWKV_TILE_XCD", "0"), ("RWKV_TILE3_FILL", "0"), ("RWKV_NO_DENSE", "1"), ("RWKV_LN_256", "1"),
-            ("RWKV_SPB", "2"), ("RWKV_KSB", "2"), ("RWKV_KSW8+RWKV_NO_LN_FUSE", "0+1")]
+            ("RWKV_SPB", "2"), ("RWKV_KSB", "2"), ("RWKV_KSW8+RWKV_NO_LN_FUSE", "0+1"), ("RWKV_TILE_SHAPE", "10"), ("RWKV_TILE_KSPLIT", "0")]
 
 
 def tol(want):
