@@ -480,6 +480,7 @@ Knobs Knobs::from_env() {
     k.tile3_fill = knob_env("RWKV_TILE3_FILL", 65); k.tile_xcd = knob_env("RWKV_TILE_XCD", 1);
     k.tile_ksplit = knob_env("RWKV_TILE_KSPLIT", 1);
     k.no_dense = knob_env("RWKV_NO_DENSE", 0); k.ln_256 = knob_env("RWKV_LN_256", 0);
+    k.prefetch = knob_env("RWKV_PREFETCH", 1);
     return k;
 }
 static thread_local Knobs t_knobs;
@@ -1193,8 +1194,12 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
     // walk one contiguous band of the row-major tile sequence: the XCD streams 1/8 of the weight strips once and re-reads
     // them for its token tiles out of its own L2.  (A bijection for any grid; L.xcd_map = 0 restores row-major.)
     int lb = (int)blockIdx.x - P.block_begin;
+    const int nb = ((nstrips + STRIPS - 1) / STRIPS) * ntt;       // tiles of this problem
+    // K split (P.ksb > 1, linear epilogues): copy kb of the tile grid walks the chunks [kb nchunk / ksb, (kb+1) nchunk / ksb) and
+    // writes partial slab kb — small steps (a few hundred rows) leave Wo / Fv with fewer tiles than the chip has CUs
+    const int kb = lb / nb;
+    lb -= kb * nb;
     if (L.xcd_map) {
-        const int nb = ((nstrips + STRIPS - 1) / STRIPS) * ntt;   // tiles of this problem
         const int k = lb & 7, j = lb >> 3;                        // XCD class relative to the problem's first block, rank in it
         int start = 0;
         for (int m = 0; m < k; ++m) start += (nb - m + 7) >> 3;   // tiles owned by the classes before this one
@@ -1204,7 +1209,8 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
     const int strip = rb * STRIPS + wave * SPW;
     const int t0 = tt * BT;
     const int K = P.K;
-    const int nchunk = (K + TG_KC - 1) / TG_KC;
+    const int nchunk_all = (K + TG_KC - 1) / TG_KC;
+    const int c0 = (int)((long)kb * nchunk_all / P.ksb), nchunk = (int)((long)(kb + 1) * nchunk_all / P.ksb);   // this copy: chunks [c0, nchunk)
     constexpr int PART = NTL * (KC / 32) * 512;                   // halfs per (buffer, hi|lo): [token tile][k-tile][lane][8], fragment order
     _Float16 *xs = (_Float16 *)smem;                              // [buf][hi|lo][token tile][k-tile][lane][8]
     constexpr int XP = BT * TG_KC / 8 / THREADS;                  // 16-byte pieces per thread per part
@@ -1279,7 +1285,7 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
     auto mma_chunk = [&](const TRound<FMT, SPW, KC> &w, int c, auto full) {
         constexpr bool FULL = decltype(full)::value;
         const int k0 = c * TG_KC;
-        const _Float16 *bh = xs + (HILO ? (c & 1) * 2 : (c & 1)) * PART;
+        const _Float16 *bh = xs + (HILO ? ((c - c0) & 1) * 2 : ((c - c0) & 1)) * PART;
 #pragma unroll
         for (int ks = 0; ks < KC / 32; ++ks) {
             if (FULL || k0 + ks * 32 < K) {
@@ -1317,20 +1323,20 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
         // chunk c+1's X tiles are issued into the other buffer at the top of iteration c (every wave passed the barrier
         // that ended iteration c-1, so nobody still reads it); the barrier at the bottom (with the vmcnt(0) the compiler
         // puts in front of it) publishes them
-        if (nfull > 0) { tg_load<FMT, SPW, KC, true>(cur, P, strip, nstrips, 0, lane); glds_issue(0, 0, T_{}); }
-        else { tg_load<FMT, SPW, KC, false>(cur, P, strip, nstrips, 0, lane); glds_issue(0, 0, F_{}); }
+        if (nfull > c0) { tg_load<FMT, SPW, KC, true>(cur, P, strip, nstrips, c0 * TG_KC, lane); glds_issue(c0, 0, T_{}); }
+        else { tg_load<FMT, SPW, KC, false>(cur, P, strip, nstrips, c0 * TG_KC, lane); glds_issue(c0, 0, F_{}); }
         __syncthreads();
-        for (int c = 0; c < nchunk; ++c) {
-            if (c + 1 < nfull) {
+        for (int c = c0; c < nchunk; ++c) {
+            if (c + 1 < nfull && c + 1 < nchunk) {
                 tg_load<FMT, SPW, KC, true>(nxt, P, strip, nstrips, (c + 1) * TG_KC, lane);
-                glds_issue(c + 1, (c + 1) & 1, T_{});
+                glds_issue(c + 1, (c + 1 - c0) & 1, T_{});
                 mma_chunk(cur, c, T_{});
                 __syncthreads();
                 cur = nxt;
             } else {
                 if (c + 1 < nchunk) {
                     tg_load<FMT, SPW, KC, false>(nxt, P, strip, nstrips, (c + 1) * TG_KC, lane);
-                    glds_issue(c + 1, (c + 1) & 1, F_{});
+                    glds_issue(c + 1, (c + 1 - c0) & 1, F_{});
                 }
                 if (c < nfull) mma_chunk(cur, c, T_{}); else mma_chunk(cur, c, F_{});
                 if (c + 1 < nchunk) {
@@ -1341,16 +1347,16 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
         }
     } else {
     XRegs xa;
-    if (nfull > 0) { tg_load<FMT, SPW, KC, true>(cur, P, strip, nstrips, 0, lane); stage_load(xa, 0, T_{}); }
-    else { tg_load<FMT, SPW, KC, false>(cur, P, strip, nstrips, 0, lane); stage_load(xa, 0, F_{}); }
+    if (nfull > c0) { tg_load<FMT, SPW, KC, true>(cur, P, strip, nstrips, c0 * TG_KC, lane); stage_load(xa, c0, T_{}); }
+    else { tg_load<FMT, SPW, KC, false>(cur, P, strip, nstrips, c0 * TG_KC, lane); stage_load(xa, c0, F_{}); }
     stage_store(xa, 0);
     __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        if (c + 1 < nfull) {                                       // steady state: everything unpredicated
+    for (int c = c0; c < nchunk; ++c) {
+        if (c + 1 < nfull && c + 1 < nchunk) {                     // steady state: everything unpredicated
             tg_load<FMT, SPW, KC, true>(nxt, P, strip, nstrips, (c + 1) * TG_KC, lane);
             stage_load(xa, c + 1, T_{});
             mma_chunk(cur, c, T_{});
-            stage_store(xa, (c + 1) & 1);
+            stage_store(xa, (c + 1 - c0) & 1);
             __syncthreads();
             cur = nxt;
         } else {
@@ -1360,14 +1366,20 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
             }
             if (c < nfull) mma_chunk(cur, c, T_{}); else mma_chunk(cur, c, F_{});
             if (c + 1 < nchunk) {
-                stage_store(xa, (c + 1) & 1);
+                stage_store(xa, (c + 1 - c0) & 1);
                 __syncthreads();
                 cur = nxt;
             }
         }
     }
     }
-    tg_epilogue<SPW, NTL>(L, P, acc, strip, nstrips, t0, lane);
+    if (P.ksb > 1) {                                              // partial slab kb (host: out_f32 only, linear epilogue)
+        GemmProb Q = P;
+        Q.out_f32 = P.out_f32 + (long)kb * P.partial_stride;
+        tg_epilogue<SPW, NTL>(L, Q, acc, strip, nstrips, t0, lane);
+    } else {
+        tg_epilogue<SPW, NTL>(L, P, acc, strip, nstrips, t0, lane);
+    }
 }
 
 template <bool HILO, int WAVES, int SPW, int NTL, int KC, bool GLDS>
@@ -1682,9 +1694,32 @@ __device__ __forceinline__ void row_layernorm(float4 (&v)[PT], int C, const floa
 }
 
 
+// touch loop of a prefetch workgroup `pb` of `pf.blocks` (PrefetchArgs, rwkv_kernels.h): one 4-byte default-policy load per 128-byte
+// line, 16 in flight per thread
+__device__ __forceinline__ void prefetch_touch(const PrefetchArgs &pf, int pb) {
+    const size_t stride = (size_t)pf.blocks * blockDim.x;                 // lines covered per sweep of the whole prefetch grid
+    unsigned acc = 0;
+    for (int s = 0; s < pf.n; ++s) {
+        const unsigned *base = (const unsigned *)pf.ptr[s];
+        const size_t nline = pf.bytes[s] >> 7;
+        for (size_t l0 = (size_t)pb * blockDim.x + threadIdx.x; l0 < nline; l0 += stride * 16) {
+            unsigned v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const size_t l = l0 + (size_t)j * stride;
+                v[j] = l < nline ? base[l * 32] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc ^= v[j];
+        }
+    }
+    if (acc == 0x9e3779b9u && pf.sink) pf.sink[0] = acc;                  // practically never: the loads must not be dead code
+}
+
 template <int PT, int NTHR>
 __global__ __launch_bounds__(NTHR) void ln_shift_kernel(const LnShiftArgs a) {
     __shared__ float red[2 * NTHR / 64];
+    if ((int)blockIdx.x >= a.T) { prefetch_touch(a.pf, (int)blockIdx.x - a.T); return; }
     const int t = blockIdx.x, C = a.C;
     TRACE_K(2, 0);
     // every load that does not depend on another load is issued here, parameters first: the kernel is one latency
@@ -1756,17 +1791,20 @@ __global__ __launch_bounds__(NTHR) void ln_shift_kernel(const LnShiftArgs a) {
         else hipLaunchKernelGGL((KERN<8>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__);             \
     } while (0)
 
-void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s) {
+void launch_ln_shift(const LnShiftArgs &a0, int T, hipStream_t s) {
+    LnShiftArgs a = a0;
+    a.T = T;
+    const int G = T + (a.pf.n > 0 ? a.pf.blocks : 0);             // row workgroups first, then the prefetch workgroups
     const int wide_off = knobs().ln_256;                         // A/B switch
     if (T <= 64 && !wide_off) {                                   // few rows: 1024 threads per row
-        if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<1, 1024>), dim3(T), dim3(1024), 0, s, a);
-        else hipLaunchKernelGGL((ln_shift_kernel<2, 1024>), dim3(T), dim3(1024), 0, s, a);
+        if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<1, 1024>), dim3(G), dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL((ln_shift_kernel<2, 1024>), dim3(G), dim3(1024), 0, s, a);
         return;
     }
-    if (a.C <= 1024) hipLaunchKernelGGL((ln_shift_kernel<1, 256>), dim3(T), dim3(256), 0, s, a);
-    else if (a.C <= 2048) hipLaunchKernelGGL((ln_shift_kernel<2, 256>), dim3(T), dim3(256), 0, s, a);
-    else if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<4, 256>), dim3(T), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((ln_shift_kernel<8, 256>), dim3(T), dim3(256), 0, s, a);
+    if (a.C <= 1024) hipLaunchKernelGGL((ln_shift_kernel<1, 256>), dim3(G), dim3(256), 0, s, a);
+    else if (a.C <= 2048) hipLaunchKernelGGL((ln_shift_kernel<2, 256>), dim3(G), dim3(256), 0, s, a);
+    else if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<4, 256>), dim3(G), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ln_shift_kernel<8, 256>), dim3(G), dim3(256), 0, s, a);
 }
 
 template <int PT>
