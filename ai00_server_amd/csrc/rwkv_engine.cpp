@@ -939,7 +939,8 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
                 // the 3 B model); copies over K fill it
                 const long t64 = gemm_tile_blocks(shape, ps[0].W->rows, T);
                 const int K = ps[0].W->K;
-                for (int b = 2; b <= 4 && K / b >= 768 && t64 * (b - 1) < 448; ++b) ksplit = b;
+                // (only below one tile per CU: at 320 tiles — 512 rows — the copies cost more in slabs than they fill: 49.6 -> 47.1 k tok/s)
+                if (t64 < 256) for (int b = 2; b <= 4 && K / b >= 768 && t64 * (b - 1) < 448; ++b) ksplit = b;
             }
         }
         int blocks = 0;
@@ -1097,21 +1098,6 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
         auto prob = [&](const DMat *W, const Opd &x, int act, float *out, int ldo) {
             ProbSpec s; s.W = W; s.x = x; s.act = act; s.out = out; s.ldo = ldo; return s;
         };
-        // decode-shaped steps: spare workgroups of a row kernel touch the weights of the GEMM that follows it into the Infinity Cache
-        // (PrefetchArgs, rwkv_kernels.h); the row kernel itself occupies T of the 256 CUs
-        auto prefetch_of = [&](std::initializer_list<const DMat *> ms) {
-            PrefetchArgs pf{};
-            if (!kn.prefetch || T > 64) return pf;
-            for (const DMat *m : ms) {
-                if (!m) continue;
-                const size_t payload = m->fmt == W_F16 ? (size_t)m->rows * m->K * 2 : m->fmt == W_INT8 ? (size_t)m->rows * m->K : (size_t)m->rows * m->K / 2;
-                if (pf.n < PREFETCH_MAXSEG) { pf.ptr[pf.n] = m->data; pf.bytes[pf.n] = (unsigned)payload; ++pf.n; }
-                if (m->scales && pf.n < PREFETCH_MAXSEG) { pf.ptr[pf.n] = m->scales; pf.bytes[pf.n] = (unsigned)(m->bytes - payload); ++pf.n; }
-            }
-            pf.blocks = std::max(0, 256 - T);
-            pf.sink = (unsigned *)d_amax_i;
-            return pf;
-        };
         // single-token steps: the LayerNorm + token shift rides as a prologue of the GEMM that consumes it, and the launch
         // after that commits the shift state (LnProArgs / ShiftCommit in rwkv_kernels.h)
         auto ln_pro = [&](const LnShiftArgs &r, float *xx_pub) {
@@ -1137,7 +1123,6 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
                 LnProArgs lp = ln_pro(a, lnp_xx_att);
                 gemm(ps, T, FAM_GEMM, &lp);
             } else {
-                a.pf = prefetch_of({w.Wk, w.Wv, w.Wr, w.Wg});
                 launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
                 gemm(ps, T, FAM_GEMM);
             }
@@ -1146,7 +1131,6 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
             a.xx_out = xx; a.dx_out = dx;
             const int no_fuse = kn.no_v6_fuse, no_ln_fuse = kn.no_ln_fuse;
             att_fused = !no_fuse && !no_ln_fuse && v6_mix_ln_supported(T, C, Dm, hilo, np);
-            a.pf = prefetch_of({w.Wk, w.Wv, w.Wr, w.Wg, w.D1});
             if (!att_fused) launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
             const int no_wide = kn.no_v6_wide;                      // A/B: two tile-GEMM launches instead of the wide fused form
             if ((v6_mix_supported(T, C, Dm) || (v6_mix_wide_supported(T, C, Dm) && !no_wide)) && !no_fuse) {
@@ -1194,7 +1178,6 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
                 LnProArgs lp = ln_pro(a, lnp_xx_att);
                 gemm(ps, T, FAM_GEMM, &lp);
             } else {
-                a.pf = prefetch_of({w.Wr, w.Wk, w.Wv, w.w1, w.a1});
                 launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
                 gemm(ps, T, FAM_GEMM);
             }
@@ -1246,7 +1229,6 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
                 LnProArgs lp = ln_pro(f, lnp_xx_ffn);
                 gemm(ps, T, FAM_GEMM, &lp);
             } else {
-                f.pf = prefetch_of({w.Fk, info.version != 7 ? w.Fr : nullptr});
                 launch(FAM_ROW, [&] { launch_ln_shift(f, T, s_main); });
                 gemm(ps, T, FAM_GEMM);
             }

@@ -22,7 +22,6 @@ struct Knobs {
     int tile_ksplit = 1;             // RWKV_TILE_KSPLIT: K split of linear launches on the pipelined prefill kernel (0 = off)
     int no_dense = 0;                // RWKV_NO_DENSE: general row metadata on dense decode steps
     int ln_256 = 0;                  // RWKV_LN_256: 256-thread ln_shift everywhere
-    int prefetch = 1;                // RWKV_PREFETCH: Infinity-Cache prefetch of the next GEMM's weights by spare workgroups of the row kernels (PrefetchArgs)
     static Knobs from_env();
 };
 const Knobs &knobs();                // the calling thread's current set
@@ -158,21 +157,6 @@ bool v6_mix_ln_supported(int T, int C, int Dm, bool hilo, int np);   // the Laye
 void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s);
 
 
-// Weight prefetch into the Infinity Cache (decode-shaped steps).  A row kernel of a decode step keeps 32 of the 256 CUs busy and
-// moves almost nothing over HBM; the GEMM that follows it streams ~27 MB from a cold start.  Extra workgroups of the row kernel
-// (`blocks` of them, after the row blocks) touch one word of every 128-byte line of the NEXT GEMM's weights with default-policy
-// loads: the line is allocated in the memory-side cache (4 B per line cross into the CU), and the GEMM's non-temporal stream then
-// hits there — profiles/r3_exp_infinity_cache_prefetch.log: a 27.5 MB launch 7.7 us cold, 5.2-5.6 us after such a touch pass
-// (non-temporal touches do NOT allocate: no gain; a prefetcher running beside the STREAMING launches makes them slower).
-constexpr int PREFETCH_MAXSEG = 10;
-struct PrefetchArgs {
-    const void *ptr[PREFETCH_MAXSEG];
-    unsigned bytes[PREFETCH_MAXSEG];
-    int n = 0;                      // segments
-    int blocks = 0;                 // extra workgroups of the carrying launch that run the touch loop (0: no prefetch)
-    unsigned *sink = nullptr;       // never written (keeps the loads alive for the compiler)
-};
-
 struct LnShiftArgs {
     const float *x_in;
     float *x_out;                   // x_in + sum of partials (ping-pong residual stream)
@@ -191,8 +175,6 @@ struct LnShiftArgs {
     int ldh;
     float *xx_out, *dx_out;         // optional fp32 copies (V6 time-mix LoRA epilogue needs them)
     int C;
-    int T = 0;                      // rows (set by launch_ln_shift; workgroups beyond T run the prefetch loop)
-    PrefetchArgs pf;
 };
 void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s);
 

@@ -480,7 +480,6 @@ Knobs Knobs::from_env() {
     k.tile3_fill = knob_env("RWKV_TILE3_FILL", 65); k.tile_xcd = knob_env("RWKV_TILE_XCD", 1);
     k.tile_ksplit = knob_env("RWKV_TILE_KSPLIT", 1);
     k.no_dense = knob_env("RWKV_NO_DENSE", 0); k.ln_256 = knob_env("RWKV_LN_256", 0);
-    k.prefetch = knob_env("RWKV_PREFETCH", 1);
     return k;
 }
 static thread_local Knobs t_knobs;
@@ -1694,32 +1693,9 @@ __device__ __forceinline__ void row_layernorm(float4 (&v)[PT], int C, const floa
 }
 
 
-// touch loop of a prefetch workgroup `pb` of `pf.blocks` (PrefetchArgs, rwkv_kernels.h): one 4-byte default-policy load per 128-byte
-// line, 16 in flight per thread
-__device__ __forceinline__ void prefetch_touch(const PrefetchArgs &pf, int pb) {
-    const size_t stride = (size_t)pf.blocks * blockDim.x;                 // lines covered per sweep of the whole prefetch grid
-    unsigned acc = 0;
-    for (int s = 0; s < pf.n; ++s) {
-        const unsigned *base = (const unsigned *)pf.ptr[s];
-        const size_t nline = pf.bytes[s] >> 7;
-        for (size_t l0 = (size_t)pb * blockDim.x + threadIdx.x; l0 < nline; l0 += stride * 16) {
-            unsigned v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const size_t l = l0 + (size_t)j * stride;
-                v[j] = l < nline ? base[l * 32] : 0u;
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc ^= v[j];
-        }
-    }
-    if (acc == 0x9e3779b9u && pf.sink) pf.sink[0] = acc;                  // practically never: the loads must not be dead code
-}
-
 template <int PT, int NTHR>
 __global__ __launch_bounds__(NTHR) void ln_shift_kernel(const LnShiftArgs a) {
     __shared__ float red[2 * NTHR / 64];
-    if ((int)blockIdx.x >= a.T) { prefetch_touch(a.pf, (int)blockIdx.x - a.T); return; }
     const int t = blockIdx.x, C = a.C;
     TRACE_K(2, 0);
     // every load that does not depend on another load is issued here, parameters first: the kernel is one latency
@@ -1791,20 +1767,19 @@ __global__ __launch_bounds__(NTHR) void ln_shift_kernel(const LnShiftArgs a) {
         else hipLaunchKernelGGL((KERN<8>), dim3(GRID), dim3(256), 0, s, __VA_ARGS__);             \
     } while (0)
 
-void launch_ln_shift(const LnShiftArgs &a0, int T, hipStream_t s) {
-    LnShiftArgs a = a0;
-    a.T = T;
-    const int G = T + (a.pf.n > 0 ? a.pf.blocks : 0);             // row workgroups first, then the prefetch workgroups
+void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s) {
+    // (Spare workgroups of this launch touching the next GEMM's weights into the Infinity Cache were built and measured in round 3:
+    // a 32-slot step went from 2.25 to 3.00 ms — profiles/r3_exp_prefetch_by_row_kernel_workgroups.log — and the code was removed.)
     const int wide_off = knobs().ln_256;                         // A/B switch
     if (T <= 64 && !wide_off) {                                   // few rows: 1024 threads per row
-        if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<1, 1024>), dim3(G), dim3(1024), 0, s, a);
-        else hipLaunchKernelGGL((ln_shift_kernel<2, 1024>), dim3(G), dim3(1024), 0, s, a);
+        if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<1, 1024>), dim3(T), dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL((ln_shift_kernel<2, 1024>), dim3(T), dim3(1024), 0, s, a);
         return;
     }
-    if (a.C <= 1024) hipLaunchKernelGGL((ln_shift_kernel<1, 256>), dim3(G), dim3(256), 0, s, a);
-    else if (a.C <= 2048) hipLaunchKernelGGL((ln_shift_kernel<2, 256>), dim3(G), dim3(256), 0, s, a);
-    else if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<4, 256>), dim3(G), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((ln_shift_kernel<8, 256>), dim3(G), dim3(256), 0, s, a);
+    if (a.C <= 1024) hipLaunchKernelGGL((ln_shift_kernel<1, 256>), dim3(T), dim3(256), 0, s, a);
+    else if (a.C <= 2048) hipLaunchKernelGGL((ln_shift_kernel<2, 256>), dim3(T), dim3(256), 0, s, a);
+    else if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<4, 256>), dim3(T), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ln_shift_kernel<8, 256>), dim3(T), dim3(256), 0, s, a);
 }
 
 template <int PT>
