@@ -1023,6 +1023,8 @@ bool v6_mix_supported(int T, int C, int Dm) { return T <= 32 && C % 256 == 0 && 
 bool v6_mix_wide_supported(int T, int C, int Dm) { return T > 32 && C % 256 == 0 && (Dm == 32 || Dm == 64); }
 
 void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
+    // (the wide form — 40 blocks that each walk every strip — for 17..32 rows too: 2.250 -> 2.36 ms per 32-slot step,
+    // profiles/r3_exp_ab_v6mix_wide_for_32_rows.log; 100 blocks of 8 strips is the measured optimum between that and the 200-block split)
     const bool wide = a.T > 32;                                // v6_mix_wide_supported: one block per (mix, 32-token tile)
     // (17..32 rows as two NT = 1 token tiles — 200 workgroups that each pull W1_c + half of z — was measured and dropped: every
     // workgroup still pulls all of W1_c, so the launch's L2 traffic grows by half: 2.250 -> 2.267 ms per 32-slot step,
