@@ -1695,6 +1695,9 @@ __device__ __forceinline__ void row_layernorm(float4 (&v)[PT], int C, const floa
 }
 
 
+// (Four consecutive rows per block on prefill-shaped steps — a row whose predecessor the block has just normalised takes it from
+// registers instead of loading and normalising it again — was built and measured in round 3: slower everywhere, 70.2 -> 69.1 k tok/s at
+// 2048 rows and 37.2 -> 35.1 k at 256, where it leaves 64 blocks for 256 CUs; profiles/r3_exp_ln_rows.log.  One row per block stays.)
 template <int PT, int NTHR>
 __global__ __launch_bounds__(NTHR) void ln_shift_kernel(const LnShiftArgs a) {
     __shared__ float red[2 * NTHR / 64];

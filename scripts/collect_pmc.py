@@ -13,7 +13,7 @@ def run_pass(counter, tag, bench_args, parse_only=False):
     out = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}")
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "c", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--decode-only", "--steps", "12", "--warmup", "4"] + bench_args
+           sys.executable, os.path.join(ROOT, "bench.py"), "--decode-only", "--sweep", "", "--verify-steps", "0", "--steps", "12", "--warmup", "4"] + bench_args
     if not parse_only:
         import shutil
         shutil.rmtree(out, ignore_errors=True)

@@ -5,7 +5,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 P=$O/profiles_new
-TAG=${1:-r2}
+TAG=${1:-r3}
 mkdir -p $P
 export TMPDIR=/tmp
 cd /tmp
@@ -23,7 +23,10 @@ run_stats v6-3b_int8_b32 $BENCH --workload v6-3b --quant int8 --batch 32
 run_stats v6-3b_int8_b1 $BENCH --workload v6-3b --quant int8 --batch 1
 run_stats v6-7b_fp16_b8 $BENCH --workload v6-7b --quant none --batch 8
 run_stats v7-2.9b_nf4_b32 $BENCH --workload v7-2.9b --quant nf4 --batch 32
+run_stats v6-3b_fp16_b32 $BENCH --workload v6-3b --quant none --batch 32
 run_stats prefill_v6-3b_int8_32x256 python $R/scripts/prefill_probe.py v6-3b 1 32 256 2048
+DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 run_stats prefill_v6-3b_int8_chunk256 python $R/scripts/prefill_probe.py v6-3b 1 32 256 256
+DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 run_stats prefill_v7-2.9b_nf4_chunk256 python $R/scripts/prefill_probe.py v7-2.9b 2 32 256 256
 # MFMA utilisation (north_star): matrix-pipe busy cycles against shader busy cycles, decode B=32 and the prefill run
 for name in decode_v6-3b_int8_b32 prefill_v6-3b_int8; do
   rm -rf $O/pmc_$name
