@@ -816,7 +816,7 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
             }
             if (!best) throw RwkvError(RWKV_ERR_UNSUPPORTED, "cannot split inner dimension");
             ksb = best;
-            if (f_ksb && valid(f_ksb)) ksb = f_ksb;
+            if (f_ksb && f_ksb <= 8 && valid(f_ksb)) ksb = f_ksb;         // the partial-sum buffer holds 8 slabs (an override of 10 once wrote past it)
         }
         const int Kb = K / ksb;
         const int nslice = (Kb + KW - 1) / KW;                 // balanced: every wave owns the same number of slices

@@ -1396,6 +1396,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tile_kernel(const GemmLaunch 
 }
 
 // =====================================================================================
+// (Round 3 built the 256-row form of this kernel for the quantised formats — four strips per wave, 128 accumulators, one block per CU,
+// a third fewer bytes through the CU's L2 port per flop — and measured it: 395-563 TFLOP/s against 658-861 for this one on the same
+// matrices, V6-3B Int8 prefill 72.0 -> 59.0 k tok/s; with one wave per SIMD nothing covers the dequantisation and the LDS reads between
+// MFMAs.  profiles/r3_exp_tile_256x128_pipelined.log; the code was removed.)
 // Pipelined tile kernel (shape 10): 128 rows x 128 tokens per block, 4 waves, wave w owns strips {2w, 2w+1} x all 8 token tiles
 // (64 accumulator registers).  Per k-step the block moves (128 + 128) x 64 B through the CU's L2 port for 64 MFMAs — half
 // of what the 64x64 shapes move per MFMA, which is what bounds them (the port sustains ~56 B/clk, they need 128 B/clk at full
