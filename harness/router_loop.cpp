@@ -1,8 +1,11 @@
-// router_loop.cpp — include/rwkv_router.hpp over REAL engines: N replicas of one model (all on the device given, so the N>1
-// path can be exercised on a one-GPU box; in production each replica names its own device index), every replica driven by
-// its own thread, requests routed by prefix affinity then least busy (replicas only, no collective).
-// Prints one line per request: "<replica> <generated token ids...>"; tests/test_gpu_parity.py compares with the oracle.
-// Usage: router_loop <model.st> <n_replicas> <device> <max_batch> <chunk> <n_new> <prompt ...> [/ <prompt ...>]...
+// router_loop.cpp — include/rwkv_router.hpp over REAL engines: N replicas of one model, replica r on device devices[r % len] —
+// `0,1,2,3,4,5,6,7` puts one replica on each GPU of a node (the serving path of SURVEY §8e: router + one driving thread per
+// engine, no collective), `0` or `0,0` puts them all on one device so the N>1 path can be exercised on a one-GPU box.
+// Requests are routed by prefix affinity then least busy.  Prints one line per request: "<replica> <generated token ids...>"
+// (tests/test_gpu_parity.py compares with the oracle), then the follow-up request, "meta ..." and, on stderr, the wall time and
+// the aggregate rate of the first wave.
+// Usage: router_loop <model.st> <n_replicas> <device[,device...]> <max_batch> <chunk> <n_new> <prompt ...> [/ <prompt ...>]...
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,25 +19,42 @@ int main(int argc, char **argv) {
     try {
         std::ifstream f(argv[1], std::ios::binary);
         std::vector<uint8_t> st((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-        const int n_rep = std::atoi(argv[2]), dev = std::atoi(argv[3]), B = std::atoi(argv[4]), chunk = std::atoi(argv[5]), n_new = std::atoi(argv[6]);
+        const int n_rep = std::atoi(argv[2]), B = std::atoi(argv[4]), chunk = std::atoi(argv[5]), n_new = std::atoi(argv[6]);
+        std::vector<int> devices;
+        for (const char *p = argv[3]; *p;) {
+            char *end = nullptr;
+            devices.push_back((int)std::strtol(p, &end, 10));
+            if (end == p) { std::fprintf(stderr, "bad device list\n"); return 2; }
+            p = *end == ',' ? end + 1 : end;
+        }
+        if (devices.empty() || n_rep < 1) { std::fprintf(stderr, "bad device list\n"); return 2; }
         std::vector<rwkv::Tokens> prompts(1);
         for (int i = 7; i < argc; ++i) {
             if (!std::strcmp(argv[i], "/")) prompts.emplace_back();
             else prompts.back().push_back((uint32_t)std::strtoul(argv[i], nullptr, 10));
         }
         std::vector<rwkv::Runtime> rts;
-        for (int r = 0; r < n_rep; ++r) rts.push_back(rwkv::ModelBuilder(st.data(), st.size(), dev).build(B, chunk, rwkv::Precision::Fp16));
+        for (int r = 0; r < n_rep; ++r)
+            rts.push_back(rwkv::ModelBuilder(st.data(), st.size(), devices[(size_t)r % devices.size()]).build(B, chunk, rwkv::Precision::Fp16));
         std::vector<rwkv::Runtime *> es;
         for (auto &r : rts) es.push_back(&r);
         std::vector<rwkv::RoutedRequest> reqs(prompts.size());
         {
             rwkv::ReplicaRouter<rwkv::Runtime> router(es);
+            const auto t0 = std::chrono::steady_clock::now();
             for (size_t i = 0; i < prompts.size(); ++i) {
                 reqs[i].tokens = prompts[i];
                 reqs[i].max_new = n_new;
                 while (router.submit(&reqs[i]) < 0) std::this_thread::yield();   // every replica full: retry, like `enqueue`
             }
             router.drain();
+            {
+                const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                size_t toks = 0;
+                for (auto &q : reqs) toks += q.tokens.size() + q.generated.size();
+                std::fprintf(stderr, "first wave: %zu requests over %d replicas on %zu device(s): %.3f s, %.0f tokens/s (prompt + generated)\n",
+                             reqs.size(), n_rep, devices.size(), sec, (double)toks / sec);
+            }
             // second wave: request 0 again, extended by its own output — must return to the replica that cached it
             rwkv::RoutedRequest again;
             again.tokens = prompts[0];

@@ -764,11 +764,14 @@ def test_cpp_router_over_two_real_engines_on_one_device(tmp_path):
     ref = R.RwkvRef(t)
     ps = [prompt(ref, 120 + i, 5 + 2 * i) for i in range(6)]
     n_new = 6
-    args = [B.ROUTER_BIN, str(path), "2", "0", "3", "16", str(n_new)]
+    args = [B.ROUTER_BIN, str(path), "2", "0,0", "3", "16", str(n_new)]       # device list: replica r on devices[r % len]
     for i, p in enumerate(ps):
         args += ([] if i == 0 else ["/"]) + [str(x) for x in p]
     out = subprocess.run(args, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
+    assert "over 2 replicas on 2 device(s)" in out.stderr
+    bad = subprocess.run([B.ROUTER_BIN, str(path), "1", str(rt.lib().rwkv_device_count()), "1", "16", "1", "5"], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 1 and "adapter index out of range" in bad.stderr             # a replica on a device that does not exist
     lines = out.stdout.strip().splitlines()
     rows = [[int(x) for x in ln.split()] for ln in lines[:7]]
     for i, p in enumerate(ps):
