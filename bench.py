@@ -87,9 +87,20 @@ def spawn_ranks(n: int, argv: list[str]) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = p.wait() or rc
+    # a rank that dies leaves the others parked in the gloo barrier: when one exits non-zero the rest (the exact children started
+    # above) are terminated, so the run fails promptly instead of waiting for the rendezvous timeout
+    rc, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in live:
+                    q.terminate()
+        time.sleep(0.05)
     return rc
 
 
@@ -408,6 +419,8 @@ def host_description() -> dict:
 # ------------------------------------------------------------------------------------------------
 def selftest_dist(job, args):
     """Stand-in workload for the CPU test of the N > 1 path: same barrier / timing / reduction / line, no engine."""
+    if os.environ.get("BENCH_SELFTEST_FAIL_RANK") == str(job.rank):   # test hook: this rank dies mid-run
+        os._exit(3)
     job.barrier()
     t = time.perf_counter()
     time.sleep(0.002 * args.steps * (1 + job.rank))          # ranks finish at different times: MAX must pick the slowest

@@ -43,6 +43,16 @@ def test_under_torch_distributed_run_as_the_driver_launches_it():
     assert last_json(r.stdout)["n_gpus"] == 2
 
 
+def test_a_failing_rank_fails_the_run_promptly():
+    """rank 1 dies before the rendezvous completes its first barrier: the launcher must come back with its exit code instead of
+    leaving rank 0 parked in the barrier."""
+    import time
+    t = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "10", "--selftest-dist"], env=clean_env(BENCH_SELFTEST_FAIL_RANK="1"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and time.time() - t < 60
+
+
 def test_world_size_and_gpus_flag_must_agree():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-dist"], env=clean_env(WORLD_SIZE="1", RANK="0"),
                        capture_output=True, text=True, timeout=60)
