@@ -22,6 +22,7 @@ struct Knobs {
     int tile_ksplit = 1;             // RWKV_TILE_KSPLIT: K split of linear launches on the pipelined prefill kernel (0 = off)
     int no_dense = 0;                // RWKV_NO_DENSE: general row metadata on dense decode steps
     int ln_256 = 0;                  // RWKV_LN_256: 256-thread ln_shift everywhere
+    int ln_threads = 0;              // RWKV_LN_THREADS: threads per row of ln_shift on prefill-shaped steps (0 = 1024 up to 256 rows, 512 above; 256 / 512 / 1024 force)
     static Knobs from_env();
 };
 const Knobs &knobs();                // the calling thread's current set

@@ -480,6 +480,7 @@ Knobs Knobs::from_env() {
     k.tile3_fill = knob_env("RWKV_TILE3_FILL", 65); k.tile_xcd = knob_env("RWKV_TILE_XCD", 1);
     k.tile_ksplit = knob_env("RWKV_TILE_KSPLIT", 1);
     k.no_dense = knob_env("RWKV_NO_DENSE", 0); k.ln_256 = knob_env("RWKV_LN_256", 0);
+    k.ln_threads = knob_env("RWKV_LN_THREADS", 0);
     return k;
 }
 static thread_local Knobs t_knobs;
@@ -1783,6 +1784,22 @@ void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s) {
     if (T <= 64 && !wide_off) {                                   // few rows: 1024 threads per row
         if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<1, 1024>), dim3(T), dim3(1024), 0, s, a);
         else hipLaunchKernelGGL((ln_shift_kernel<2, 1024>), dim3(T), dim3(1024), 0, s, a);
+        return;
+    }
+    // prefill-shaped steps (measured, profiles/r3_exp_ln_threads.log): up to 256 rows the 1024-thread form is still ahead (+3 % on a
+    // 256-token chunk), above that 512 threads per row (+0.6 % at 2048 rows; 1024 there is -1.8 %: 2 blocks per CU).  The 256-thread
+    // form keeps ~250 VGPRs, i.e. 8 waves per CU.
+    int thr = knobs().ln_threads;
+    if (thr == 0) thr = T <= 256 ? 1024 : 512;
+    if (thr == 1024 && a.C <= 8192) {
+        if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<1, 1024>), dim3(T), dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL((ln_shift_kernel<2, 1024>), dim3(T), dim3(1024), 0, s, a);
+        return;
+    }
+    if (thr == 512 && a.C <= 8192) {
+        if (a.C <= 2048) hipLaunchKernelGGL((ln_shift_kernel<1, 512>), dim3(T), dim3(512), 0, s, a);
+        else if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<2, 512>), dim3(T), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((ln_shift_kernel<4, 512>), dim3(T), dim3(512), 0, s, a);
         return;
     }
     if (a.C <= 1024) hipLaunchKernelGGL((ln_shift_kernel<1, 256>), dim3(T), dim3(256), 0, s, a);
