@@ -151,6 +151,7 @@ struct V6MixArgs {
     int ldh, T, C, Dm;
     LnProArgs lnp;                  // lnp.x_in set: LayerNorm + shift computed in the kernel (z, xx, dx unused)
     const float *mu_x;              // with lnp: z = xx + dx * mu_x
+    int xcd_group = 0;              // wide form, set by launch_v6_mix: the five mixes of a token tile numbered onto one XCD
 };
 bool v6_mix_supported(int T, int C, int Dm);
 bool v6_mix_wide_supported(int T, int C, int Dm);                   // steps with more than 32 rows: block = (mix, 32-token tile), all strips

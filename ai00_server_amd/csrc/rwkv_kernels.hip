@@ -36,6 +36,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -818,10 +819,21 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = blockIdx.y;                                     // mix index
+    int c = blockIdx.y;                                           // mix index
     const int sg = blockIdx.x;                                    // strip group (8 strips of W2_c)
     const int C = a.C, Dm = a.Dm, T = a.T;
-    const int t0 = (int)blockIdx.z * NT * 16;                      // first token of this block's tile (decode form: 17..32 rows run two NT = 1 tiles)
+    int tz = blockIdx.z;
+    if constexpr (WIDE) {
+        // a.xcd_group (launch: gridDim.x == 1 and a multiple of 8 token tiles): the five blocks of a token tile read the same
+        // xx / dx / z tile, so they are numbered to land on ONE XCD (linear block id mod 8), back to back — the tile comes from
+        // HBM once and from that XCD's L2 four times, instead of five times from HBM through five L2s
+        if (a.xcd_group) {
+            const int id = (int)blockIdx.y + 5 * (int)blockIdx.z, xcd = id & 7, slot = id >> 3;
+            c = slot % 5;
+            tz = (slot / 5) * 8 + xcd;
+        }
+    }
+    const int t0 = tz * NT * 16;                                  // first token of this block's tile (decode form: 17..32 rows run two NT = 1 tiles)
     // DS = Dm/16 strips of W1_c (2 or 4)
     const int KT1 = C >> 5;                                       // k-tiles of W1 per strip
     const int kst = KT1 >> 3;                                     // k-steps per wave in phase 1 (C/8/32)
@@ -1039,8 +1051,10 @@ void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
     if (wide) {
         const int ntile = (a.T + 31) / 32;
         grid = dim3(std::max(1, std::min(8, 256 / (5 * ntile))), 5, ntile);   // fill the chip when the step has few token tiles
-        if (a.Dm == 32) { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 2, false, true>), grid, block, lds, s, a); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 2, false, true>), grid, block, lds, s, a); }
-        else { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 4, false, true>), grid, block, lds, s, a); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 4, false, true>), grid, block, lds, s, a); }
+        V6MixArgs b = a;
+        b.xcd_group = (grid.x == 1 && ntile % 8 == 0 && knobs().tile_xcd) ? 1 : 0;
+        if (a.Dm == 32) { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 2, false, true>), grid, block, lds, s, b); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 2, false, true>), grid, block, lds, s, b); }
+        else { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 4, false, true>), grid, block, lds, s, b); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 4, false, true>), grid, block, lds, s, b); }
         return;
     }
     static bool attr_done[16] = {false};
@@ -2016,25 +2030,6 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
 // to ~20 LDS reads + 48 FMAs + 16 DPP adds.
 // =====================================================================================
 constexpr int WKV_CH = 32;                               // tokens per chunk: 8 per wave in the parallel phases
-template <int DD>
-__device__ __forceinline__ float wkv_decay_dot(const f16x8 (&d2r)[DD / 8], const float *tdl) {
-    constexpr int PER8 = DD / 32;
-    float ps[4];
-#pragma unroll
-    for (int part = 0; part < 4; ++part) {
-        float dsum = 0.f;
-#pragma unroll
-        for (int g8 = 0; g8 < PER8; ++g8) {
-            const int d8 = part * PER8 + g8;
-            const f16x8 wv = d2r[d8];
-            const float4 t0v = *(const float4 *)(tdl + d8 * 8), t1v = *(const float4 *)(tdl + d8 * 8 + 4);
-            dsum += (float)wv[0] * t0v.x + (float)wv[1] * t0v.y + (float)wv[2] * t0v.z + (float)wv[3] * t0v.w +
-                    (float)wv[4] * t1v.x + (float)wv[5] * t1v.y + (float)wv[6] * t1v.z + (float)wv[7] * t1v.w;
-        }
-        ps[part] = dsum;
-    }
-    return (ps[0] + ps[1]) + (ps[2] + ps[3]);
-}
 template <int VER, int DD>
 __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
     __shared__ __attribute__((aligned(16))) float s_r[WKV_CH][64], s_k[WKV_CH][64], s_v[WKV_CH][64], s_w[WKV_CH][64];
@@ -2058,10 +2053,9 @@ __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
     for (int aa = 0; aa < 4; ++aa) T[aa] = __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4 *)(st + (aa * 16 + ig) * 64 + jg * 4)));
     if (VER != 7 && tid < 64) s_u[tid] = a.u[cb + tid];
     // per-channel parameters of phase A (channel = lane)
-    float kk_p = 0.f, ka_p = 0.f, wconst = 0.f, decay0 = 0.f;
+    float kk_p = 0.f, ka_p = 0.f, wconst = 0.f;
     if (VER == 7) { kk_p = a.k_k[cb + lane]; ka_p = a.k_a[cb + lane]; }
     if (VER == 5) wconst = a.wdec_or_decay[cb + lane];
-    if (VER == 6) decay0 = a.wdec_or_decay[cb + lane];
 
     for (int c0 = 0; c0 < nrow; c0 += WKV_CH) {
         const int n = min(WKV_CH, nrow - c0);
@@ -2092,26 +2086,47 @@ __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
             }
         }
         if (c0 == 0) TRACE_K(3, 1);
-        if (VER == 6) {                            // td rows of the chunk -> LDS (coalesced), read back as broadcasts
-            const float *tdp = a.td + (long)(row0 + c0) * Dd;
-            for (int i = tid * 4; i < n * Dd; i += 256 * 4) *(float4 *)(s_td + i) = *(const float4 *)(tdp + i);
-            __syncthreads();
-        }
-        f16x8 d2r[DD / 8];                               // V6: this channel's row of D2 (L2-hot; scoped to the phase so that
-        if (VER == 6) {                            // its 64 registers are free again during the recurrence)
-            const _Float16 *d2 = a.D2 + (long)(cb + lane) * Dd;
+        if (VER == 6) {
+            // decay LoRA stage 2 on the matrix pipe: dd[ch][t] = sum_d D2[ch][d] * td[t][d] is a 64 x 32 x Dd product per chunk.
+            // Wave w owns channels 16w .. 16w+15 (A = its rows of D2, f16 as stored), both 16-token tiles; td (fp32) goes in as
+            // an f16 (hi, lo) pair, so a product is exact and the sum is an fp32 accumulation as before — in MFMA order instead of
+            // the decode kernel's four partial sums, which the oracle's tolerance covers.  (The VALU form — every lane 64 FMAs +
+            // 64 converts per token over LDS broadcasts — was 4 us of a chunk's 15, profiles/r3_trace_wkv_chunk.log.)
+            constexpr int KS = DD / 32;
+            const _Float16 *d2 = a.D2 + (long)(cb + wave * 16 + (lane & 15)) * Dd + (lane >> 4) * 8;
+            f16x8 af[KS];
 #pragma unroll
-            for (int d8 = 0; d8 < DD / 8; ++d8) d2r[d8] = *(const f16x8 *)(d2 + d8 * 8);
+            for (int ks = 0; ks < KS; ++ks) af[ks] = *(const f16x8 *)(d2 + ks * 32);
+            const float4 dec4 = *(const float4 *)(a.wdec_or_decay + cb + wave * 16 + (lane >> 4) * 4);
+#pragma unroll
+            for (int tile = 0; tile < WKV_CH / 16; ++tile) {
+                const int tt = tile * 16 + (lane & 15);
+                const float *tdp = a.td + (long)(row0 + c0 + min(tt, n - 1)) * Dd + (lane >> 4) * 8;
+                float4 t0[KS], t1[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) { t0[ks] = *(const float4 *)(tdp + ks * 32); t1[ks] = *(const float4 *)(tdp + ks * 32 + 4); }
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const float tv[8] = {t0[ks].x, t0[ks].y, t0[ks].z, t0[ks].w, t1[ks].x, t1[ks].y, t1[ks].z, t1[ks].w};
+                    f16x8 bh, bl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { _Float16 hh, ll; split_hilo(tv[e], hh, ll); bh[e] = hh; bl[e] = ll; }
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks], bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks], bl, acc, 0, 0, 0);
+                }
+                if (tt < n) {
+                    float4 wv;
+                    wv.x = expf(-expf(dec4.x + acc[0])); wv.y = expf(-expf(dec4.y + acc[1]));
+                    wv.z = expf(-expf(dec4.z + acc[2])); wv.w = expf(-expf(dec4.w + acc[3]));
+                    *(float4 *)(&s_w[tt][wave * 16 + (lane >> 4) * 4]) = wv;
+                }
+            }
         }
         for (int tt = wave; tt < n; tt += 4) {
             if (VER == 5) {
                 s_w[tt][lane] = wconst;
-            } else if (VER == 6) {
-                // decay LoRA stage 2 in the decode kernel's order: four partial sums over Dd/4, combined (p0+p1)+(p2+p3)
-                const float *tdl = s_td + tt * Dd;
-                const float dd = wkv_decay_dot<DD>(d2r, tdl);
-                s_w[tt][lane] = expf(-expf(decay0 + dd));
-            } else {
+            } else if (VER == 7) {
                 const float av = s_ka[tt][lane];
                 float k = s_k[tt][lane], v = s_v[tt][lane];
                 float kk = k * kk_p;
@@ -2132,33 +2147,40 @@ __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
         float4 uq = make_float4(0.f, 0.f, 0.f, 0.f);
         if (VER != 7) uq = *(const float4 *)(s_u + jg * 4);
         // one wave per SIMD: no other wave hides the LDS latency, so four tokens' LDS rows are fetched per trip
+        // two state columns per instruction (v_pk_mul_f32 / v_pk_fma_f32 run at twice the scalar rate, and the recurrence is
+        // VALU-issue-bound: two waves per SIMD, nothing else to hide behind): every element sees the operations it saw before
+        // (kv = k*v; o += r*(u*kv + S); S = kv + w*S), only the four products of an output are added pairwise
         auto step = [&](int tt, const float4 &rq, const float4 &kq, const float4 &wq, const float4 &nk, const float4 &ka, const float (&vp4)[4]) {
             float outp[4];
+            const f32x2 r01 = {rq.x, rq.y}, r23 = {rq.z, rq.w}, k01 = {kq.x, kq.y}, k23 = {kq.z, kq.w}, w01 = {wq.x, wq.y}, w23 = {wq.z, wq.w};
             if (VER != 7) {
+                const f32x2 u01 = {uq.x, uq.y}, u23 = {uq.z, uq.w};
 #pragma unroll
                 for (int aa = 0; aa < 4; ++aa) {
-                    const float vp = vp4[aa];
-                    float4 &S = T[aa];
-                    float o, kv;
-                    kv = kq.x * vp; o = rq.x * (uq.x * kv + S.x); S.x = kv + wq.x * S.x;
-                    kv = kq.y * vp; o += rq.y * (uq.y * kv + S.y); S.y = kv + wq.y * S.y;
-                    kv = kq.z * vp; o += rq.z * (uq.z * kv + S.z); S.z = kv + wq.z * S.z;
-                    kv = kq.w * vp; o += rq.w * (uq.w * kv + S.w); S.w = kv + wq.w * S.w;
-                    outp[aa] = sum16(o);
+                    const f32x2 vp = {vp4[aa], vp4[aa]};
+                    f32x2 S0 = {T[aa].x, T[aa].y}, S1 = {T[aa].z, T[aa].w};
+                    const f32x2 kv0 = k01 * vp, kv1 = k23 * vp;
+                    f32x2 o2 = r01 * __builtin_elementwise_fma(u01, kv0, S0);
+                    o2 = __builtin_elementwise_fma(r23, __builtin_elementwise_fma(u23, kv1, S1), o2);
+                    S0 = __builtin_elementwise_fma(w01, S0, kv0);
+                    S1 = __builtin_elementwise_fma(w23, S1, kv1);
+                    T[aa] = make_float4(S0[0], S0[1], S1[0], S1[1]);
+                    outp[aa] = sum16(o2[0] + o2[1]);
                 }
             } else {
+                const f32x2 n01 = {nk.x, nk.y}, n23 = {nk.z, nk.w}, a01 = {ka.x, ka.y}, a23 = {ka.z, ka.w};
 #pragma unroll
                 for (int aa = 0; aa < 4; ++aa) {
-                    const float vp = vp4[aa];
-                    float4 &S = T[aa];
-                    float sa = S.x * nk.x + S.y * nk.y + S.z * nk.z + S.w * nk.w;
-                    sa = sum16(sa);
-                    S.x = S.x * wq.x + sa * ka.x + vp * kq.x;
-                    S.y = S.y * wq.y + sa * ka.y + vp * kq.y;
-                    S.z = S.z * wq.z + sa * ka.z + vp * kq.z;
-                    S.w = S.w * wq.w + sa * ka.w + vp * kq.w;
-                    const float o = S.x * rq.x + S.y * rq.y + S.z * rq.z + S.w * rq.w;
-                    outp[aa] = sum16(o);
+                    const f32x2 vp = {vp4[aa], vp4[aa]};
+                    f32x2 S0 = {T[aa].x, T[aa].y}, S1 = {T[aa].z, T[aa].w};
+                    const f32x2 d2 = __builtin_elementwise_fma(S1, n23, S0 * n01);
+                    const float sa = sum16(d2[0] + d2[1]);
+                    const f32x2 sa2 = {sa, sa};
+                    S0 = __builtin_elementwise_fma(vp, k01, __builtin_elementwise_fma(sa2, a01, S0 * w01));
+                    S1 = __builtin_elementwise_fma(vp, k23, __builtin_elementwise_fma(sa2, a23, S1 * w23));
+                    T[aa] = make_float4(S0[0], S0[1], S1[0], S1[1]);
+                    const f32x2 o2 = __builtin_elementwise_fma(S1, r23, S0 * r01);
+                    outp[aa] = sum16(o2[0] + o2[1]);
                 }
             }
             if (jg == 0) {

@@ -93,6 +93,34 @@ def test_every_switch_gives_the_oracles_answers(models, switch, value):
                 os.environ[k] = v
 
 
+def test_wide_mix_numbered_by_xcd_on_a_1024_row_step(models):
+    """Steps whose token tiles come in multiples of eight (and are too many to split a mix's strips over several blocks) number the
+    five mix blocks of a token tile onto one XCD (v6_mix_kernel, a.xcd_group): a 1024-row step takes that path, RWKV_TILE_XCD=0 the
+    plain numbering; both must give the oracle's logits, and the same bits as each other (only the block -> tile map differs)."""
+    tens, st = models[6]
+    B, L = 32, 32
+    ps = [[t % 1024 for t in R.synth_prompt(90 + b, L)] for b in range(B)]
+    rb = R.RwkvRefBatch(tens, 0, 0)
+    want = rb.prefill(ps, rb.init_states(B))
+    res = []
+    for off in (False, True):
+        if off:
+            os.environ["RWKV_TILE_XCD"] = "0"
+        try:
+            eng = rt.ModelBuilder(st).build(max_batch=B, token_chunk_size=1024, precision=rt.Precision.Fp16)
+        finally:
+            os.environ.pop("RWKV_TILE_XCD", None)
+        inp = rt.RnnInput([rt.RnnInputBatch(list(p), rt.RnnOption.Last) for p in ps])
+        inp, outs = eng.infer(inp)
+        assert inp.num_token() == 0                                  # one 1024-row step
+        got = np.stack([o[-1] for o in outs])
+        for b in range(B):
+            assert float(np.abs(got[b] - want[b]).max()) <= tol(want[b])
+        res.append(got)
+        eng.close()
+    assert np.array_equal(res[0], res[1])
+
+
 def test_switches_are_frozen_per_engine(models):
     """An engine keeps the choices it was created with: flipping the environment afterwards changes nothing for it (its captured
     graphs stay valid), while the next engine picks the new value up."""
