@@ -1868,6 +1868,18 @@ void launch_ln_out(const LnOutArgs &a, int n_out, hipStream_t s) { ROW_DISPATCH(
 // followed by GroupNorm over the head (eps 64e-5), gate, and (v7) the r.k.r_k bonus.
 // =====================================================================================
 __device__ __forceinline__ float sum16(float v) { return row_sum16(v); }   // the 16 lanes sharing (tid>>4) are one DPP row
+// Four row sums at once: lane j of the row ends up with the sum of o[j & 3] over the row's 16 lanes.  The same addition tree as
+// four row_sum16 (lane pairs, then pairs of pairs, then the four quads), so the same bits — but after each of the first two levels a
+// lane keeps only the half of the values its partner does not, which makes it 5 DPP adds + 6 selects instead of 16 DPP adds.
+__device__ __forceinline__ float row_sum16x4(float o0, float o1, float o2, float o3, int j) {
+    const bool b0 = j & 1, b1 = j & 2;
+    const float p0 = (b0 ? o1 : o0) + dpp_f32<0xB1>(b0 ? o0 : o1);
+    const float p1 = (b0 ? o3 : o2) + dpp_f32<0xB1>(b0 ? o2 : o3);
+    float q = (b1 ? p1 : p0) + dpp_f32<0x4E>(b1 ? p0 : p1);
+    q += dpp_f32<0x124>(q);
+    q += dpp_f32<0x128>(q);
+    return q;
+}
 
 // Decode form (one row per sequence; also correct for several): <= 102 VGPRs, 5 blocks per CU = 1280 (B=32 x 40 heads)
 // in one generation.  Steps in which a sequence has several rows use wkv_chunk_kernel below.
@@ -2031,16 +2043,14 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
 // =====================================================================================
 constexpr int WKV_CH = 32;                               // tokens per chunk: 8 per wave in the parallel phases
 template <int VER, int DD>
-__global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
+__global__ __launch_bounds__(256, VER == 7 ? 2 : 3) void wkv_chunk_kernel(const WkvArgs a) {
     __shared__ __attribute__((aligned(16))) float s_r[WKV_CH][64], s_k[WKV_CH][64], s_v[WKV_CH][64], s_w[WKV_CH][64];
-    // kappa rows ([0]) and kappa*a rows ([1]) of V7 in ONE array: V6 reuses the pair as the chunk's td rows [WKV_CH][Dd], which
-    // for Dd = 128 (7B) needs both halves back to back — two separate arrays are not guaranteed to be adjacent in LDS
-    __shared__ __attribute__((aligned(16))) float s_kka[2][WKV_CH][64], s_o[WKV_CH][64];
+    // kappa rows ([0]) and kappa*a rows ([1]) exist for V7 only: V5 / V6 keep 40 KiB of LDS and run three blocks per CU (a launch of
+    // 1280 blocks is 1.7 rounds of 768 instead of 2.5 of 512)
+    __shared__ __attribute__((aligned(16))) float s_kka[VER == 7 ? 2 : 1][VER == 7 ? WKV_CH : 1][64], s_o[WKV_CH][64];
     __shared__ __attribute__((aligned(16))) float s_u[64];
-    float (&s_kk)[WKV_CH][64] = s_kka[0];
-    float (&s_ka)[WKV_CH][64] = s_kka[1];
-    static_assert(DD <= 128, "td rows of a chunk must fit s_kka");
-    float *s_td = &s_kka[0][0][0];                       // V6: td rows of the chunk [WKV_CH][Dd]
+    auto &s_kk = s_kka[0];
+    auto &s_ka = s_kka[VER == 7 ? 1 : 0];
     const int seq = blockIdx.x, h = blockIdx.y;
     const int tid = threadIdx.x, ig = tid >> 4, jg = tid & 15, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2165,7 +2175,7 @@ __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
                     S0 = __builtin_elementwise_fma(w01, S0, kv0);
                     S1 = __builtin_elementwise_fma(w23, S1, kv1);
                     T[aa] = make_float4(S0[0], S0[1], S1[0], S1[1]);
-                    outp[aa] = sum16(o2[0] + o2[1]);
+                    outp[aa] = o2[0] + o2[1];
                 }
             } else {
                 const f32x2 n01 = {nk.x, nk.y}, n23 = {nk.z, nk.w}, a01 = {ka.x, ka.y}, a23 = {ka.z, ka.w};
@@ -2180,13 +2190,11 @@ __global__ __launch_bounds__(256, 2) void wkv_chunk_kernel(const WkvArgs a) {
                     S1 = __builtin_elementwise_fma(vp, k23, __builtin_elementwise_fma(sa2, a23, S1 * w23));
                     T[aa] = make_float4(S0[0], S0[1], S1[0], S1[1]);
                     const f32x2 o2 = __builtin_elementwise_fma(S1, r23, S0 * r01);
-                    outp[aa] = sum16(o2[0] + o2[1]);
+                    outp[aa] = o2[0] + o2[1];
                 }
             }
-            if (jg == 0) {
-#pragma unroll
-                for (int aa = 0; aa < 4; ++aa) s_o[tt][aa * 16 + ig] = outp[aa];
-            }
+            const float q = row_sum16x4(outp[0], outp[1], outp[2], outp[3], jg);    // lane jg < 4 holds output aa = jg
+            if (jg < 4) s_o[tt][jg * 16 + ig] = q;
         };
         for (int t4 = 0; t4 < n; t4 += 4) {
             float4 rq[4], kq[4], wq[4], nk[4], ka[4];
