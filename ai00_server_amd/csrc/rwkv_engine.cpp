@@ -1140,6 +1140,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
                 for (int c = 0; c < 5; ++c) { m.W2[c] = w.W2[c]->data; m.mu[c] = w.mu[1 + c]; m.ohi[c] = opA[1 + c].hi; m.olo[c] = opA[1 + c].lo; }
                 m.zhi = opA[0].hi; m.zlo = opA[0].lo; m.ldz = C;
                 m.xx = xx; m.dx = dx; m.ldh = C; m.T = T; m.C = C; m.Dm = Dm;
+                m.mg_hi = opM.hi; m.mg_lo = opM.lo;               // scratch of the two-launch form (T x 5 Dm halves, like the unfused path's operand)
                 if (att_fused) { m.lnp = ln_pro(a, lnp_xx_att); m.mu_x = w.mu[0]; }
                 launch(FAM_GEMM, [&] { launch_v6_mix(m, hilo, s_main); });
             } else {

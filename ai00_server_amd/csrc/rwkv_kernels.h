@@ -22,6 +22,7 @@ struct Knobs {
     int tile_ksplit = 1;             // RWKV_TILE_KSPLIT: K split of linear launches on the pipelined prefill kernel (0 = off)
     int no_dense = 0;                // RWKV_NO_DENSE: general row metadata on dense decode steps
     int ln_256 = 0;                  // RWKV_LN_256: 256-thread ln_shift everywhere
+    int v6_split_min_t = 512;        // RWKV_V6_SPLIT_MIN_T: rows from which the wide V6 mix runs as two launches (v6_mix_apply_kernel)
     int ln_threads = 0;              // RWKV_LN_THREADS: threads per row of ln_shift on prefill-shaped steps (0 = 1024 up to 256 rows, 512 above; 256 / 512 / 1024 force)
     static Knobs from_env();
 };
@@ -151,7 +152,7 @@ struct V6MixArgs {
     int ldh, T, C, Dm;
     LnProArgs lnp;                  // lnp.x_in set: LayerNorm + shift computed in the kernel (z, xx, dx unused)
     const float *mu_x;              // with lnp: z = xx + dx * mu_x
-    int xcd_group = 0;              // wide form, set by launch_v6_mix: the five mixes of a token tile numbered onto one XCD
+    _Float16 *mg_hi = nullptr, *mg_lo = nullptr;   // scratch for the two-launch form (>= 512 rows): m_c tiles [5][T/32][32][Dm]
 };
 bool v6_mix_supported(int T, int C, int Dm);
 bool v6_mix_wide_supported(int T, int C, int Dm);                   // steps with more than 32 rows: block = (mix, 32-token tile), all strips
@@ -177,6 +178,7 @@ struct LnShiftArgs {
     int ldh;
     float *xx_out, *dx_out;         // optional fp32 copies (V6 time-mix LoRA epilogue needs them)
     int C;
+    int xcd_rows = 0;               // set by launch_ln_shift on prefill-shaped steps: an XCD's blocks own a contiguous run of rows
 };
 void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s);
 

@@ -482,6 +482,7 @@ Knobs Knobs::from_env() {
     k.tile_ksplit = knob_env("RWKV_TILE_KSPLIT", 1);
     k.no_dense = knob_env("RWKV_NO_DENSE", 0); k.ln_256 = knob_env("RWKV_LN_256", 0);
     k.ln_threads = knob_env("RWKV_LN_THREADS", 0);
+    k.v6_split_min_t = knob_env("RWKV_V6_SPLIT_MIN_T", 512);
     return k;
 }
 static thread_local Knobs t_knobs;
@@ -814,25 +815,19 @@ int gemm_max_rounds(int fmt, int NT, bool hilo) { return NT == 4 ? 2 : (fmt == W
 // tile, computes m_c for its tokens once and then walks ALL strips of W2_c (8 waves, strip = wave, wave+8, ...).  Per block:
 // z tile 160 KB + W1_c 164 KB + W2_c 164 KB + the xx/dx tile, against 5 x C/16 x T/16 tiles of work: one launch of ~15 us
 // for a 512-row step instead of the two tile-GEMM launches (W1: 24 workgroups, 25 us; W2 with K = 32: 46 us) it replaces.
-template <int NT, bool HILO, int DS, bool LNP, bool WIDE = false>
+// SPLIT (steps of >= 512 rows, a multiple of 32): the wide form taken apart at its barrier.  As one launch every (mix, token tile)
+// block pulls the tile's xx / dx rows (655 KB of its 1.3 MB) and a launch of 320 such blocks on 256 CUs is two rounds.  P1ONLY stops
+// after phase 1 and leaves m_c in HBM (1.3 MB per step); v6_mix_apply_kernel then runs phase 2 per (8 strips, token tile) for all five
+// mixes — xx / dx are read once instead of five times, 1280 small blocks balance.
+template <int NT, bool HILO, int DS, bool LNP, bool WIDE = false, bool P1ONLY = false>
 __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int c = blockIdx.y;                                           // mix index
+    const int c = blockIdx.y;                                     // mix index
     const int sg = blockIdx.x;                                    // strip group (8 strips of W2_c)
     const int C = a.C, Dm = a.Dm, T = a.T;
-    int tz = blockIdx.z;
-    if constexpr (WIDE) {
-        // a.xcd_group (launch: gridDim.x == 1 and a multiple of 8 token tiles): the five blocks of a token tile read the same
-        // xx / dx / z tile, so they are numbered to land on ONE XCD (linear block id mod 8), back to back — the tile comes from
-        // HBM once and from that XCD's L2 four times, instead of five times from HBM through five L2s
-        if (a.xcd_group) {
-            const int id = (int)blockIdx.y + 5 * (int)blockIdx.z, xcd = id & 7, slot = id >> 3;
-            c = slot % 5;
-            tz = (slot / 5) * 8 + xcd;
-        }
-    }
+    const int tz = blockIdx.z;
     const int t0 = tz * NT * 16;                                  // first token of this block's tile (decode form: 17..32 rows run two NT = 1 tiles)
     // DS = Dm/16 strips of W1_c (2 or 4)
     const int KT1 = C >> 5;                                       // k-tiles of W1 per strip
@@ -963,9 +958,16 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
         f16x4 hh, ll;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { _Float16 x, y; split_hilo(tanhf(v[r]), x, y); hh[r] = x; ll[r] = y; }
-        *(f16x4 *)(m_hi + t * mstride + d * 16 + (lane >> 4) * 4) = hh;
-        if constexpr (HILO) *(f16x4 *)(m_lo + t * mstride + d * 16 + (lane >> 4) * 4) = ll;
+        if constexpr (P1ONLY) {
+            const long mo = (((long)c * gridDim.z + tz) * (NT * 16) + t) * Dm + d * 16 + (lane >> 4) * 4;
+            *(f16x4 *)(a.mg_hi + mo) = hh;
+            if constexpr (HILO) *(f16x4 *)(a.mg_lo + mo) = ll;
+        } else {
+            *(f16x4 *)(m_hi + t * mstride + d * 16 + (lane >> 4) * 4) = hh;
+            if constexpr (HILO) *(f16x4 *)(m_lo + t * mstride + d * 16 + (lane >> 4) * 4) = ll;
+        }
     }
+    if constexpr (P1ONLY) return;
     __syncthreads();
     TRACE_K(0, 3);
     // ---- phase 2: a strip of W2_c times m_c, lerp epilogue.  Decode form: strip sg*8 + wave, operands prefetched before
@@ -1032,6 +1034,73 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     TRACE_K(0, 4);
 }
 
+// Phase 2 of the split form: block = (8 strips of the C rows, one 32-token tile), wave = one strip, all five mixes.
+template <bool HILO, int DS>
+__global__ __launch_bounds__(512) void v6_mix_apply_kernel(const V6MixArgs a) {
+    constexpr int NT = 2, Dm = DS * 16, mstride = Dm + 8;
+    __shared__ __attribute__((aligned(16))) _Float16 m_hi[5 * NT * 16 * mstride], m_lo[HILO ? 5 * NT * 16 * mstride : 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = a.C, T = a.T, tz = blockIdx.y, t0 = tz * NT * 16, ntile = gridDim.y;
+    const int strip = min((int)blockIdx.x * 8 + wave, (C >> 4) - 1);      // clamped: the last group's spare waves redo the last strip
+    const int r0 = strip * 16 + (lane >> 4) * 4;
+    const act_t bxx = act_buf(a.xx), bdx = act_buf(a.dx);
+    // everything this wave needs, issued before the m tiles are staged
+    float4 xxv[NT], dxv[NT], muv[5];
+    u32x4 w2[5][DS / 2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int t = min(t0 + nt * 16 + (lane & 15), T - 1);
+        xxv[nt] = act_ld4(bxx, (long)t * C + r0);
+        dxv[nt] = act_ld4(bdx, (long)t * C + r0);
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+#pragma unroll
+        for (int ks = 0; ks < DS / 2; ++ks) w2[c][ks] = ((const u32x4 *)a.W2[c])[((long)strip * (DS / 2) + ks) * 64 + lane];
+        muv[c] = *(const float4 *)(a.mu[c] + r0);
+    }
+    // m_c tiles of this token tile: 5 x 32 x Dm halves, 16-byte pieces
+    constexpr int PPR = Dm / 8, NP = 5 * NT * 16 * PPR;                    // pieces per token row, pieces in all
+    for (int i = tid; i < NP; i += 512) {
+        const int c = i / (NT * 16 * PPR), rem = i - c * (NT * 16 * PPR), t = rem / PPR, d8 = rem - t * PPR;
+        const long go = (((long)c * ntile + tz) * (NT * 16) + t) * Dm + d8 * 8;
+        *(u32x4 *)(m_hi + (c * NT * 16 + t) * mstride + d8 * 8) = *(const u32x4 *)(a.mg_hi + go);
+        if constexpr (HILO) *(u32x4 *)(m_lo + (c * NT * 16 + t) * mstride + d8 * 8) = *(const u32x4 *)(a.mg_lo + go);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const act_t boh = act_buf(a.ohi[c]), bol = act_buf(a.olo[c]);
+        f32x4 o[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < DS / 2; ++ks) {
+            const f16x8 af = __builtin_bit_cast(f16x8, w2[c][ks]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int off = (c * NT * 16 + nt * 16 + (lane & 15)) * mstride + ks * 32 + (lane >> 4) * 8;
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, *(const f16x8 *)(m_hi + off), o[nt], 0, 0, 0);
+                if constexpr (HILO) o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, *(const f16x8 *)(m_lo + off), o[nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int t = t0 + nt * 16 + (lane & 15);
+            if (t < T) {
+                const float4 xx = xxv[nt], dx = dxv[nt];
+                float4 r;
+                r.x = xx.x + dx.x * (muv[c].x + o[nt][0]);
+                r.y = xx.y + dx.y * (muv[c].y + o[nt][1]);
+                r.z = xx.z + dx.z * (muv[c].z + o[nt][2]);
+                r.w = xx.w + dx.w * (muv[c].w + o[nt][3]);
+                act_store_operand4(boh, bol, a.olo[c] != nullptr, opd_off(t, r0, a.ldh), r);
+            }
+        }
+    }
+}
+
 bool v6_mix_supported(int T, int C, int Dm) { return T <= 32 && C % 256 == 0 && (Dm == 32 || Dm == 64); }
 bool v6_mix_wide_supported(int T, int C, int Dm) { return T > 32 && C % 256 == 0 && (Dm == 32 || Dm == 64); }
 
@@ -1051,8 +1120,19 @@ void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
     if (wide) {
         const int ntile = (a.T + 31) / 32;
         grid = dim3(std::max(1, std::min(8, 256 / (5 * ntile))), 5, ntile);   // fill the chip when the step has few token tiles
-        V6MixArgs b = a;
-        b.xcd_group = (grid.x == 1 && ntile % 8 == 0 && knobs().tile_xcd) ? 1 : 0;
+        const V6MixArgs &b = a;
+        if (a.T >= knobs().v6_split_min_t && a.T % 32 == 0 && a.mg_hi && (!hilo || a.mg_lo)) {
+            grid = dim3(1, 5, ntile);
+            const dim3 g2((a.C / 16 + 7) / 8, ntile);
+            if (a.Dm == 32) {
+                if (hilo) { hipLaunchKernelGGL((v6_mix_kernel<2, true, 2, false, true, true>), grid, block, lds, s, b); hipLaunchKernelGGL((v6_mix_apply_kernel<true, 2>), g2, block, 0, s, b); }
+                else { hipLaunchKernelGGL((v6_mix_kernel<2, false, 2, false, true, true>), grid, block, lds, s, b); hipLaunchKernelGGL((v6_mix_apply_kernel<false, 2>), g2, block, 0, s, b); }
+            } else {
+                if (hilo) { hipLaunchKernelGGL((v6_mix_kernel<2, true, 4, false, true, true>), grid, block, lds, s, b); hipLaunchKernelGGL((v6_mix_apply_kernel<true, 4>), g2, block, 0, s, b); }
+                else { hipLaunchKernelGGL((v6_mix_kernel<2, false, 4, false, true, true>), grid, block, lds, s, b); hipLaunchKernelGGL((v6_mix_apply_kernel<false, 4>), g2, block, 0, s, b); }
+            }
+            return;
+        }
         if (a.Dm == 32) { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 2, false, true>), grid, block, lds, s, b); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 2, false, true>), grid, block, lds, s, b); }
         else { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 4, false, true>), grid, block, lds, s, b); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 4, false, true>), grid, block, lds, s, b); }
         return;
@@ -1720,7 +1800,14 @@ __device__ __forceinline__ void row_layernorm(float4 (&v)[PT], int C, const floa
 template <int PT, int NTHR>
 __global__ __launch_bounds__(NTHR) void ln_shift_kernel(const LnShiftArgs a) {
     __shared__ float red[2 * NTHR / 64];
-    const int t = blockIdx.x, C = a.C;
+    // a.xcd_rows (prefill-shaped steps): block b runs on XCD b mod 8, and row t re-reads row t-1 with all its partial slabs — rows are
+    // numbered so that an XCD owns a contiguous run of them and the predecessor comes from that XCD's L2 instead of HBM
+    int t = blockIdx.x;
+    if (a.xcd_rows) {
+        const int nrow = gridDim.x, x = t & 7, slot = t >> 3, base = nrow >> 3, rem = nrow & 7;
+        t = x * base + min(x, rem) + slot;
+    }
+    const int C = a.C;
     TRACE_K(2, 0);
     // every load that does not depend on another load is issued here, parameters first: the kernel is one latency
     // chain (it moves ~100 KB), so each load left behind a reduction costs a full L2/MALL round trip
@@ -1805,21 +1892,24 @@ void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s) {
     // form keeps ~250 VGPRs, i.e. 8 waves per CU.
     int thr = knobs().ln_threads;
     if (thr == 0) thr = T <= 256 ? 1024 : 512;
+    LnShiftArgs b = a;
+    b.xcd_rows = knobs().tile_xcd ? 1 : 0;
+    const LnShiftArgs &a2 = b;
     if (thr == 1024 && a.C <= 8192) {
-        if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<1, 1024>), dim3(T), dim3(1024), 0, s, a);
-        else hipLaunchKernelGGL((ln_shift_kernel<2, 1024>), dim3(T), dim3(1024), 0, s, a);
+        if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<1, 1024>), dim3(T), dim3(1024), 0, s, a2);
+        else hipLaunchKernelGGL((ln_shift_kernel<2, 1024>), dim3(T), dim3(1024), 0, s, a2);
         return;
     }
     if (thr == 512 && a.C <= 8192) {
-        if (a.C <= 2048) hipLaunchKernelGGL((ln_shift_kernel<1, 512>), dim3(T), dim3(512), 0, s, a);
-        else if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<2, 512>), dim3(T), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((ln_shift_kernel<4, 512>), dim3(T), dim3(512), 0, s, a);
+        if (a.C <= 2048) hipLaunchKernelGGL((ln_shift_kernel<1, 512>), dim3(T), dim3(512), 0, s, a2);
+        else if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<2, 512>), dim3(T), dim3(512), 0, s, a2);
+        else hipLaunchKernelGGL((ln_shift_kernel<4, 512>), dim3(T), dim3(512), 0, s, a2);
         return;
     }
-    if (a.C <= 1024) hipLaunchKernelGGL((ln_shift_kernel<1, 256>), dim3(T), dim3(256), 0, s, a);
-    else if (a.C <= 2048) hipLaunchKernelGGL((ln_shift_kernel<2, 256>), dim3(T), dim3(256), 0, s, a);
-    else if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<4, 256>), dim3(T), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((ln_shift_kernel<8, 256>), dim3(T), dim3(256), 0, s, a);
+    if (a.C <= 1024) hipLaunchKernelGGL((ln_shift_kernel<1, 256>), dim3(T), dim3(256), 0, s, a2);
+    else if (a.C <= 2048) hipLaunchKernelGGL((ln_shift_kernel<2, 256>), dim3(T), dim3(256), 0, s, a2);
+    else if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<4, 256>), dim3(T), dim3(256), 0, s, a2);
+    else hipLaunchKernelGGL((ln_shift_kernel<8, 256>), dim3(T), dim3(256), 0, s, a2);
 }
 
 template <int PT>

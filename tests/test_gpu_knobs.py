@@ -93,32 +93,34 @@ def test_every_switch_gives_the_oracles_answers(models, switch, value):
                 os.environ[k] = v
 
 
-def test_wide_mix_numbered_by_xcd_on_a_1024_row_step(models):
-    """Steps whose token tiles come in multiples of eight (and are too many to split a mix's strips over several blocks) number the
-    five mix blocks of a token tile onto one XCD (v6_mix_kernel, a.xcd_group): a 1024-row step takes that path, RWKV_TILE_XCD=0 the
-    plain numbering; both must give the oracle's logits, and the same bits as each other (only the block -> tile map differs)."""
+def test_wide_mix_forms_agree_on_a_1024_row_step(models):
+    """Steps of >= 1024 rows (a multiple of 32) run the wide V6 mix as two launches (v6_mix_kernel<..., P1ONLY> + v6_mix_apply_kernel);
+    RWKV_V6_SPLIT_MIN_T above the step keeps the single launch.  Both must give the oracle's logits and the same bits as each other
+    (same products, same order — only the work distribution differs); fp16 and the hi/lo operand form.  RWKV_TILE_XCD=0 on top: the
+    row kernels' plain row numbering."""
     tens, st = models[6]
     B, L = 32, 32
     ps = [[t % 1024 for t in R.synth_prompt(90 + b, L)] for b in range(B)]
     rb = R.RwkvRefBatch(tens, 0, 0)
     want = rb.prefill(ps, rb.init_states(B))
-    res = []
-    for off in (False, True):
-        if off:
-            os.environ["RWKV_TILE_XCD"] = "0"
-        try:
-            eng = rt.ModelBuilder(st).build(max_batch=B, token_chunk_size=1024, precision=rt.Precision.Fp16)
-        finally:
-            os.environ.pop("RWKV_TILE_XCD", None)
-        inp = rt.RnnInput([rt.RnnInputBatch(list(p), rt.RnnOption.Last) for p in ps])
-        inp, outs = eng.infer(inp)
-        assert inp.num_token() == 0                                  # one 1024-row step
-        got = np.stack([o[-1] for o in outs])
-        for b in range(B):
-            assert float(np.abs(got[b] - want[b]).max()) <= tol(want[b])
-        res.append(got)
-        eng.close()
-    assert np.array_equal(res[0], res[1])
+    for prec in (rt.Precision.Fp16, rt.Precision.Fp32):
+        res = []
+        for env in ({}, {"RWKV_V6_SPLIT_MIN_T": "4096"}, {"RWKV_TILE_XCD": "0"}):
+            os.environ.update(env)
+            try:
+                eng = rt.ModelBuilder(st).build(max_batch=B, token_chunk_size=1024, precision=prec)
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+            inp = rt.RnnInput([rt.RnnInputBatch(list(p), rt.RnnOption.Last) for p in ps])
+            inp, outs = eng.infer(inp)
+            assert inp.num_token() == 0                                  # one 1024-row step
+            got = np.stack([o[-1] for o in outs])
+            for b in range(B):
+                assert float(np.abs(got[b] - want[b]).max()) <= tol(want[b])
+            res.append(got)
+            eng.close()
+        assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
 
 
 def test_switches_are_frozen_per_engine(models):
