@@ -905,15 +905,18 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         if (T >= 1024 && tot64 >= 2500) shape = 7;
         // The pipelined 128x128 kernel (shape 10) keeps two blocks per CU resident, 512 tiles a round, and runs ~820 TFLOP/s on
         // whole rounds against ~540 for the 64x64 shapes whatever the grid (scripts/tile_bench2.py); a partial last round costs
-        // a whole one (blocks left alone on a CU are latency-bound), so it is used when its rounds are at least 65 % full:
-        // V6-3B chunk 2048 60.8 -> 69.5 k prefill tok/s, V6-7B chunk 1024 30.4 -> 32.7 k.  RWKV_TILE3_FILL=<percent> (0 = never).
+        // a whole one (blocks left alone on a CU are latency-bound), so it is used when its rounds are at least 60 % full and it has
+        // at least 300 tiles: V6-3B chunk 2048 60.8 -> 69.5 k prefill tok/s, V6-7B chunk 1024 30.4 -> 32.7 k.  (Round 3 moved the bar
+        // from 65 % / 400 tiles: Wo of the 3 B models at 2048 rows — 320 tiles, 62.5 % of a round — is 75 us on 64x64 tiles and one
+        // round of this kernel, ~64 us: 76.4 -> 78.3 k, V7-2.9B NF4 69.2 -> 71.8 k; profiles/r3_exp_tile3_thresholds.log.)
+        // RWKV_TILE3_FILL=<percent> (0 = never), RWKV_TILE3_MIN_TILES.
         bool ok3 = true;
         {
             long t3 = 0;
             for (auto &sp : ps) { t3 += gemm_tile_blocks(GEMM_TILE3, sp.W->rows, T); ok3 = ok3 && gemm_tile3_supported(hilo, sp.W->K); }
             const long fill_min = kn.tile3_fill;
             const long rounds = (t3 + 511) / 512;
-            if (ok3 && fill_min > 0 && t3 >= 400 && t3 * 100 >= fill_min * rounds * 512) shape = GEMM_TILE3;
+            if (ok3 && fill_min > 0 && t3 >= kn.tile3_min_tiles && t3 * 100 >= fill_min * rounds * 512) shape = GEMM_TILE3;
         }
         if (f_shape >= 0 && f_shape < GEMM_TILE_SHAPES && (f_shape != GEMM_TILE3 || ok3)) shape = f_shape;
         // K split of a linear launch on the pipelined kernel (Wo, Fv: one `partial` problem whose output the next row kernel sums

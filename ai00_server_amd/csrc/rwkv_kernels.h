@@ -18,10 +18,11 @@ struct Knobs {
     int ksw8 = 1;                    // RWKV_KSW8: T <= 16 steps run 256-k waves (ten per block); 0 = 512-k waves (five)
     int no_ln_fuse = 0;              // RWKV_NO_LN_FUSE: row kernels instead of the LayerNorm prologue on single-token steps
     int no_v6_fuse = 0, no_v6_wide = 0, v6mix_split = 0;   // RWKV_NO_V6_FUSE / RWKV_NO_V6_WIDE / RWKV_V6MIX_SPLIT
-    int no_tile = 0, tile_shape = -1, tile3_fill = 65, tile_xcd = 1;   // RWKV_NO_TILE / RWKV_TILE_SHAPE / RWKV_TILE3_FILL / RWKV_TILE_XCD
+    int no_tile = 0, tile_shape = -1, tile3_fill = 60, tile_xcd = 1;   // RWKV_NO_TILE / RWKV_TILE_SHAPE / RWKV_TILE3_FILL / RWKV_TILE_XCD
     int tile_ksplit = 1;             // RWKV_TILE_KSPLIT: K split of linear launches on the pipelined prefill kernel (0 = off)
     int no_dense = 0;                // RWKV_NO_DENSE: general row metadata on dense decode steps
     int ln_256 = 0;                  // RWKV_LN_256: 256-thread ln_shift everywhere
+    int tile3_min_tiles = 300;       // RWKV_TILE3_MIN_TILES: fewest tiles for which the pipelined prefill kernel is considered
     int v6_split_min_t = 512;        // RWKV_V6_SPLIT_MIN_T: rows from which the wide V6 mix runs as two launches (v6_mix_apply_kernel)
     int ln_threads = 0;              // RWKV_LN_THREADS: threads per row of ln_shift on prefill-shaped steps (0 = 1024 up to 256 rows, 512 above; 256 / 512 / 1024 force)
     static Knobs from_env();

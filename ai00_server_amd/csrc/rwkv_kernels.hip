@@ -478,11 +478,12 @@ Knobs Knobs::from_env() {
     k.no_ln_fuse = knob_env("RWKV_NO_LN_FUSE", 0); k.no_v6_fuse = knob_env("RWKV_NO_V6_FUSE", 0);
     k.no_v6_wide = knob_env("RWKV_NO_V6_WIDE", 0); k.v6mix_split = knob_env("RWKV_V6MIX_SPLIT", 0);
     k.no_tile = knob_env("RWKV_NO_TILE", 0); k.tile_shape = knob_env("RWKV_TILE_SHAPE", -1);
-    k.tile3_fill = knob_env("RWKV_TILE3_FILL", 65); k.tile_xcd = knob_env("RWKV_TILE_XCD", 1);
+    k.tile3_fill = knob_env("RWKV_TILE3_FILL", 60); k.tile_xcd = knob_env("RWKV_TILE_XCD", 1);
     k.tile_ksplit = knob_env("RWKV_TILE_KSPLIT", 1);
     k.no_dense = knob_env("RWKV_NO_DENSE", 0); k.ln_256 = knob_env("RWKV_LN_256", 0);
     k.ln_threads = knob_env("RWKV_LN_THREADS", 0);
     k.v6_split_min_t = knob_env("RWKV_V6_SPLIT_MIN_T", 512);
+    k.tile3_min_tiles = knob_env("RWKV_TILE3_MIN_TILES", 300);
     return k;
 }
 static thread_local Knobs t_knobs;

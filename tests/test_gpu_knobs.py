@@ -94,7 +94,7 @@ def test_every_switch_gives_the_oracles_answers(models, switch, value):
 
 
 def test_wide_mix_forms_agree_on_a_1024_row_step(models):
-    """Steps of >= 1024 rows (a multiple of 32) run the wide V6 mix as two launches (v6_mix_kernel<..., P1ONLY> + v6_mix_apply_kernel);
+    """Steps of >= 512 rows (a multiple of 32) run the wide V6 mix as two launches (v6_mix_kernel<..., P1ONLY> + v6_mix_apply_kernel);
     RWKV_V6_SPLIT_MIN_T above the step keeps the single launch.  Both must give the oracle's logits and the same bits as each other
     (same products, same order — only the work distribution differs); fp16 and the hi/lo operand form.  RWKV_TILE_XCD=0 on top: the
     row kernels' plain row numbering."""
