@@ -899,6 +899,12 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         bool all_f16 = true;
         for (auto &s : ps) all_f16 = all_f16 && s.W->fmt == W_F16;
         if (all_f16) shape = 3;
+        // NF4 sits in between (a quarter of the bytes per weight, the most dequantisation work): the 128-k chunks win from ~500 tiles
+        // (isolated, 3 B width, 256 rows: r/k/v/g 42.0 -> 40.2 us, Fk + Fr 50.8 -> 47.4; Wo / Fv with 160 tiles lose 40 %),
+        // profiles/r3_exp_tile_128x64.log
+        bool all_nf4 = true;
+        for (auto &s : ps) all_nf4 = all_nf4 && s.W->fmt == W_NF4;
+        if (all_nf4 && tot64 >= kn.nf4_kc128_min) shape = 3;
         // the direct-to-LDS 128x64 shape (7: two strips per wave, X tiles by global_load_lds) pays only for very large
         // grids: 7B fp16 prefill at chunk 1024 25.9 -> 27.5 k tok/s, but 21.3 -> 17.8 k at chunk 512; the 256x128
         // GLDS shape (9) wins isolated large fp16 GEMMs (404 -> 536 TFLOP/s) and loses the model (small matrices starve)

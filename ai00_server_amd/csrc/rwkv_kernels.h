@@ -23,6 +23,7 @@ struct Knobs {
     int no_dense = 0;                // RWKV_NO_DENSE: general row metadata on dense decode steps
     int ln_256 = 0;                  // RWKV_LN_256: 256-thread ln_shift everywhere
     int tile3_min_tiles = 300;       // RWKV_TILE3_MIN_TILES: fewest tiles for which the pipelined prefill kernel is considered
+    int nf4_kc128_min = 512;         // RWKV_NF4_KC128_MIN: 64x64 tiles of an all-NF4 launch walk K in 128-k chunks from this many tiles
     int v6_split_min_t = 512;        // RWKV_V6_SPLIT_MIN_T: rows from which the wide V6 mix runs as two launches (v6_mix_apply_kernel)
     int ln_threads = 0;              // RWKV_LN_THREADS: threads per row of ln_shift on prefill-shaped steps (0 = 1024 up to 256 rows, 512 above; 256 / 512 / 1024 force)
     static Knobs from_env();

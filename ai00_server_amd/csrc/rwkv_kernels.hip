@@ -484,6 +484,7 @@ Knobs Knobs::from_env() {
     k.ln_threads = knob_env("RWKV_LN_THREADS", 0);
     k.v6_split_min_t = knob_env("RWKV_V6_SPLIT_MIN_T", 512);
     k.tile3_min_tiles = knob_env("RWKV_TILE3_MIN_TILES", 300);
+    k.nf4_kc128_min = knob_env("RWKV_NF4_KC128_MIN", 512);
     return k;
 }
 static thread_local Knobs t_knobs;
@@ -1691,6 +1692,8 @@ bool gemm_tile3_supported(bool hilo, int K) { return !hilo && K % 128 == 0; }
 // tile shapes, largest first: {waves, strips per wave, n-tiles, k per chunk}
 static const int kTileShapes[GEMM_TILE_SHAPES][5] = {{8, 2, 8, 128, 0}, {8, 1, 8, 128, 0}, {4, 1, 8, 128, 0}, {4, 1, 4, 128, 0}, {4, 1, 4, 256, 0}, {8, 1, 8, 256, 0},
                                                      {4, 1, 4, 256, 1}, {4, 2, 4, 128, 1}, {4, 2, 8, 128, 1}, {8, 2, 8, 128, 1}, {4, 2, 8, 128, 2}};
+// (128 rows x 64 tokens with 8 waves, 256-k and 128-k chunks — half the operand re-reads of the 64x64 shapes on steps of a few hundred
+// rows — was built and measured in round 3: slower on every matrix but one, profiles/r3_exp_tile_128x64.log; removed.)
 int gemm_tile_blocks(int shape, int rows, int T) {
     const int strips = kTileShapes[shape][0] * kTileShapes[shape][1], bt = kTileShapes[shape][2] * 16;
     return ((rows / 16 + strips - 1) / strips) * ((T + bt - 1) / bt);
