@@ -1896,9 +1896,8 @@ void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s) {
     // form keeps ~250 VGPRs, i.e. 8 waves per CU.
     int thr = knobs().ln_threads;
     if (thr == 0) thr = T <= 256 ? 1024 : 512;
-    LnShiftArgs b = a;
-    b.xcd_rows = knobs().tile_xcd ? 1 : 0;
-    const LnShiftArgs &a2 = b;
+    LnShiftArgs a2 = a;
+    a2.xcd_rows = knobs().tile_xcd ? 1 : 0;
     if (thr == 1024 && a.C <= 8192) {
         if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<1, 1024>), dim3(T), dim3(1024), 0, s, a2);
         else hipLaunchKernelGGL((ln_shift_kernel<2, 1024>), dim3(T), dim3(1024), 0, s, a2);
