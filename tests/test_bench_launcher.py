@@ -67,3 +67,26 @@ def test_real_bench_as_two_ranks_on_one_device():
     d = last_json(r.stdout)
     assert d["n_gpus"] == 2 and len(d["per_rank_tokens_per_s"]) == 2 and d["tokens_verified"] is True
     assert d["value"] > 0 and d["config"]["parallelism"].startswith("replicas x2")
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The line the driver parses (profiles/r3_bench_default.json is the last one measured on the GPU box): every key of the bench
+    contract, the roofline and cpu_baseline objects with their fields, value = tokens of all ranks / the slowest rank's time."""
+    import json
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r3_bench_default.json")).readline())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in line, k
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None and line["data"] == "synthetic"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    rf = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["traffic"] is None or rf["traffic"] >= rf["algorithmic_bytes_per_launch"]      # HBM bytes cannot undercut the algorithmic ones
+    cb = line["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1
+    B = line["config"]["batch_per_gpu"]
+    assert abs(line["value"] - line["n_gpus"] * B * 1000.0 / line["ms_per_step"]) / line["value"] < 1e-6
+    assert line["tokens_verified"] is True and line["embeddings"]["embeddings_verified"] is True
