@@ -908,7 +908,11 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         // the direct-to-LDS 128x64 shape (7: two strips per wave, X tiles by global_load_lds) pays only for very large
         // grids: 7B fp16 prefill at chunk 1024 25.9 -> 27.5 k tok/s, but 21.3 -> 17.8 k at chunk 512; the 256x128
         // GLDS shape (9) wins isolated large fp16 GEMMs (404 -> 536 TFLOP/s) and loses the model (small matrices starve)
-        if (T >= 1024 && tot64 >= 2500) shape = 7;
+        // (not for launches whose matrices are all short in K — V7's second-stage LoRA, K = 64..320, four [T][C] outputs: 88 us on that
+        // shape at 2048 rows; on the 64x64 shapes V7-2.9B NF4 prefill 74.4 -> 76.5 k tok/s, 64.7 -> 66.5 k at 1024; profiles/r3_exp_shape7_by_k.log)
+        int maxK = 0;
+        for (auto &s : ps) maxK = std::max(maxK, s.W->K);
+        if (T >= 1024 && tot64 >= 2500 && maxK >= 1024) shape = 7;
         // The pipelined 128x128 kernel (shape 10) keeps two blocks per CU resident, 512 tiles a round, and runs ~820 TFLOP/s on
         // whole rounds against ~540 for the 64x64 shapes whatever the grid (scripts/tile_bench2.py); a partial last round costs
         // a whole one (blocks left alone on a CU are latency-bound), so it is used when its rounds are at least 60 % full and it has
