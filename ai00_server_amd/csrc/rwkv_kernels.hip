@@ -1122,21 +1122,20 @@ void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
     if (wide) {
         const int ntile = (a.T + 31) / 32;
         grid = dim3(std::max(1, std::min(8, 256 / (5 * ntile))), 5, ntile);   // fill the chip when the step has few token tiles
-        const V6MixArgs &b = a;
         if (a.T >= knobs().v6_split_min_t && a.T % 32 == 0 && a.mg_hi && (!hilo || a.mg_lo)) {
             grid = dim3(1, 5, ntile);
             const dim3 g2((a.C / 16 + 7) / 8, ntile);
             if (a.Dm == 32) {
-                if (hilo) { hipLaunchKernelGGL((v6_mix_kernel<2, true, 2, false, true, true>), grid, block, lds, s, b); hipLaunchKernelGGL((v6_mix_apply_kernel<true, 2>), g2, block, 0, s, b); }
-                else { hipLaunchKernelGGL((v6_mix_kernel<2, false, 2, false, true, true>), grid, block, lds, s, b); hipLaunchKernelGGL((v6_mix_apply_kernel<false, 2>), g2, block, 0, s, b); }
+                if (hilo) { hipLaunchKernelGGL((v6_mix_kernel<2, true, 2, false, true, true>), grid, block, lds, s, a); hipLaunchKernelGGL((v6_mix_apply_kernel<true, 2>), g2, block, 0, s, a); }
+                else { hipLaunchKernelGGL((v6_mix_kernel<2, false, 2, false, true, true>), grid, block, lds, s, a); hipLaunchKernelGGL((v6_mix_apply_kernel<false, 2>), g2, block, 0, s, a); }
             } else {
-                if (hilo) { hipLaunchKernelGGL((v6_mix_kernel<2, true, 4, false, true, true>), grid, block, lds, s, b); hipLaunchKernelGGL((v6_mix_apply_kernel<true, 4>), g2, block, 0, s, b); }
-                else { hipLaunchKernelGGL((v6_mix_kernel<2, false, 4, false, true, true>), grid, block, lds, s, b); hipLaunchKernelGGL((v6_mix_apply_kernel<false, 4>), g2, block, 0, s, b); }
+                if (hilo) { hipLaunchKernelGGL((v6_mix_kernel<2, true, 4, false, true, true>), grid, block, lds, s, a); hipLaunchKernelGGL((v6_mix_apply_kernel<true, 4>), g2, block, 0, s, a); }
+                else { hipLaunchKernelGGL((v6_mix_kernel<2, false, 4, false, true, true>), grid, block, lds, s, a); hipLaunchKernelGGL((v6_mix_apply_kernel<false, 4>), g2, block, 0, s, a); }
             }
             return;
         }
-        if (a.Dm == 32) { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 2, false, true>), grid, block, lds, s, b); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 2, false, true>), grid, block, lds, s, b); }
-        else { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 4, false, true>), grid, block, lds, s, b); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 4, false, true>), grid, block, lds, s, b); }
+        if (a.Dm == 32) { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 2, false, true>), grid, block, lds, s, a); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 2, false, true>), grid, block, lds, s, a); }
+        else { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 4, false, true>), grid, block, lds, s, a); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 4, false, true>), grid, block, lds, s, a); }
         return;
     }
     static bool attr_done[16] = {false};
