@@ -278,6 +278,9 @@ __device__ __forceinline__ f16x8 frag(const WRound<FMT> &w, int ks, const Nf4Lut
         return __builtin_bit_cast(f16x8, w.q[ks]);
     } else if constexpr (FMT == W_INT8) {
         const u32x4 q = w.q[ks >> 1];
+#ifdef RWKV_EXP_NODQ
+        { u32x4 r0; r0.x = (ks & 1) ? q.z : q.x; r0.y = (ks & 1) ? q.w : q.y; r0.z = w.s.x; r0.w = w.s.y; return __builtin_bit_cast(f16x8, r0); }
+#endif
         const u32 d0 = (ks & 1) ? q.z : q.x, d1 = (ks & 1) ? q.w : q.y;
         const u32 ab = (ks >> 2) ? w.s.y : w.s.x;                // 128-block inside the 256-group
         const f16x2 abh = as_h2(ab);
@@ -534,6 +537,9 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     f32x4 &d = (NT == 1 && (ks & 1)) ? acc2[nt] : acc[nt];   // NT = 2 already has two independent chains
+#ifdef RWKV_EXP_NOMFMA
+                    { const f32x4 af = __builtin_bit_cast(f32x4, a), xf = __builtin_bit_cast(f32x4, xb[nt][sub * RS + ks]); d[0] += af[0] * xf[0]; d[1] += af[1]; d[2] += af[2]; d[3] += af[3]; continue; }
+#endif
                     d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[nt][sub * RS + ks], d, 0, 0, 0);
                     if constexpr (HILO) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xl[nt][sub * RS + ks], d, 0, 0, 0);
                 }
@@ -555,20 +561,23 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
     constexpr int RD = (!SHOT && FMT != W_F16) ? ((NT >= 2 || HILO || LNP) ? 2 : 4) : 1;
     WRound<FMT> ring[RD];
     // weights of one K slice of this wave: everything (single shot), the first RD rounds (ring) or the first round
-    auto issue_w = [&](int k0, int nsub, int nround, bool ringed) {
+    // `part`: 0 = everything, 1 = the first strip's rounds only, 2 = the rest (see the issue order below)
+    auto issue_w = [&](int k0, int nsub, int nround, bool ringed, int part) {
         if constexpr (SHOT) {
             // single shot: every weight tile of this wave is in flight before the first MFMA (host: spb * SUB <= MAXR)
 #pragma unroll
             for (int r = 0; r < MAXR; ++r) {
                 const int s = r / SUB, sub = r % SUB;
-                if (s < nstrip && sub < nsub) load_round<FMT, TAIL>(w[r], P, strip0 + s, k0 + sub * RK, kend, true, lane);
+                if ((part == 0 || (part == 1) == (s == 0)) && s < nstrip && sub < nsub)
+                    load_round<FMT, TAIL>(w[r], P, strip0 + s, k0 + sub * RK, kend, true, lane);
             }
         } else if (ringed) {
 #pragma unroll
             for (int j = 0; j < RD; ++j)
-                if (j < nround) load_round<FMT, TAIL>(ring[j], P, strip0 + j / SUB, k0 + (j % SUB) * RK, kend, true, lane);
+                if ((part == 0 || (part == 1) == (j < SUB)) && j < nround)
+                    load_round<FMT, TAIL>(ring[j], P, strip0 + j / SUB, k0 + (j % SUB) * RK, kend, true, lane);
         } else {
-            load_round<FMT, TAIL>(cur, P, strip0, k0, kend, true, lane);
+            if (part != 2) load_round<FMT, TAIL>(cur, P, strip0, k0, kend, true, lane);
         }
     };
 
@@ -624,7 +633,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                 _Float16 *op_l = (_Float16 *)(lred + 64);
                 LnCarry carry;
                 ln_prologue_load(L.lnp, L.T, xx_l, pv_l, lred, blockIdx.x == 0, carry);
-                issue_w(k0, nsub, nround, ringed);             // the weights fly while the rows are reduced and normalised
+                issue_w(k0, nsub, nround, ringed, 0);          // the weights fly while the rows are reduced and normalised
                 ln_prologue_finish<HILO>(L.lnp, L.T, P.lnp_mu, xx_l, pv_l, op_l, lred, blockIdx.x == 0, carry);
                 const int tl = min(lane & 15, L.T - 1);
                 const _Float16 *oph = op_l + lnp_op_off(L.T, k0 + (lane >> 4) * 8, tl);
@@ -635,8 +644,22 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                     if constexpr (HILO) xl[0][ks] = in ? *(const f16x8 *)(oph + (size_t)L.T * L.lnp.C + (size_t)ks * 4 * L.T * 8) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                 }
             } else {
+#if defined(RWKV_EXP_W0FIRST)
+                // first strip's weights -> X -> the other strips: HBM is asked for its first bytes before the CU spends ~1 us pulling
+                // the operand from L2, and the first strip's MFMAs still only wait for (strip 0, X) in vmcnt order
+                issue_w(k0, nsub, nround, ringed, 1);
                 load_x();
-                issue_w(k0, nsub, nround, ringed);
+                issue_w(k0, nsub, nround, ringed, 2);
+#elif defined(RWKV_EXP_NOX)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int ks = 0; ks < KSW; ++ks) { xb[nt][ks] = (f16x8){1, 1, 1, 1, 1, 1, 1, 1}; if constexpr (HILO) xl[nt][ks] = xb[nt][ks]; }
+                issue_w(k0, nsub, nround, ringed, 0);
+#else
+                load_x();
+                issue_w(k0, nsub, nround, ringed, 0);
+#endif
             }
 #ifdef RWKV_TRACE
             TRACE_PT(1);
