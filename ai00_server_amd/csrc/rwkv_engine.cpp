@@ -389,6 +389,14 @@ struct rwkv_engine {
 // ------------------------------------------------------------------------------------------------
 // loader
 // ------------------------------------------------------------------------------------------------
+// the tensor names `LoraBlend::full` matches: blocks.<digits>.<anything>
+static bool lora_scope(const std::string &name) {
+    if (name.compare(0, 7, "blocks.") != 0) return false;
+    size_t i = 7;
+    while (i < name.size() && name[i] >= '0' && name[i] <= '9') ++i;
+    return i > 7 && i + 1 < name.size() && name[i] == '.';
+}
+
 static bool is_quant_target(int version, const std::string &suffix) {
     static const char *att56[] = {"att.receptance.weight", "att.key.weight", "att.value.weight", "att.output.weight", "att.gate.weight"};
     static const char *att7[] = {"att.receptance.weight", "att.key.weight", "att.value.weight", "att.output.weight"};
@@ -515,11 +523,15 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
         if (want && (size_t)t.numel() != want) throw RwkvError(RWKV_ERR_FORMAT, name + ": unexpected size");
         upload_raw(t);
         float *v = dalloc<float>((size_t)t.numel());
-        // `LoraBlend::full(alpha)` (lib.rs:466-482) matches EVERY tensor: a LoRA file that holds a tensor of this name (time_mix_*,
-        // time_decay, time_first, LayerNorm weights ...) is blended in whole, v += alpha * l, before the load-time transform
+        // `LoraBlend::full(alpha)` (lib.rs:466-482).  web-rwkv is not vendored in the reference tree; restated from its loader
+        // (runtime/loader.rs, 0.10.x) and UNPINNED: `full` is the single pattern `blocks\.([0-9]+)\.([0-9a-zA-Z\.\_]+)`, so only
+        // per-block tensors blend (emb, head, ln_out do not; blocks.0.ln0 does), and a VECTOR the LoRA file holds under the model's
+        // own name (time_mix_*, time_decay, time_first, LayerNorm weights ...: fine-tuned whole, not low-rank) is blended
+        // v = alpha * l + (1 - alpha) * v — `factor = [alpha, 1 - alpha]` of its `load_vector_*`; alpha = 1 replaces it —
+        // in fp32 before the load-time transform.  Matrices: W += alpha * B A^T (`factor = [alpha, 1]`), load_mat below.
         bool blended = false;
         for (auto &lp : loras) {
-            const StTensor *l = lp.first.find(name);
+            const StTensor *l = lora_scope(name) ? lp.first.find(name) : nullptr;
             if (!l) continue;
             if (l->dtype != "F16" || l->numel() != t.numel()) throw RwkvError(RWKV_ERR_FORMAT, name + ": LoRA tensor does not match the model's");
             if (!blended) { launch_f16_to_f32(raw, v, t.numel(), 0, s_main); blended = true; }
@@ -596,6 +608,7 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
             // LoRA blend on the raw fp16 matrix (fp32 math, one rounding back to fp16)
             const std::string stem = name.size() > 7 && name.substr(name.size() - 7) == ".weight" ? name.substr(0, name.size() - 7) : name;
             for (auto &lp : loras) {
+                if (!lora_scope(name)) break;                                   // LoraBlend::full matches `blocks.N.*` only (see load_vec)
                 const StTensor *A = lp.first.find(stem + ".lora.0"), *B = lp.first.find(stem + ".lora.1");
                 if (!A || !B) continue;
                 if (A->shape.size() != 2 || B->shape.size() != 2 || A->shape[0] != K || B->shape[0] != rows || A->shape[1] != B->shape[1])

@@ -261,7 +261,7 @@ void launch_tile_f16(const _Float16 *raw, int rows_valid, int rows, int K, void 
 void launch_quant_int8(const _Float16 *raw, int rows, int K, void *out, void *scales, hipStream_t s);
 void launch_quant_nf4(const _Float16 *raw, int rows, int K, void *out, void *scales, hipStream_t s);
 void launch_f16_to_f32(const _Float16 *in, float *out, long n, int op, hipStream_t s); // op 0: copy, 1: exp(-exp(x))
-void launch_vec_blend(float *v, const _Float16 *l, long n, float alpha, hipStream_t s);   // v += alpha * l   (LoRA on a vector tensor)
+void launch_vec_blend(float *v, const _Float16 *l, long n, float alpha, hipStream_t s);   // v = alpha * l + (1 - alpha) * v   (LoRA file holds a whole vector tensor)
 void launch_vec_op(float *v, long n, int op, hipStream_t s);                              // the load-time transform, in place
 // W[rows][K] (fp16 raw) += alpha * B[rows][r] * A^T  (A stored [K][r]) — LoRA blend, fp32 math
 void launch_lora_blend(_Float16 *W, const _Float16 *B, const _Float16 *A, int rows, int K, int r, float alpha, hipStream_t s);

@@ -658,6 +658,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                 issue_w(k0, nsub, nround, ringed, 0);
 #else
                 load_x();
+                TRACE_PT(7);
                 issue_w(k0, nsub, nround, ringed, 0);
 #endif
             }
@@ -2893,7 +2894,7 @@ void launch_f16_to_f32(const _Float16 *in, float *out, long n, int op, hipStream
 // LoRA on a non-matrix tensor (`LoraBlend::full(alpha)` matches every tensor, lib.rs:466-482): a LoRA file that carries a tensor of
 // the SAME name blends it in whole, v += alpha * l, on the fp32 copy and BEFORE any load-time transform (op 1: exp(-exp(v))).
 __global__ void vec_blend_kernel(float *v, const _Float16 *l, long n, float alpha) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) v[i] += alpha * (float)l[i];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) v[i] = alpha * (float)l[i] + (1.0f - alpha) * v[i];
 }
 __global__ void vec_op_kernel(float *v, long n, int op) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)

@@ -9,6 +9,13 @@
 //      sits in that replica's host memory) — ties and misses fall through to
 //   2. the replica with the fewest busy slots (then the lowest index), skipping replicas that are full.
 //
+// Health: a replica whose ENGINE throws (a HIP device fault is sticky: every later step on that device throws again) would empty
+// at once, win every least-busy tie and absorb — and fail — most new traffic.  So engine failures are counted per replica; after
+// `eject_after` consecutive ones (a successful step resets the count) the replica is EJECTED: route() / submit() skip it, the
+// requests it had accepted but not started are re-routed to healthy replicas, and submit() returns -1 when none is left.
+// `revive()` puts a replica back (after the operator reset the device).  A throwing `sample` callback is the REQUEST's fault: it
+// fails that request alone and does not count against the replica.
+//
 // Threading follows the reference's contract per engine (two long-lived caller threads: `infer` and `softmax`,
 // run.rs:1072-1190): every replica is driven by its OWN thread (`Replica::run`), which is the only thread that touches that
 // engine's scheduler; `submit` only appends to the replica's inbox under its mutex.  Header-only, no HIP: `Engine` is what
@@ -42,9 +49,13 @@ struct RoutedRequest {
 template <class Engine>
 class ReplicaRouter {
    public:
-    explicit ReplicaRouter(std::vector<Engine *> engines, size_t max_cached = 256) {
+    explicit ReplicaRouter(std::vector<Engine *> engines, size_t max_cached = 256, int eject_after = 2) {
         for (Engine *e : engines) reps_.emplace_back(new Replica(*e, max_cached));
-        for (auto &r : reps_) r->thread = std::thread([p = r.get()] { p->run(); });
+        for (auto &r : reps_) {
+            r->eject_after = std::max(1, eject_after);
+            r->reroute = [this](RoutedRequest *rq) { return submit(rq); };
+            r->thread = std::thread([p = r.get()] { p->run(); });
+        }
     }
     ~ReplicaRouter() {
         for (auto &r : reps_) { { std::lock_guard<std::mutex> g(r->mu); r->stop = true; } r->cv.notify_all(); }
@@ -58,7 +69,7 @@ class ReplicaRouter {
         size_t best_len = 0;
         for (size_t i = 0; i < reps_.size(); ++i) {                      // 1. prefix affinity
             std::lock_guard<std::mutex> g(reps_[i]->mu);
-            if (reps_[i]->load() >= reps_[i]->capacity) continue;
+            if (!reps_[i]->healthy || reps_[i]->load() >= reps_[i]->capacity) continue;
             const size_t len = reps_[i]->sched.match_len(tokens);          // thread-safe probe: never inserts, see Scheduler::match_len
             if (len > best_len) { best_len = len; best = (int)i; }
         }
@@ -67,7 +78,7 @@ class ReplicaRouter {
         for (size_t i = 0; i < reps_.size(); ++i) {                      // 2. least busy
             std::lock_guard<std::mutex> g(reps_[i]->mu);
             const int busy = reps_[i]->load();
-            if (busy >= reps_[i]->capacity) continue;
+            if (!reps_[i]->healthy || busy >= reps_[i]->capacity) continue;
             if (least < 0 || busy < least_busy) { least = (int)i; least_busy = busy; }
         }
         return {least, 0};
@@ -84,7 +95,7 @@ class ReplicaRouter {
             Replica &r = *reps_[(size_t)where.first];
             {
                 std::lock_guard<std::mutex> g(r.mu);
-                if (r.inflight >= r.capacity || r.stop) continue;
+                if (r.inflight >= r.capacity || r.stop || !r.healthy) continue;
                 req->replica = where.first;
                 r.inbox.push_back(req);
                 ++r.inflight;
@@ -102,6 +113,15 @@ class ReplicaRouter {
         }
     }
     int busy(int replica) { std::lock_guard<std::mutex> g(reps_[(size_t)replica]->mu); return reps_[(size_t)replica]->load(); }
+    bool healthy(int replica) { std::lock_guard<std::mutex> g(reps_[(size_t)replica]->mu); return reps_[(size_t)replica]->healthy; }
+    int healthy_count() { int n = 0; for (size_t i = 0; i < reps_.size(); ++i) n += healthy((int)i) ? 1 : 0; return n; }
+    // Put an ejected replica back into rotation (its engine was reset / replaced by the operator).
+    void revive(int replica) {
+        Replica &r = *reps_[(size_t)replica];
+        std::lock_guard<std::mutex> g(r.mu);
+        r.healthy = true;
+        r.engine_failures = 0;
+    }
     uint64_t steps(int replica) const { return reps_[(size_t)replica]->steps.load(); }
 
    private:
@@ -113,6 +133,10 @@ class ReplicaRouter {
         std::deque<RoutedRequest *> inbox;
         int inflight = 0;                         // submitted and not yet completed (inbox + slots)
         bool stop = false;
+        bool healthy = true;                      // false: ejected after `eject_after` consecutive engine failures (guarded by mu)
+        int engine_failures = 0;                  // consecutive; a successful step resets it (guarded by mu)
+        int eject_after = 2;
+        std::function<int(RoutedRequest *)> reroute;   // the router's submit(): where unstarted requests of an ejected replica go
         std::atomic<uint64_t> steps{0};
         std::thread thread;
         Replica(Engine &e, size_t max_cached) : sched(e, max_cached), capacity(e.max_batch) {}
@@ -133,9 +157,10 @@ class ReplicaRouter {
                 }
                 fresh.insert(fresh.begin(), parked.begin(), parked.end());
                 parked.clear();
-                // One replica's failure (a device error, a throwing sample callback, a malformed request) must not take the process
-                // down (an exception leaving a std::thread is std::terminate) nor wedge drain(): everything this replica holds is
-                // failed with the message, its slots are given up, and the thread goes on serving.
+                // One replica's failure (a device error, a malformed request) must not take the process down (an exception leaving a
+                // std::thread is std::terminate) nor wedge drain(): everything this replica holds in a slot is failed with the
+                // message and its slots are given up.  Engine failures count towards ejection (see the header comment).
+                bool engine_ok = true, stepped = false;
                 try {
                     while (!fresh.empty()) {
                         RoutedRequest *rq = fresh.front();
@@ -145,10 +170,20 @@ class ReplicaRouter {
                         owner[(size_t)b] = rq;
                     }
                     parked.swap(fresh);
-                    if (sched.pending()) { sched.step(); ++steps; }
-                    for (int b = 0; b < capacity; ++b) {
-                        RoutedRequest *rq = owner[(size_t)b];
-                        if (!rq) continue;
+                    if (sched.pending()) { sched.step(); ++steps; stepped = true; }
+                } catch (const std::exception &ex) {
+                    engine_ok = false;
+                    engine_failed(owner, fresh, parked, ex.what());
+                } catch (...) {
+                    engine_ok = false;
+                    engine_failed(owner, fresh, parked, "unknown exception in the replica thread");
+                }
+                if (!engine_ok) continue;
+                if (stepped) { std::lock_guard<std::mutex> g(mu); engine_failures = 0; }
+                for (int b = 0; b < capacity; ++b) {
+                    RoutedRequest *rq = owner[(size_t)b];
+                    if (!rq) continue;
+                    try {
                         auto &r = sched.request(b);
                         if (!r.suffix.empty() || r.output.empty()) continue;           // still reading tokens in
                         if ((int)rq->generated.size() < rq->max_new) {
@@ -162,13 +197,49 @@ class ReplicaRouter {
                         sched.finish(b);
                         owner[(size_t)b] = nullptr;
                         complete(rq, nullptr);
+                    } catch (const std::exception &ex) {                               // the request's own callback (or its bookkeeping) threw:
+                        fail_slot(owner, b, ex.what());                                // that request fails, the replica is not to blame
+                    } catch (...) {
+                        fail_slot(owner, b, "unknown exception while sampling");
                     }
-                } catch (const std::exception &ex) {
-                    fail_all(owner, fresh, parked, ex.what());
-                } catch (...) {
-                    fail_all(owner, fresh, parked, "unknown exception in the replica thread");
                 }
             }
+        }
+        void fail_slot(std::vector<RoutedRequest *> &owner, int b, const char *what) {
+            try { sched.abort(b); } catch (...) {}
+            RoutedRequest *rq = owner[(size_t)b];
+            owner[(size_t)b] = nullptr;
+            if (rq) complete(rq, what);
+        }
+        // The engine threw: requests that sit in a slot have lost their state and fail; the failure counts.  On ejection the requests
+        // that had not started yet (no slot, nothing consumed) go back to the router, which places them on a healthy replica or fails
+        // them when none is left; below the threshold they stay parked here and ride the next step.
+        void engine_failed(std::vector<RoutedRequest *> &owner, std::deque<RoutedRequest *> &fresh, std::deque<RoutedRequest *> &parked, const char *what) {
+            bool ejected = false;
+            std::deque<RoutedRequest *> orphans;
+            {                                                                      // health first: whoever sees a request of this step
+                std::lock_guard<std::mutex> g(mu);                                 // completed also sees the replica's new standing
+                if (++engine_failures >= eject_after) {
+                    healthy = false;
+                    ejected = true;
+                    orphans.swap(inbox);
+                }
+            }
+            for (int b = 0; b < capacity; ++b) {
+                try { sched.abort(b); } catch (...) {}                             // Idle, nothing cached from a step that failed
+                if (owner[(size_t)b]) { complete(owner[(size_t)b], what); owner[(size_t)b] = nullptr; }
+            }
+            for (auto *q : {&fresh, &parked}) { for (RoutedRequest *rq : *q) orphans.push_back(rq); q->clear(); }
+            if (!ejected) { parked.swap(orphans); return; }                        // transient so far: the unstarted requests wait for the next step
+            for (RoutedRequest *rq : orphans) {
+                { std::lock_guard<std::mutex> g(mu); --inflight; }
+                rq->replica = -1;
+                if (!reroute || reroute(rq) < 0) {
+                    { std::lock_guard<std::mutex> g(mu); ++inflight; }             // complete() takes it off again
+                    complete(rq, (std::string(what) + " (replica ejected; no healthy replica has room)").c_str());
+                }
+            }
+            idle_cv.notify_all();
         }
         void complete(RoutedRequest *rq, const char *err) {
             {
@@ -178,13 +249,6 @@ class ReplicaRouter {
                 --inflight;
             }
             idle_cv.notify_all();
-        }
-        void fail_all(std::vector<RoutedRequest *> &owner, std::deque<RoutedRequest *> &fresh, std::deque<RoutedRequest *> &parked, const char *what) {
-            for (int b = 0; b < capacity; ++b) {
-                sched.abort(b);                                                    // Idle, nothing cached from a step that failed
-                if (owner[(size_t)b]) { complete(owner[(size_t)b], what); owner[(size_t)b] = nullptr; }
-            }
-            for (auto *q : {&fresh, &parked}) { for (RoutedRequest *rq : *q) complete(rq, what); q->clear(); }
         }
         static bool active(const std::vector<RoutedRequest *> &o) { for (auto *p : o) if (p) return true; return false; }
     };

@@ -36,8 +36,10 @@ namespace rwkv {
 using Tokens = std::vector<uint32_t>;
 
 struct CachedItem {                              // run.rs:201-223
-    std::vector<float> state;                    // public slab [C, N+2, L, 1]
-    std::vector<float> output;                   // logits of the last token of the cached prefix
+    // Immutable once cached and shared by reference: a checkout hands out the pointers (the reference clones an `Arc`'d tensor the
+    // same way, `backed.clone()` run.rs:962,979), so no lock is ever held across the copy of a 21 MB slab.
+    std::shared_ptr<const std::vector<float>> state;    // public slab [C, N+2, L, 1]
+    std::shared_ptr<const std::vector<float>> output;   // logits of the last token of the cached prefix
     uint64_t stamp = 0;                          // logical clock (the reference uses Instant)
 };
 
@@ -59,7 +61,7 @@ class PrefixCache {                              // `Trie<Tokens, CachedItem>` k
             n->next.clear();
         }                                                                           // n dies here with no children left
     }
-    struct Checkout { size_t prefix_len = 0; std::vector<float> state, output; bool hit = false; };
+    struct Checkout { size_t prefix_len = 0; std::shared_ptr<const std::vector<float>> state, output; bool hit = false; };
     // longest cached key that is a prefix of `tokens` (run.rs:447-455); refreshes the item's stamp (CachedItem::update)
     Checkout checkout(const Tokens &tokens, uint64_t now) {
         std::lock_guard<std::mutex> g(mu_);
@@ -112,7 +114,8 @@ class PrefixCache {                              // `Trie<Tokens, CachedItem>` k
             n = slot.get();
         }
         if (!n->item) { n->item.reset(new CachedItem()); ++count_; n->item->stamp = now; n->age = by_age_.emplace(now, n); }
-        n->item->state = std::move(state); n->item->output = std::move(output);
+        n->item->state = std::make_shared<const std::vector<float>>(std::move(state));
+        n->item->output = std::make_shared<const std::vector<float>>(std::move(output));
         touch(n, now);
         while (count_ > max_cached_) evict_oldest();                                // `Cache::maintain`, run.rs:237-257
     }
@@ -265,22 +268,22 @@ class Scheduler {
         // (The reference does this for all three choices, Continue included: run.rs:548-626.)
         // A request that is cached whole starts with an empty suffix and the cached output row: the process loop samples from
         // it without touching the engine (`(0, Some(output)) => output`, run.rs:809-811).
-        PrefixCache::Checkout co;
-        bool cached_whole = false;
-        {
-            std::lock_guard<std::mutex> g(cache_mu_);
-            PrefixCache &cache = cache_of(state_id);
-            co = cache.checkout(tokens, clock_);
-            cached_whole = cache.contains(tokens);
-        }
+        // `cache_mu_` guards the MAP of caches only and is held just long enough to find this request's trie (map entries are
+        // node-stable, and only this thread — the engine's one driving thread — ever erases one, in check_in_state); the trie has its
+        // own mutex, and a checkout copies two pointers under it, not a slab: a router thread probing `match_len` on this replica
+        // never waits behind a 21 MB memcpy.
+        PrefixCache *cache = nullptr;
+        { std::lock_guard<std::mutex> g(cache_mu_); cache = &cache_of(state_id); }
+        PrefixCache::Checkout co = cache->checkout(tokens, clock_);
+        const bool cached_whole = cache->contains(tokens);
         const size_t len = co.hit ? co.prefix_len : 0;
-        if (co.hit) e_.state.load(co.state, batch);
+        if (co.hit) e_.state.load(*co.state, batch);
         else if (state_id != 0) e_.state.load(init_states_[state_id], batch);       // `state.unwrap_or_else(|| self.state.init())`, run.rs:476-477
         else e_.state.load(e_.state.init(), batch);
         Request r;
         r.prefix.assign(tokens.begin(), tokens.begin() + (long)len);
         r.suffix.assign(tokens.begin() + (long)len, tokens.end());
-        r.output = co.hit ? co.output : std::vector<float>();
+        r.output = co.hit ? *co.output : std::vector<float>();
         r.option = option;
         r.state_id = state_id;
         r.prompt_len = tokens.size();
@@ -376,9 +379,10 @@ class Scheduler {
         if (!r.suffix.empty()) throw std::logic_error("finish(): tokens still pending");
         ++clock_;
         if (!r.prefix.empty() && !r.output.empty()) {
-            auto slab = e_.state.back(batch);                                      // device round trip OUTSIDE the cache lock
-            std::lock_guard<std::mutex> g(cache_mu_);
-            cache_of(r.state_id).insert(r.prefix, std::move(slab), r.output, clock_);
+            auto slab = e_.state.back(batch);                                      // device round trip OUTSIDE any lock
+            PrefixCache *cache = nullptr;
+            { std::lock_guard<std::mutex> g(cache_mu_); cache = &cache_of(r.state_id); }
+            cache->insert(r.prefix, std::move(slab), r.output, clock_);
         }
         slots_[batch].kind = SlotKind::Idle;
         slots_[batch].content = r.prefix;
@@ -455,8 +459,9 @@ class Scheduler {
             }
             if (r.cache_prompt && r.suffix.empty() && r.prefix.size() == r.prompt_len && !r.output.empty()) {   // run.rs:829-838
                 auto slab = e_.state.back((int)b);
-                std::lock_guard<std::mutex> g(cache_mu_);
-                cache_of(r.state_id).insert(r.prefix, std::move(slab), r.output, ++clock_);
+                PrefixCache *cache = nullptr;
+                { std::lock_guard<std::mutex> g(cache_mu_); cache = &cache_of(r.state_id); }
+                cache->insert(r.prefix, std::move(slab), r.output, ++clock_);
                 r.cache_prompt = false;
             }
         }
@@ -479,7 +484,7 @@ class Scheduler {
         return it->second;
     }
     size_t max_cached_;
-    mutable std::mutex cache_mu_;                    // guards caches_ and the tries inside (held for host work only, never across a device call)
+    mutable std::mutex cache_mu_;                    // guards the MAP caches_ (lookup / erase); each trie is guarded by its own PrefixCache::mu_
     std::map<uint64_t, PrefixCache> caches_;
     std::map<uint64_t, std::vector<float>> init_states_;
     uint64_t clock_ = 0;

@@ -99,33 +99,50 @@ impl Engine {
         let c = CString::new(path).map_err(|_| Error { code: sys::RWKV_ERR_INVALID, message: "path contains NUL".into() })?;
         check(unsafe { sys::rwkv_engine_save_prefab(self.raw, c.as_ptr()) })
     }
-    /// rows one call can emit: a `Full` slot emits at most `token_chunk_size` rows, a `Last` slot one
-    pub fn rows_needed(&self, input: &[SlotInput]) -> usize {
-        input.iter().map(|s| match (s.tokens.is_empty(), s.option) {
-            (true, _) | (_, OutputOption::None) => 0, (_, OutputOption::Last) => 1,
-            (_, OutputOption::Full) => s.tokens.len().min(self.token_chunk_size) }).sum()
+    /// Rows each slot can emit in the NEXT call, computed the way the engine computes them: `rwkv_plan_chunk` is the engine's own
+    /// split of the `token_chunk_size` budget over the slots (the call consumes at most `token_chunk_size` tokens IN TOTAL, so two
+    /// `Full` slots of 100 tokens at chunk 128 emit 128 rows together, not 200); a `Full` slot emits one row per consumed token, a
+    /// `Last` slot one row when the call exhausts its tokens, a `None` slot nothing.  The sum is <= token_chunk_size + max_batch.
+    pub fn plan_rows(&self, input: &[SlotInput]) -> Result<Vec<usize>> {
+        let pending: Vec<usize> = input.iter().map(|s| s.tokens.len()).collect();
+        let mut take = vec![0i32; input.len()];
+        check(unsafe { sys::rwkv_plan_chunk(self.max_batch as i32, self.token_chunk_size as i32, pending.as_ptr(), take.as_mut_ptr()) })?;
+        Ok(input.iter().zip(&take).map(|(s, &t)| match s.option {
+            OutputOption::None => 0,
+            OutputOption::Last => usize::from(t > 0 && t as usize == s.tokens.len()),
+            OutputOption::Full => t.max(0) as usize }).collect())
     }
+    pub fn rows_needed(&self, input: &[SlotInput]) -> Result<usize> { Ok(self.plan_rows(input)?.iter().sum()) }
     /// `runtime.infer(input)` (run.rs:1143): ONE step over <= token_chunk_size tokens.  Consumed tokens are drained from `input`;
-    /// returns, per slot, the rows it emitted as `(offset_in_floats, n_rows)` into `logits`.
+    /// returns, per slot, the rows it emitted as `(offset_in_floats, n_rows)` into `logits` (`(0, 0)` for a slot without rows).
+    /// Never panics on a caller mistake: a wrong slot count or a block that is too small comes back as `Err` (the infer task treats
+    /// it like any other runtime error, run.rs:1143 `?`) instead of taking the server down.
     pub fn infer(&self, input: &mut [SlotInput], logits: &mut PinnedLogits) -> Result<Vec<(usize, usize)>> {
-        assert_eq!(input.len(), self.max_batch, "one SlotInput per state slot");
+        if input.len() != self.max_batch {
+            return Err(Error { code: sys::RWKV_ERR_INVALID, message: format!("infer: {} slot inputs for max_batch {}", input.len(), self.max_batch) });
+        }
         let v = self.info.num_vocab as usize;
-        assert!(self.rows_needed(input) * v <= logits.floats, "logits block too small");
+        let rows = self.plan_rows(input)?;
+        let total: usize = rows.iter().sum();
+        if total * v > logits.floats {
+            return Err(Error { code: sys::RWKV_ERR_INVALID, message: format!("infer: logits block holds {} rows, the step emits {}", logits.floats / v, total) });
+        }
         let inp: Vec<_> = input.iter().map(|s| sys::rwkv_slot_input {
             tokens: if s.tokens.is_empty() { ptr::null() } else { s.tokens.as_ptr() }, n_tokens: s.tokens.len(), option: s.option as i32, reserved: 0 }).collect();
         let mut off = 0usize;
-        let mut out: Vec<_> = input.iter().map(|s| {
-            let rows = self.rows_needed(std::slice::from_ref(s));
-            let o = sys::rwkv_slot_output { logits: if rows == 0 { ptr::null_mut() } else { unsafe { logits.ptr.add(off) } },
-                                            logits_capacity_rows: rows, n_rows: 0, n_consumed: 0 };
-            off += rows * v;                      // consecutive pieces of one pinned block: one D2H copy
+        let mut offs = Vec::with_capacity(rows.len());
+        let mut out: Vec<_> = rows.iter().map(|&r| {
+            let o = sys::rwkv_slot_output { logits: if r == 0 { ptr::null_mut() } else { unsafe { logits.ptr.add(off) } },
+                                            logits_capacity_rows: r, n_rows: 0, n_consumed: 0 };
+            offs.push(off);
+            off += r * v;                         // consecutive pieces of one pinned block: one D2H copy
             o
         }).collect();
         check(unsafe { sys::rwkv_infer(self.raw, inp.as_ptr(), out.as_mut_ptr()) })?;     // fatal for the infer task, like `?` at run.rs:1143
         let mut res = Vec::with_capacity(out.len());
-        for (s, o) in input.iter_mut().zip(&out) {
+        for ((s, o), &at) in input.iter_mut().zip(&out).zip(&offs) {
             s.tokens.drain(..o.n_consumed);
-            res.push((unsafe { o.logits.offset_from(logits.ptr) }.max(0) as usize, o.n_rows));
+            res.push(if o.n_rows == 0 { (0, 0) } else { (at, o.n_rows) });      // no pointer arithmetic on the null pointer of a row-less slot
         }
         Ok(res)
     }

@@ -28,6 +28,7 @@ stores them (convert_safetensors.py:64 `.half()`).
 from __future__ import annotations
 
 import json
+import re
 import struct
 from dataclasses import dataclass
 
@@ -247,10 +248,12 @@ class RwkvRef:
     def __init__(self, tensors: dict[str, np.ndarray], quant_layers: int = 0,
                  quant_type: int = QUANT_NONE, lora: list | None = None):
         """`lora`: [(lora_tensors, alpha), ...] blended at load like `ModelBuilder::lora(Lora { data, blend: LoraBlend::full(alpha) })`
-        (lib.rs:466-482).  `full(alpha)` matches every tensor name.  As published in web-rwkv's loader (0.10, not vendored in the
-        reference tree — restated, unpinned): a matrix `X.weight` with `X.lora.0` [in, r] / `X.lora.1` [out, r] in the file gets
-        W += alpha * B A^T; any other tensor the file holds under the model's own name is blended whole, v += alpha * l.  Matrices are
-        blended on the fp16 values in fp32 and rounded back once (then quantised, if their layer is); vectors stay fp32."""
+        (lib.rs:466-482).  As published in web-rwkv's loader (runtime/loader.rs, 0.10.x; not vendored in the reference tree —
+        restated, UNPINNED): `full(alpha)` is the one pattern `blocks\.([0-9]+)\.([0-9a-zA-Z\.\_]+)` — per-block tensors only; a matrix
+        `X.weight` with `X.lora.0` [in, r] / `X.lora.1` [out, r] in the file gets W += alpha * B A^T (factor [alpha, 1]); any other
+        tensor the file holds under the model's own name is blended whole, v = alpha * l + (1 - alpha) * v (factor [alpha, 1 - alpha]:
+        alpha = 1 replaces a fine-tuned vector).  Matrices are blended on the fp16 values in fp32 and rounded back once (then
+        quantised, if their layer is); vectors stay fp32."""
         self.info = model_info(tensors)
         self.quant_layers = quant_layers
         self.quant_type = quant_type
@@ -263,7 +266,8 @@ class RwkvRef:
         for k, v in tensors.items():
             v16 = np.asarray(v, dtype=np.float16)
             vec32 = None
-            for lt, alpha in (lora or []):
+            in_scope = re.fullmatch(r"blocks\.[0-9]+\..+", k) is not None
+            for lt, alpha in ((lora or []) if in_scope else []):
                 stem = k[:-len(".weight")] if k.endswith(".weight") else k
                 if stem + ".lora.0" in lt and stem + ".lora.1" in lt and v16.ndim == 2:
                     A = np.asarray(lt[stem + ".lora.0"], np.float16).astype(np.float32)
@@ -271,7 +275,7 @@ class RwkvRef:
                     v16 = (v16.astype(np.float32) + np.float32(alpha) * (B @ A.T)).astype(np.float16)
                 elif k in lt:
                     base = v16.astype(np.float32) if vec32 is None else vec32
-                    vec32 = base + np.float32(alpha) * np.asarray(lt[k], np.float16).astype(np.float32).reshape(base.shape)
+                    vec32 = np.float32(alpha) * np.asarray(lt[k], np.float16).astype(np.float32).reshape(base.shape) + (np.float32(1.0) - np.float32(alpha)) * base
             if k in qn:
                 v16 = fake_quant(v16, quant_type)
             dst = big_empty(v16.shape, np.float32)

@@ -8,7 +8,7 @@ import ctypes, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "ai00_server_amd")
-LIB = os.path.join(PKG, "librwkv_hip_trace.so")
+LIB = os.environ.get("TRACE_LIB") or os.path.join(PKG, "librwkv_hip_trace.so")
 
 def build(level):
     cs = os.path.join(PKG, "csrc")
@@ -22,6 +22,8 @@ def run():
     lib = ctypes.CDLL(LIB)
     us = ctypes.c_float(); blk = ctypes.c_float()
     cases = [("K3", 10240 + 64, 2560, 1), ("FkFr", 8960 + 2560, 2560, 1), ("Fv", 2560, 8960, 1), ("Wo", 2560, 2560, 1)]
+    if os.environ.get("FMT"):
+        cases = [(n, r, k, int(os.environ["FMT"])) for n, r, k, _ in cases]
     for T in [int(x) for x in os.environ.get("TS", "32,1").split(",")]:
         for name, rows, K, fmt in cases:
             buf = np.zeros(4096 * 8, dtype=np.uint64)
@@ -38,8 +40,8 @@ def run():
             def st(i):
                 v = (tr[:, :, i][act & (tr[:, :, i] > 0)] - t0) / 100.0   # us (100 MHz)
                 return "n/a" if v.size == 0 else f"min {v.min():5.2f} med {np.median(v):5.2f} max {v.max():5.2f}"
-            print(f"T={T} {name:5s} rows={rows} K={K}: {us.value:6.2f} us/launch, {blk.value:.0f} blocks, waves/block {act[0].sum()}")
-            for i, lab in ((0, "entry"), (6, "X issued"), (1, "X+W0 issued"), (5, "loads landed"), (2, "mfma+park done"), (3, "after barrier"), (4, "exit")):
+            print(f"T={T} fmt={fmt} {name:5s} rows={rows} K={K}: {us.value:6.2f} us/launch, {blk.value:.0f} blocks, waves/block {act[0].sum()}")
+            for i, lab in ((0, "entry"), (6, "slice start"), (7, "X issued"), (1, "X+W issued"), (5, "loads landed"), (2, "mfma+park done"), (3, "after barrier"), (4, "exit")):
                 print(f"      {lab:15s} {st(i)}")
 
 if __name__ == "__main__":

@@ -21,9 +21,12 @@ struct FakeEngine {
     std::atomic<int> calls{0};   // read by the test thread while a replica thread may be stepping
     std::vector<int> riders;
     std::atomic<int> fail_at{-1};   // infer call number that throws (a device error in the middle of a serving loop); -1: never
+    std::atomic<int> fail_from{-1}; // every infer call from this number on throws (a STICKY device fault: HIP errors do not go away); -1: never
     FakeEngine(int B, int chunk_) : max_batch(B), chunk(chunk_) { info.num_vocab = 8; state.slots.assign((size_t)B, state.init()); }
     std::vector<rwkv::RnnOutputBatch> infer(rwkv::RnnInput &in) {
-        if (++calls == fail_at.load()) throw std::runtime_error("fake device error");
+        const int call = ++calls;
+        if (call == fail_at.load()) throw std::runtime_error("fake device error");
+        if (fail_from.load() >= 0 && call >= fail_from.load()) throw std::runtime_error("fake sticky device fault");
         int n = 0;
         std::vector<rwkv::RnnOutputBatch> out((size_t)max_batch);
         for (int b = 0; b < max_batch; ++b) {

@@ -1,6 +1,8 @@
 // CPU test of include/rwkv_router.hpp over fake engines (no GPU, no HIP): prefix affinity, least-busy placement, full
 // replicas skipped, per-replica threads, results identical to a single-engine run.
 #include <cassert>
+#include <chrono>
+#include <thread>
 #include <cstdio>
 
 #include "../../include/rwkv_router.hpp"
@@ -113,6 +115,61 @@ int main() {
         CHECK(router.submit(&t) >= 0);
         router.drain();
         CHECK(t.done && t.failed && t.error == "sampler blew up");
+    }
+    // --- a STICKY engine fault (every step throws from some call on, like a HIP device fault): after `eject_after` consecutive
+    //     failures the replica is ejected — it no longer wins the least-busy tie, new traffic goes to the healthy replica and
+    //     completes, requests it had accepted but not started are re-routed, and with no healthy replica left submit() says -1
+    {
+        FakeEngine e0(2, 100), e1(2, 100);
+        e0.fail_from = 2;                                                // replica 0: first step fine, then broken for good
+        std::vector<FakeEngine *> es{&e0, &e1};
+        std::vector<RoutedRequest> first(2), later(12);
+        std::deque<RoutedRequest> probes;                                // stable addresses; declared before the router: they outlive its threads
+        first[0].tokens = {1, 2}; first[0].max_new = 30; first[1].tokens = {3}; first[1].max_new = 30;
+        ReplicaRouter<FakeEngine> router(es, 256, 2);
+        CHECK(router.submit(&first[0]) == 0 && router.submit(&first[1]) == 1);
+        for (int spin = 0; spin < 20000 && router.healthy(0); ++spin) {  // keep feeding replica 0 until its failures add up
+            probes.emplace_back();
+            RoutedRequest *probe = &probes.back();
+            probe->tokens = {(uint32_t)(100 + spin)}; probe->max_new = 2;
+            if (router.submit(probe) < 0) std::this_thread::yield();
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        CHECK(!router.healthy(0) && router.healthy(1) && router.healthy_count() == 1);
+        router.drain();
+        CHECK(first[0].done && first[0].failed && first[0].error.find("sticky") != std::string::npos);
+        CHECK(first[1].done && !first[1].failed && first[1].generated == greedy_alone(first[1].tokens, 30));
+        const int calls_before = e0.calls.load();
+        for (int i = 0; i < 12; ++i) {                                   // an empty, broken replica must not absorb this traffic
+            later[(size_t)i].tokens = {(uint32_t)(7 + i), 1}; later[(size_t)i].max_new = 3;
+            int where;
+            while ((where = router.submit(&later[(size_t)i])) < 0) std::this_thread::yield();
+            CHECK(where == 1);
+        }
+        router.drain();
+        for (auto &q : later) CHECK(q.done && !q.failed && q.replica == 1 && q.generated == greedy_alone(q.tokens, 3));
+        CHECK(e0.calls.load() == calls_before);                          // nothing was even tried on the ejected engine
+        CHECK(router.route({42}).first == 1);
+        // revive: the operator reset the device
+        e0.fail_from = -1;
+        router.revive(0);
+        RoutedRequest back;
+        back.tokens = {5, 5}; back.max_new = 4;
+        CHECK(router.healthy(0) && router.submit(&back) == 0);
+        router.drain();
+        CHECK(back.done && !back.failed && back.generated == greedy_alone(back.tokens, 4));
+    }
+    {   // every replica broken: submit() returns -1 instead of queueing onto a dead engine
+        FakeEngine e0(1, 100);
+        e0.fail_from = 1;
+        std::vector<FakeEngine *> es{&e0};
+        RoutedRequest a, b;
+        a.tokens = {1}; a.max_new = 5; b.tokens = {2}; b.max_new = 5;
+        ReplicaRouter<FakeEngine> router(es, 256, 1);
+        CHECK(router.submit(&a) == 0);
+        router.drain();
+        CHECK(a.done && a.failed && !router.healthy(0));
+        CHECK(router.submit(&b) == -1 && !b.done);
     }
     // --- many threads submitting at once: nobody gets a slot twice, in-flight never exceeds capacity, everything completes
     {

@@ -236,9 +236,10 @@ def test_lora_blend_at_load():
 
 @pytest.mark.parametrize("name", ["v5-tiny", "v6-tiny", "v7-tiny"])
 def test_lora_blends_vectors_as_well_as_matrices(name):
-    """`LoraBlend::full(alpha)` (lib.rs:466-482) matches EVERY tensor: the engine blends the projection matrices (W += alpha B A^T)
-    and whatever other tensor the LoRA file holds under the model's own name (token-shift mixes, decay, LayerNorm weights:
-    v += alpha l, before the load-time transform of the V5 decay).  Two LoRA files stack.  Against the oracle loaded the same way."""
+    """`LoraBlend::full(alpha)` (lib.rs:466-482) matches every `blocks.N.*` tensor: the engine blends the projection matrices
+    (W += alpha B A^T) and whatever other per-block tensor the LoRA file holds under the model's own name (token-shift mixes, decay,
+    LayerNorm weights: v = alpha l + (1 - alpha) v, before the load-time transform of the V5 decay); `ln_out.bias` in the file is outside
+    the pattern and must be ignored.  Two LoRA files stack.  Against the oracle loaded the same way (web-rwkv's loader restated, unpinned)."""
     t = R.synth_named(name)
     rng = np.random.default_rng(13)
     C, r = 128, 8

@@ -294,8 +294,9 @@ def test_compiled_fake_quantisation_is_bit_identical_to_the_numpy_one():
 
 
 def test_lora_argument_equals_blending_the_tensors_by_hand():
-    """`RwkvRef(..., lora=[(file, alpha)])` = the checkpoint with W += alpha B A^T on matrices (fp16 result) and v += alpha l on
-    every other tensor the LoRA file names (LoraBlend::full matches every tensor, lib.rs:466-482)."""
+    """`RwkvRef(..., lora=[(file, alpha)])` = the checkpoint with W += alpha B A^T on matrices (fp16 result) and
+    v = alpha l + (1 - alpha) v on every other `blocks.N.*` tensor the LoRA file names; tensors outside `blocks.N.*` are out of
+    `LoraBlend::full`'s pattern and stay as they are (lib.rs:466-482; web-rwkv's loader restated, unpinned — see RwkvRef.__init__)."""
     t = R.synth_named("v6-tiny")
     rng = np.random.default_rng(9)
     C, r, alpha = 128, 4, 0.75
@@ -303,14 +304,19 @@ def test_lora_argument_equals_blending_the_tensors_by_hand():
             "blocks.0.att.key.lora.1": (rng.standard_normal((C, r)) * 0.05).astype(np.float16),
             "blocks.1.att.time_mix_k": (rng.standard_normal((1, 1, C)) * 0.1).astype(np.float16),
             "blocks.0.ln2.weight": (rng.standard_normal(C) * 0.1).astype(np.float16),
-            "blocks.1.att.time_decay": (rng.standard_normal((1, 1, C)) * 0.1).astype(np.float16)}
+            "blocks.1.att.time_decay": (rng.standard_normal((1, 1, C)) * 0.1).astype(np.float16),
+            "ln_out.weight": (rng.standard_normal(C) * 0.1).astype(np.float16),                                  # outside the pattern
+            "head.lora.0": (rng.standard_normal((C, r)) * 0.05).astype(np.float16),
+            "head.lora.1": (rng.standard_normal((t["head.weight"].shape[0], r)) * 0.05).astype(np.float16)}
     a = R.RwkvRef(t, lora=[(lora, alpha)])
     k = "blocks.0.att.key.weight"
     want = (t[k].astype(np.float32) + np.float32(alpha) * (lora["blocks.0.att.key.lora.1"].astype(np.float32) @ lora["blocks.0.att.key.lora.0"].astype(np.float32).T)).astype(np.float16)
     np.testing.assert_array_equal(a.w[k], want.astype(np.float32))
     for name in ("blocks.1.att.time_mix_k", "blocks.0.ln2.weight", "blocks.1.att.time_decay"):
-        np.testing.assert_array_equal(a.w[name], t[name].astype(np.float32) + np.float32(alpha) * lora[name].astype(np.float32).reshape(t[name].shape))
-    assert np.array_equal(a.w["blocks.1.ln2.weight"], t["blocks.1.ln2.weight"].astype(np.float32))      # untouched
+        np.testing.assert_array_equal(a.w[name], np.float32(alpha) * lora[name].astype(np.float32).reshape(t[name].shape)
+                                      + (np.float32(1.0) - np.float32(alpha)) * t[name].astype(np.float32))
+    for name in ("blocks.1.ln2.weight", "ln_out.weight", "head.weight"):                                # untouched
+        assert np.array_equal(a.w[name], t[name].astype(np.float32)), name
     p = _prompt(a, 2, 9)
     base = R.RwkvRef(t)
     s0, s1 = base.init_state(), a.init_state()
