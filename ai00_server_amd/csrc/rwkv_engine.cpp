@@ -849,6 +849,7 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
         g.W = s.W->data; g.S = s.W->scales; g.fmt = s.W->fmt; g.rows = s.W->rows; g.K = K;
         g.xhi = s.x.hi + (s.xoff >> 5) * 512; g.xlo = s.x.lo ? s.x.lo + (s.xoff >> 5) * 512 : nullptr; g.ldx = s.x.ld;   // column offset = whole k-tiles
         g.spb = spb; g.nw = nw; g.ksb = ksb;
+        g.Kb = Kb; g.nslice = nslice;
         g.nblk_strip = (strips + spb - 1) / spb;
         g.block_begin = blocks;
         blocks += g.nblk_strip * ksb;
@@ -1842,10 +1843,25 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
         HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
         std::vector<float *> parts;                                   // partial-sum target when K needs a block split
         float *pbuf = (float *)dal((size_t)8 * T * rows * 4);
+        // RWKV_BENCH_DUAL=1 (dev): TWO dependent chains over the same matrices on two streams of one graph — what two half-batches
+        // of a decode step would do (each chain's launch k streams matrix k; the chains are independent of each other)
+        const bool dual = std::getenv("RWKV_BENCH_DUAL") && std::atoi(std::getenv("RWKV_BENCH_DUAL")) != 0;
+        hipStream_t st2 = nullptr;
+        Opd x2 = x;
+        float *out2 = out, *pbuf2 = pbuf;
+        if (dual) {
+            HIP_CHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+            x2.hi = (_Float16 *)dal(xcap); x2.lo = (_Float16 *)dal(xcap);
+            HIP_CHECK(hipMemset(x2.hi, 0, xcap)); HIP_CHECK(hipMemset(x2.lo, 0, xcap));
+            out2 = (float *)dal((size_t)T * rows * 4);
+            pbuf2 = (float *)dal((size_t)8 * T * rows * 4);
+        }
+        hipStream_t run_st = st;
         auto run = [&](int n) {
+            const bool second = run_st != st;
             for (int i = 0; i < n; ++i) {
                 std::vector<ProbSpec> ps(1);
-                ps[0].W = &mats[i % nmat]; ps[0].x = x; ps[0].out = K > 5120 ? pbuf : out; ps[0].ldo = rows;
+                ps[0].W = &mats[i % nmat]; ps[0].x = second ? x2 : x; ps[0].out = K > 5120 ? (second ? pbuf2 : pbuf) : (second ? out2 : out); ps[0].ldo = rows;
                 ps[0].partial = K > 5120;
                 GemmLaunch Lh;
                 if (T >= GEMM_TILE_MIN_T) {                      // prefill path; `spb` selects the tile shape (0..3), -1 = auto
@@ -1864,20 +1880,29 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
                     Lh.total_blocks = gemm_tile_blocks(shape, rows, T);
                     Lh.xcd_map = knobs().tile_xcd;
                     if (lds_kib) *lds_kib = (float)Lh.total_blocks;
-                    launch_gemm_tile(Lh, shape, hilo != 0, st);
+                    launch_gemm_tile(Lh, shape, hilo != 0, run_st);
                     continue;
                 }
                 plan_gemm(Lh, ps, T, hilo != 0, (long)T * rows, spb);
                 if (lds_kib) *lds_kib = (float)Lh.total_blocks;
-                launch_gemm(Lh, hilo != 0, st);
+                launch_gemm(Lh, hilo != 0, run_st);
             }
         };
         run(nmat);
         HIP_CHECK(hipStreamSynchronize(st));
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+        if (dual) { HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); }
         hipGraph_t g = nullptr;
         hipGraphExec_t ge = nullptr;
         HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        if (dual) {
+            HIP_CHECK(hipEventRecord(ev_fork, st));
+            HIP_CHECK(hipStreamWaitEvent(st2, ev_fork, 0));
+            run_st = st2; run(iters); run_st = st;
+            HIP_CHECK(hipEventRecord(ev_join, st2));
+        }
         run(iters);
+        if (dual) HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
         HIP_CHECK(hipStreamEndCapture(st, &g));
         HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         HIP_CHECK(hipGraphLaunch(ge, st));
@@ -1892,6 +1917,7 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
         if (us_per_launch) *us_per_launch = ms * 1e3f / iters;
         for (void *p : bufs) (void)hipFree(p);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
+        if (dual) { (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipStreamDestroy(st2); }
     });
 }
 

@@ -101,6 +101,7 @@ struct GemmProb {
     int spb;                        // strips (of 16 output rows) per block
     int nw;                         // waves covering the block's K range (KW = 512 or 256 k each)
     int ksb;                        // blocks splitting K (partials written, linear epilogue only)
+    int Kb, nslice;                 // K / ksb and ceil(Kb / (KSW * 32)) of the launch's variant: computed by the host, not by every wave
     int nblk_strip;                 // blocks per K-slice = ceil(strips / spb)
     int block_begin;                // first block of this problem in the launch
     // epilogue:  v = act(acc + bias[row]);  POST_MUL: v *= m0[t][row];  POST_MIX: v = m0 + m1 * v

@@ -278,9 +278,6 @@ __device__ __forceinline__ f16x8 frag(const WRound<FMT> &w, int ks, const Nf4Lut
         return __builtin_bit_cast(f16x8, w.q[ks]);
     } else if constexpr (FMT == W_INT8) {
         const u32x4 q = w.q[ks >> 1];
-#ifdef RWKV_EXP_NODQ
-        { u32x4 r0; r0.x = (ks & 1) ? q.z : q.x; r0.y = (ks & 1) ? q.w : q.y; r0.z = w.s.x; r0.w = w.s.y; return __builtin_bit_cast(f16x8, r0); }
-#endif
         const u32 d0 = (ks & 1) ? q.z : q.x, d1 = (ks & 1) ? q.w : q.y;
         const u32 ab = (ks >> 2) ? w.s.y : w.s.x;                // 128-block inside the 256-group
         const f16x2 abh = as_h2(ab);
@@ -509,20 +506,42 @@ __device__ __forceinline__ void shift_commit(const ShiftCommit &c) {
 }
 
 #if RWKV_PART_ON(0)
+// make a wave-uniform value live in SGPRs from this point on (an empty asm the compiler cannot look through)
+__device__ __forceinline__ int pin_s(int v) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ const void *pin_p(const void *p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)pin_s((int)(unsigned)v), hi = (unsigned)pin_s((int)(unsigned)(v >> 32));
+    return (const void *)(((unsigned long long)hi << 32) | lo);
+}
+// the switch outside, four values inside: one pass over the branches per output fragment instead of one per element (same arithmetic)
+__device__ __forceinline__ void apply_act4(int act, float (&v)[4]) {
+    switch (act) {
+        case ACT_NONE: break;
+        case ACT_TANH: for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]); break;
+        case ACT_SIGMOID: for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]); break;
+        case ACT_RELU2: for (int r = 0; r < 4; ++r) { const float q = fmaxf(v[r], 0.0f); v[r] = q * q; } break;
+        case ACT_SILU: for (int r = 0; r < 4; ++r) v[r] = v[r] * sigmoidf_(v[r]); break;
+        case ACT_DECAY7: for (int r = 0; r < 4; ++r) v[r] = expf(-0.606531f * sigmoidf_(v[r])); break;
+        default: break;
+    }
+}
 template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, int FMT, bool LNP>
 __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
     constexpr int KW = KSW * 32, SUB = KSW / RS, RK = RS * 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches/addresses
     const int lb = (int)blockIdx.x - P.block_begin;
-    const int kb = lb / P.nblk_strip, sb = lb - kb * P.nblk_strip;
+    // (a scalar integer division is ~40 SALU instructions in front of the first load: the host hands over Kb and nslice, and only
+    // K-split problems divide the block index)
+    const int kb = P.ksb == 1 ? 0 : lb / P.nblk_strip, sb = lb - kb * P.nblk_strip;
     const int spb = P.spb, nw = P.nw;                             // nw = waves of this block that own K slices
     const int strip0 = sb * spb;
     const int nstrip = min(spb, (P.rows >> 4) - strip0);
-    const int Kb = P.K / P.ksb;
+    const int Kb = P.Kb;                                          // K / ksb
     const int kbeg = kb * Kb, kend = kbeg + Kb;
-    const int nslice = (Kb + KW - 1) / KW;                        // >= nw; a wave takes slices wave, wave+nw, ...
+    const int nslice = P.nslice;                                  // ceil(Kb / KW) >= nw; a wave takes slices wave, wave+nw, ...
     f32x4 *red = (f32x4 *)smem;                                   // [spb][nw][NT][64 lanes]
+
     Nf4Lut lut;
     if constexpr (FMT == W_NF4) lut = make_nf4_lut();
 
@@ -537,9 +556,6 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     f32x4 &d = (NT == 1 && (ks & 1)) ? acc2[nt] : acc[nt];   // NT = 2 already has two independent chains
-#ifdef RWKV_EXP_NOMFMA
-                    { const f32x4 af = __builtin_bit_cast(f32x4, a), xf = __builtin_bit_cast(f32x4, xb[nt][sub * RS + ks]); d[0] += af[0] * xf[0]; d[1] += af[1]; d[2] += af[2]; d[3] += af[3]; continue; }
-#endif
                     d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[nt][sub * RS + ks], d, 0, 0, 0);
                     if constexpr (HILO) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xl[nt][sub * RS + ks], d, 0, 0, 0);
                 }
@@ -561,23 +577,20 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
     constexpr int RD = (!SHOT && FMT != W_F16) ? ((NT >= 2 || HILO || LNP) ? 2 : 4) : 1;
     WRound<FMT> ring[RD];
     // weights of one K slice of this wave: everything (single shot), the first RD rounds (ring) or the first round
-    // `part`: 0 = everything, 1 = the first strip's rounds only, 2 = the rest (see the issue order below)
-    auto issue_w = [&](int k0, int nsub, int nround, bool ringed, int part) {
+    auto issue_w = [&](int k0, int nsub, int nround, bool ringed) {
         if constexpr (SHOT) {
             // single shot: every weight tile of this wave is in flight before the first MFMA (host: spb * SUB <= MAXR)
 #pragma unroll
             for (int r = 0; r < MAXR; ++r) {
                 const int s = r / SUB, sub = r % SUB;
-                if ((part == 0 || (part == 1) == (s == 0)) && s < nstrip && sub < nsub)
-                    load_round<FMT, TAIL>(w[r], P, strip0 + s, k0 + sub * RK, kend, true, lane);
+                if (s < nstrip && sub < nsub) load_round<FMT, TAIL>(w[r], P, strip0 + s, k0 + sub * RK, kend, true, lane);
             }
         } else if (ringed) {
 #pragma unroll
             for (int j = 0; j < RD; ++j)
-                if ((part == 0 || (part == 1) == (j < SUB)) && j < nround)
-                    load_round<FMT, TAIL>(ring[j], P, strip0 + j / SUB, k0 + (j % SUB) * RK, kend, true, lane);
+                if (j < nround) load_round<FMT, TAIL>(ring[j], P, strip0 + j / SUB, k0 + (j % SUB) * RK, kend, true, lane);
         } else {
-            if (part != 2) load_round<FMT, TAIL>(cur, P, strip0, k0, kend, true, lane);
+            load_round<FMT, TAIL>(cur, P, strip0, k0, kend, true, lane);
         }
     };
 
@@ -633,7 +646,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                 _Float16 *op_l = (_Float16 *)(lred + 64);
                 LnCarry carry;
                 ln_prologue_load(L.lnp, L.T, xx_l, pv_l, lred, blockIdx.x == 0, carry);
-                issue_w(k0, nsub, nround, ringed, 0);          // the weights fly while the rows are reduced and normalised
+                issue_w(k0, nsub, nround, ringed);             // the weights fly while the rows are reduced and normalised
                 ln_prologue_finish<HILO>(L.lnp, L.T, P.lnp_mu, xx_l, pv_l, op_l, lred, blockIdx.x == 0, carry);
                 const int tl = min(lane & 15, L.T - 1);
                 const _Float16 *oph = op_l + lnp_op_off(L.T, k0 + (lane >> 4) * 8, tl);
@@ -644,23 +657,9 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                     if constexpr (HILO) xl[0][ks] = in ? *(const f16x8 *)(oph + (size_t)L.T * L.lnp.C + (size_t)ks * 4 * L.T * 8) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                 }
             } else {
-#if defined(RWKV_EXP_W0FIRST)
-                // first strip's weights -> X -> the other strips: HBM is asked for its first bytes before the CU spends ~1 us pulling
-                // the operand from L2, and the first strip's MFMAs still only wait for (strip 0, X) in vmcnt order
-                issue_w(k0, nsub, nround, ringed, 1);
-                load_x();
-                issue_w(k0, nsub, nround, ringed, 2);
-#elif defined(RWKV_EXP_NOX)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int ks = 0; ks < KSW; ++ks) { xb[nt][ks] = (f16x8){1, 1, 1, 1, 1, 1, 1, 1}; if constexpr (HILO) xl[nt][ks] = xb[nt][ks]; }
-                issue_w(k0, nsub, nround, ringed, 0);
-#else
                 load_x();
                 TRACE_PT(7);
-                issue_w(k0, nsub, nround, ringed, 0);
-#endif
+                issue_w(k0, nsub, nround, ringed);
             }
 #ifdef RWKV_TRACE
             TRACE_PT(1);
@@ -732,34 +731,59 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
             (void)nround;
         }
         TRACE_PT(2);
-        __syncthreads();
-        TRACE_PT(3);
-        // ---- reduce + epilogue: (strip, n-tile) items round-robin over the block's waves
-        const int nwaves = blockDim.x >> 6;
-        for (int item = wave; item < nstrip * NT; item += nwaves) {
+        // ---- reduce + epilogue: (strip, n-tile) items round-robin over the block's waves.  Everything an item needs that does not
+        // depend on the reduction (bias, the POST_MUL / POST_MIX operands) is requested BEFORE the barrier, for the wave's first item,
+        // and lands while the wave waits for the block's slowest; the K partials are read with ONE wait (all loads, then the adds, in
+        // slice order as before) instead of a load-wait-add round trip per partial.
+        // Epilogue parameters, pinned into SGPRs HERE (in front of the barrier, behind the K loop whose registers they must not crowd).
+        // The argument struct lives in the kernarg segment, so every field read is a scalar load; left to the compiler they were
+        // re-read inside the item loop — a scalar-cache round trip in front of every output row, inside the ~1 us between the barrier
+        // and the end of the kernel.
+        const int e_act = pin_s(P.act), e_post = pin_s(P.post), e_ldm = pin_s(P.ldm), e_ldo = pin_s(P.ldo), e_ldh = pin_s(P.ldh);
+        const float *e_bias = (const float *)pin_p(P.bias);
+        const bool e_f32 = pin_s(P.out_f32 != nullptr) != 0, e_hi = pin_s(P.out_hi != nullptr) != 0, e_lo = pin_s(P.out_lo != nullptr) != 0;
+        const int nwaves = blockDim.x >> 6, nitem = nstrip * NT;
+        float4 pb = make_float4(0.f, 0.f, 0.f, 0.f), pm0 = pb, pm1 = pb;
+        auto prefetch = [&](int item) {
             const int s = item / NT, nt = item - s * NT;
-            f32x4 v4 = red[((s * nw) * NT + nt) * 64 + lane];
-            for (int w2 = 1; w2 < nw; ++w2) v4 += red[((s * nw + w2) * NT + nt) * 64 + lane];
             const int row0 = (strip0 + s) * 16 + (lane >> 4) * 4;
             const int t = t0 + nt * 16 + (lane & 15);
             if (t < L.T) {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = v4[r];
-                    if (P.bias) x += P.bias[row0 + r];
-                    x = apply_act(P.act, x);
-                    v[r] = x;
+                if (e_bias) pb = *(const float4 *)(e_bias + row0);
+                if (e_post != POST_NONE) pm0 = act_ld4(bm0, (long)t * e_ldm + row0);
+                if (e_post == POST_MIX) pm1 = act_ld4(bm1, (long)t * e_ldm + row0);
+            }
+        };
+        if (wave < nitem) prefetch(wave);
+        __syncthreads();
+        TRACE_PT(3);
+        for (int item = wave; item < nitem; item += nwaves) {
+            if (item != wave) prefetch(item);
+            const int s = item / NT, nt = item - s * NT;
+            // K partials in slice order, three LDS reads per wait (ten of them in one array made hipcc keep 40 more registers live
+            // across the K loop and spill; one read per wait was nine LDS round trips)
+            const f32x4 *rp = red + ((s * nw) * NT + nt) * 64 + lane;
+            f32x4 v4 = rp[0];
+            for (int w2 = 1; w2 < nw; w2 += 3) {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 pa = rp[w2 * NT * 64];
+                const f32x4 pb2 = w2 + 1 < nw ? rp[(w2 + 1) * NT * 64] : zero;
+                const f32x4 pc = w2 + 2 < nw ? rp[(w2 + 2) * NT * 64] : zero;
+                v4 += pa; v4 += pb2; v4 += pc;
+            }
+            const int row0 = (strip0 + s) * 16 + (lane >> 4) * 4;
+            const int t = t0 + nt * 16 + (lane & 15);
+            if (t < L.T) {
+                float v[4] = {v4[0], v4[1], v4[2], v4[3]};
+                if (e_bias) { v[0] += pb.x; v[1] += pb.y; v[2] += pb.z; v[3] += pb.w; }
+                apply_act4(e_act, v);
+                if (e_post == POST_MUL) {
+                    v[0] *= pm0.x; v[1] *= pm0.y; v[2] *= pm0.z; v[3] *= pm0.w;
+                } else if (e_post == POST_MIX) {
+                    v[0] = pm0.x + pm1.x * v[0]; v[1] = pm0.y + pm1.y * v[1]; v[2] = pm0.z + pm1.z * v[2]; v[3] = pm0.w + pm1.w * v[3];
                 }
-                if (P.post == POST_MUL) {
-                    const float4 m = act_ld4(bm0, (long)t * P.ldm + row0);
-                    v[0] *= m.x; v[1] *= m.y; v[2] *= m.z; v[3] *= m.w;
-                } else if (P.post == POST_MIX) {
-                    const float4 m = act_ld4(bm0, (long)t * P.ldm + row0), n = act_ld4(bm1, (long)t * P.ldm + row0);
-                    v[0] = m.x + n.x * v[0]; v[1] = m.y + n.y * v[1]; v[2] = m.z + n.z * v[2]; v[3] = m.w + n.w * v[3];
-                }
-                if (P.out_f32) act_st4(bo32, (long)t * P.ldo + row0, make_float4(v[0], v[1], v[2], v[3]));
-                if (P.out_hi) act_store_operand4(boh, bol, P.out_lo != nullptr, opd_off(t, row0, P.ldh), make_float4(v[0], v[1], v[2], v[3]));
+                if (e_f32) act_st4(bo32, (long)t * e_ldo + row0, make_float4(v[0], v[1], v[2], v[3]));
+                if (e_hi) act_store_operand4(boh, bol, e_lo, opd_off(t, row0, e_ldh), make_float4(v[0], v[1], v[2], v[3]));
             }
         }
         if (t0 + NT * 16 < L.T) __syncthreads();
