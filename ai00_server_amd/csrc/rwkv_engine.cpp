@@ -866,6 +866,15 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
     Lh.total_blocks = blocks;
     Lh.threads = max_nw * 64;
     Lh.lds_items = lds_items;
+    // 17..32-row steps over quantised weights: a ring of two rounds in flight per wave instead of every load issued up-front.  A wave that
+    // has issued its 16 operand tiles and 12 weight tiles sits in the issue queue for ~3 us (profiles/r4_trace_gemm_timeline_t1_t32.log)
+    // and only then starts on a strip that landed long ago; with the ring its dequantisation starts a round earlier: r/k/v/g Int8 at
+    // T = 32 10.07 -> 9.74 us, Fk / Fr 10.70 -> 10.48, fp16 and T <= 16 unchanged or slower (profiles/r4_exp_gemm_ring_vs_shot.log).
+    {
+        bool all_quant = true;
+        for (auto &sp : ps) all_quant = all_quant && (sp.W->fmt != W_F16 || sp.W->rows <= 256);   // (the decay LoRA's 64 fp16 rows ride along)
+        if (NT == 2 && all_quant && !hilo) shot = false;
+    }
     Lh.single_shot = shot ? 1 : 0;
     Lh.tail = tail ? 1 : 0;
     return np;
