@@ -235,6 +235,9 @@ struct rwkv_engine {
     bool hilo = false;
     int quant_layers = 0, quant_type = 0;
     hipStream_t s_main = nullptr, s_soft = nullptr;
+    hipStream_t s_copy = nullptr;                              // rwkv_state_back_layer_async: pack + device-to-host copy beside the compute stream
+    hipEvent_t ev_copy_a = nullptr, ev_copy_b = nullptr;
+    float *emb_stage = nullptr;                                // [max_batch][64 * C]: one packed layer slice per slot
     std::vector<void *> allocs;
     std::map<std::string, DMat> mats;
     std::map<std::string, float *> vecs;
@@ -319,6 +322,7 @@ struct rwkv_engine {
         (void)hipSetDevice(device);
         if (s_main) (void)hipStreamSynchronize(s_main);
         if (s_soft) (void)hipStreamSynchronize(s_soft);
+        if (s_copy) (void)hipStreamSynchronize(s_copy);
         for (auto &g : graphs) if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
         for (auto &g : greedy_graphs) if (g.second) (void)hipGraphExecDestroy(g.second);
         for (auto ev : prof_ev) (void)hipEventDestroy(ev);
@@ -334,6 +338,10 @@ struct rwkv_engine {
         if (ev1) (void)hipEventDestroy(ev1);
         if (s_main) (void)hipStreamDestroy(s_main);
         if (s_soft) (void)hipStreamDestroy(s_soft);
+        if (s_copy) (void)hipStreamDestroy(s_copy);
+        if (ev_copy_a) (void)hipEventDestroy(ev_copy_a);
+        if (ev_copy_b) (void)hipEventDestroy(ev_copy_b);
+        if (emb_stage) (void)hipFree(emb_stage);
     }
 
     // ---- launch wrapper: optional per-family hipEvent timing on the compute stream.  Event pairs are recorded
@@ -1675,6 +1683,43 @@ rwkv_status rwkv_state_back_layer(rwkv_engine *e, int32_t slot, int32_t layer, f
         HIP_CHECK(hipMemcpyAsync(e->slab_host, e->slab_dev, n * 4, hipMemcpyDeviceToHost, e->s_main));
         HIP_CHECK(hipStreamSynchronize(e->s_main));
         std::memcpy(dst, e->slab_host, n * 4);
+    });
+}
+rwkv_status rwkv_state_back_layer_async(rwkv_engine *e, int32_t slot, int32_t layer, float *dst) {
+    return guard([&] {
+        check_slot(e, slot);
+        if (!dst || layer < 0 || layer >= e->info.num_layer) throw RwkvError(RWKV_ERR_INVALID, "bad layer/dst");
+        HIP_CHECK(hipSetDevice(e->device));
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, dst) != hipSuccess || at.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            throw RwkvError(RWKV_ERR_INVALID, "rwkv_state_back_layer_async: dst must be pinned host memory (rwkv_host_alloc)");
+        }
+        const size_t n = (size_t)64 * e->info.num_emb;
+        if (!e->s_copy) {
+            HIP_CHECK(hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&e->ev_copy_a, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&e->ev_copy_b, hipEventDisableTiming));
+            HIP_CHECK(hipMalloc((void **)&e->emb_stage, (size_t)e->max_batch * n * 4));
+        }
+        // the pack reads the slot as the compute stream left it ...
+        HIP_CHECK(hipEventRecord(e->ev_copy_a, e->s_main));
+        HIP_CHECK(hipStreamWaitEvent(e->s_copy, e->ev_copy_a, 0));
+        StatePackArgs a = pack_args(e, e->sxa + slot * e->sx_slot_stride, e->sxf + slot * e->sx_slot_stride,
+                                    e->wkv + slot * e->wkv_slot_stride, 1, layer);
+        a.slab = e->emb_stage + (size_t)slot * n;                // per-slot staging: the copy stream is in order, so a slot's staging
+        launch_state_pack(a, e->s_copy);                         // area is free again before its next pack runs
+        // ... and whatever the compute stream does to the slot next waits for the pack (microseconds), not for the PCIe copy
+        HIP_CHECK(hipEventRecord(e->ev_copy_b, e->s_copy));
+        HIP_CHECK(hipStreamWaitEvent(e->s_main, e->ev_copy_b, 0));
+        HIP_CHECK(hipMemcpyAsync(dst, a.slab, n * 4, hipMemcpyDeviceToHost, e->s_copy));
+    });
+}
+rwkv_status rwkv_state_sync(rwkv_engine *e) {
+    return guard([&] {
+        if (!e) throw RwkvError(RWKV_ERR_INVALID, "null engine");
+        HIP_CHECK(hipSetDevice(e->device));
+        if (e->s_copy) HIP_CHECK(hipStreamSynchronize(e->s_copy));
     });
 }
 rwkv_status rwkv_state_read(rwkv_engine *e, int32_t slot, rwkv_dstate **snap) {

@@ -164,6 +164,65 @@ class MirostatSampler:
         self.max_surprise = np.float32(min(np.float32(self.max_surprise - self.rate * err), np.float32(4.0) * self.target))
 
 
+class StateJob:
+    """`GenerateKind::State` requests as a batch job with SLOT TURNOVER — the documented `/embeddings` route (docs/doc-api/openai.md:
+    376-437; `GenerateKind::State` run.rs:980-989; `api/oai/state.rs:29-40`) fed a list of documents.  The scheduling is the reference's
+    (`queue` run.rs:488-626 -> `infer` steps run.rs:1121-1157 -> `finish`), the C++ form is `rwkv::Scheduler::queue / step / state`
+    (include/rwkv_scheduler.hpp): every idle slot takes the next waiting document (an `Empty` slot: nothing cached matches a fresh document, so
+    the state it starts from is the initial one, written from a device-resident snapshot like `state.write(backed.clone(), batch)`
+    run.rs:1104), all busy slots ride the same `infer` call (`RWKV_OPTION_NONE`: state-only, no head GEMM), and a slot whose document has
+    been consumed hands over its embedding — one layer's WKV rows, `rwkv_state_back_layer_async` into pinned memory on the engine's copy
+    stream — and is free for the next document at once: the read-back of a finished document overlaps the prefill of the following ones.
+
+    `run(docs)` returns (embeddings [n_docs, N, C] in pinned memory, number of infer calls)."""
+
+    def __init__(self, runtime, layer: int | None = None, arena=None):
+        from .runtime import PinnedArena
+        self.rt = runtime
+        self.layer = runtime.info.num_layer - 1 if layer is None else int(layer)
+        self._Arena = arena or PinnedArena           # `arena(shape)` -> object with `.array`, `.close()` (tests pass a numpy one)
+        # the initial state, device-resident (state.init() -> load -> read once; `backed.clone()` afterwards)
+        runtime.state.load(runtime.state.init(), 0)
+        self.zero = runtime.state.read(0)
+        self.out = None
+
+    def run(self, docs: list):
+        rt, B = self.rt, self.rt.max_batch
+        N, Cn = rt.info.head_size, rt.info.num_emb
+        if self.out is None or self.out.array.shape[0] < len(docs):
+            if self.out is not None:
+                self.out.close()
+            self.out = self._Arena((len(docs), N, Cn))
+        out = self.out.array
+        waiting = deque(range(len(docs)))
+        owner = [-1] * B                        # document id a slot works on
+        rest = [[] for _ in range(B)]           # its tokens not yet consumed
+        calls = 0
+        while waiting or any(o >= 0 for o in owner):
+            for b in range(B):                  # `queue`: the next document takes an idle slot
+                if owner[b] < 0 and waiting:
+                    d = waiting.popleft()
+                    rt.state.write(self.zero, b)
+                    owner[b], rest[b] = d, list(docs[d]) if len(docs[d]) else [0]          # empty prompt => [0] (run.rs:489-492)
+            inp = RnnInput([RnnInputBatch(rest[b] if owner[b] >= 0 else [], RnnOption.NoOutput) for b in range(B)])
+            inp, _ = rt.infer(inp)              # one step over <= token_chunk_size tokens of all busy slots
+            calls += 1
+            for b in range(B):
+                if owner[b] < 0:
+                    continue
+                rest[b] = inp.batches[b].tokens
+                if not len(rest[b]):            # `finish`: the embedding leaves on the copy stream, the slot is idle again
+                    rt.state.embed_async(self.layer, b, out[owner[b]])
+                    owner[b] = -1
+        rt.state.sync()
+        return out[:len(docs)], calls
+
+    def close(self):
+        if self.out is not None:
+            self.out.close()
+            self.out = None
+
+
 class ReplicaRouter:
     """Request-level sharding over independent engines (one per GPU): round-robin for batch jobs, least-busy for
     interactive requests.  No collective: each replica owns its weights, slots and stream.  (The full policy —

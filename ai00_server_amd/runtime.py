@@ -94,6 +94,8 @@ ABI_SYMBOLS = {
     "rwkv_state_write": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "rwkv_dstate_free": (None, [C.c_void_p]),
     "rwkv_state_back_layer": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "rwkv_state_back_layer_async": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "rwkv_state_sync": (C.c_int32, [C.c_void_p]),
     "rwkv_read_init_state": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rwkv_softmax": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t]),
     "rwkv_tokenizer_create": (C.c_int32, [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -278,6 +280,38 @@ class State:
         a = np.empty((r - 2, c), np.float32)
         _check(lib().rwkv_state_back_layer(self._rt._h, batch, layer, a.ctypes.data))
         return a
+
+    def embed_async(self, layer: int, batch: int, dst: np.ndarray):
+        """The same read-back, not waited for (rwkv_state_back_layer_async): `dst` is a [N, C] float32 view into pinned memory
+        (`PinnedArena`), valid after `sync()`.  The slot may be re-used at once."""
+        _check(lib().rwkv_state_back_layer_async(self._rt._h, batch, layer, dst.ctypes.data))
+
+    def sync(self):
+        _check(lib().rwkv_state_sync(self._rt._h))
+
+
+class PinnedArena:
+    """A float32 array in pinned host memory (rwkv_host_alloc): the destination of asynchronous read-backs (`State.embed_async`)
+    and of direct logits copies.  `close()` (or garbage collection) frees it; views must not outlive it."""
+
+    def __init__(self, shape):
+        self.shape = tuple(int(x) for x in shape)
+        n = int(np.prod(self.shape))
+        self._ptr = C.c_void_p()
+        _check(lib().rwkv_host_alloc(max(1, n) * 4, C.byref(self._ptr)))
+        self.array = np.ctypeslib.as_array(C.cast(self._ptr, C.POINTER(C.c_float)), shape=(max(1, n),))[:n].reshape(self.shape)
+
+    def close(self):
+        if self._ptr:
+            self.array = None
+            lib().rwkv_host_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class TensorGpu:

@@ -43,6 +43,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_PEAK = 2.5e15   # dense fp16 / bf16 MFMA peak
+EMBED_DOCS_PER_RANK = int(os.environ.get("BENCH_EMBED_DOCS", "512"))   # 4,096 documents over 8 replicas (test hook: fewer)
 QT = {"none": 0, "int8": 1, "nf4": 2}
 DTYPE = {"none": "f16", "int8": "u8->f16", "nf4": "nf4->f16"}
 
@@ -203,35 +204,54 @@ def decode_point(job, eng, first, steps, warmup):
     return dt_max, dt_all, dev_ms
 
 
-def embed_leg(rt, R, eng, info, B, doc_len=256):
-    """Second half of BASELINE's metric: documents prefilled state-only (RWKV_OPTION_NONE: no head GEMM, no logits) and read back
-    as one layer's WKV rows (rwkv_state_back_layer, docs/doc-api/openai.md:376-437) per second.  Refuses to report unless the
-    embeddings equal, bit for bit, those of the same documents prefilled with `Last` (the reference-shaped call)."""
-    V, layer = info.num_vocab, info.num_layer - 1
-    docs = [[t % V for t in R.synth_prompt(100 + b, doc_len)] for b in range(B)]
-    zero = eng.state.init()
+def timed_on_all_ranks(job, fn):
+    """`fn()` bracketed by barrier + synchronize on both sides on every rank; returns (MAX over ranks, every rank's time, fn's result)."""
+    job.barrier()
+    t = time.perf_counter()
+    res = fn()
+    job.sync()
+    dt = time.perf_counter() - t
+    job.barrier()
+    dt_max, dt_all = job.max_and_all(dt)
+    return dt_max, dt_all, res
 
-    def run(option):
-        for b in range(B):
-            eng.state.load(zero, b)
-        t = time.perf_counter()
-        inp = rt.RnnInput([rt.RnnInputBatch(list(docs[b]) if b < B else [], option) for b in range(eng.max_batch)])
-        while inp.num_token() > 0:
-            inp, _ = eng.infer(inp)
-        vecs = [eng.state.embed(layer, b) for b in range(B)]
-        return time.perf_counter() - t, vecs
 
-    best, vecs = None, None
-    for _ in range(3):
-        dt, vecs = run(rt.RnnOption.NoOutput)
-        best = dt if best is None else min(best, dt)
-    _, ref = run(rt.RnnOption.Last)
-    ok = all(np.array_equal(a, b) for a, b in zip(vecs, ref)) and all(np.isfinite(a).all() and np.abs(a).max() > 0 for a in vecs)
-    assert ok, "state-only (RWKV_OPTION_NONE) embeddings differ from a `Last` prefill of the same documents"
-    return {"value": B / best, "unit": "embeddings/s", "doc_tokens": doc_len, "docs": B, "prefill_tokens_per_s": B * doc_len / best,
-            "token_chunk_size": eng.token_chunk_size, "embeddings_verified": ok,
-            "checksum": float(np.sum([np.abs(a).astype(np.float64).sum() for a in vecs])),
-            "embedding": f"layer {layer} WKV rows [64 x {info.num_emb}] via rwkv_state_back_layer"}
+def embed_job_leg(job, rt, R, eng, info, n_docs, doc_len=256, verify=True):
+    """Second half of BASELINE's metric, as SURVEY 8(d) config #4 specifies it: a batch of `doc_len`-token documents — 4,096 over 8
+    replicas, i.e. `n_docs` = 512 per rank, sharded round-robin (document d belongs to rank d mod world) — prefilled state-only
+    (RWKV_OPTION_NONE: no head GEMM, no logits) through `harness.StateJob`: GenerateKind::State requests with slot turnover, the layer
+    slice of a finished document (docs/doc-api/openai.md:376-437) leaving on the engine's copy stream into pinned memory while the
+    following documents prefill.  Every rank runs its shard inside one barrier-bracketed region; the rate is all documents over the
+    slowest rank's time.  Verified on every rank: the first and the last `max_batch` documents of the shard equal, bit for bit, the
+    same documents prefilled with `Last` (the reference-shaped call) in the same slots."""
+    from ai00_server_amd.harness import StateJob, ReplicaRouter
+    V, layer, B = info.num_vocab, info.num_layer - 1, eng.max_batch
+    mine = list(ReplicaRouter.shard(n_docs * job.world, job.rank, job.world))           # global document ids of this rank
+    docs = [[t % V for t in R.synth_prompt(100 + d, doc_len)] for d in mine]
+    sj = StateJob(eng, layer)
+    sj.run(docs[:B])                                                                    # warm: graphs of the step shapes, the arena
+    dt_max, dt_all, (emb, calls) = timed_on_all_ranks(job, lambda: sj.run(docs))
+    ok = bool(np.isfinite(emb).all() and np.abs(emb).max() > 0)
+    if verify:
+        zero = eng.state.init()
+        for lo in sorted({0, max(0, len(docs) - B)}):
+            group = docs[lo:lo + B]
+            for b in range(len(group)):
+                eng.state.load(zero, b)
+            inp = rt.RnnInput([rt.RnnInputBatch(list(group[b]) if b < len(group) else [], rt.RnnOption.Last) for b in range(B)])
+            while inp.num_token() > 0:
+                inp, _ = eng.infer(inp)
+            ok = ok and all(np.array_equal(eng.state.embed(layer, b), emb[lo + b]) for b in range(len(group)))
+        assert ok, "state-only (RWKV_OPTION_NONE) embeddings of the job differ from a `Last` prefill of the same documents"
+    total = len(docs) * job.world
+    res = {"value": total / dt_max, "unit": "embeddings/s", "doc_tokens": doc_len, "docs": total, "docs_per_rank": len(docs),
+           "prefill_tokens_per_s": total * doc_len / dt_max, "per_rank_embeddings_per_s": [len(docs) / d for d in dt_all],
+           "infer_calls_per_rank": calls, "token_chunk_size": eng.token_chunk_size, "slots": B, "embeddings_verified": ok if verify else None,
+           "checksum": float(np.abs(emb[:B]).astype(np.float64).sum()),
+           "job": "harness.StateJob: slot turnover, rwkv_state_back_layer_async into pinned memory (read-back overlaps the next documents' prefill)",
+           "embedding": f"layer {layer} WKV rows [64 x {info.num_emb}]"}
+    sj.close()
+    return res
 
 
 def roofline_leg(rt, R, eng, info, shapes, first, ms_per_step, workload, quant, step_frac, ab):
@@ -339,7 +359,7 @@ def config_leg(job, rt, R, name, quant, batches, steps, verify_steps, embed_chun
     eng.close()
     if embed_chunk is not None:
         e = build_engine(rt, st, job.local_rank, ql, qt, B, embed_chunk)
-        out["embeddings"] = embed_leg(rt, R, e, info, B)
+        out["embeddings"] = embed_job_leg(job, rt, R, e, info, EMBED_DOCS_PER_RANK)
         e.close()
     return out
 
@@ -433,7 +453,14 @@ def selftest_dist(job, args):
                           "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max * 1e3 / args.steps,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "selftest", "data": "none",
                           "config": {"workload": "launcher self-test (sleep)"},
-                          "per_rank_tokens_per_s": [B * args.steps / d for d in dt_all], "selftest": True}), flush=True)
+                          "per_rank_tokens_per_s": [B * args.steps / d for d in dt_all], "selftest": True,
+                          # the legs every rank of a real N > 1 run adds (same aggregation: all units over the slowest rank's time)
+                          "pcie_inclusive_tokens_per_s": B * job.world * args.steps / dt_max,
+                          "pcie_inclusive": {"value": B * job.world * args.steps / dt_max, "per_rank": [B * args.steps / d for d in dt_all]},
+                          "on_device_sampling_tokens_per_s": B * job.world * args.steps / dt_max,
+                          "on_device_sampling": {"value": B * job.world * args.steps / dt_max, "per_rank": [B * args.steps / d for d in dt_all]},
+                          "embeddings": {"value": 8 * job.world / dt_max, "unit": "embeddings/s", "docs": 8 * job.world, "docs_per_rank": 8,
+                                         "per_rank_embeddings_per_s": [8 / d for d in dt_all]}}), flush=True)
 
 
 def main(argv=None):
@@ -487,24 +514,31 @@ def main(argv=None):
             sweep[str(nb)] = {"tokens_per_s": nb * args.steps / d2, "ms_per_step": d2 * 1e3 / args.steps,
                               "frac_of_peak": abn["per_step"] * (args.steps / d2) / HBM_PEAK}
 
-    # PCIe-inclusive rate through rwkv_infer (logits of every slot D2H every token, as run.rs:809-832 receives them) — never
-    # `value`; and the serving path with the on-device sampling front-end (rwkv_infer_sample: 8 bytes per slot over PCIe)
+    # On EVERY rank (the N > 1 line carries the whole metric, not only the device-resident loop — the host side is where replica
+    # scaling can break): the PCIe-inclusive rate through rwkv_infer (logits of every slot D2H every token, as
+    # run.rs:809-832 receives them) — never `value`; the serving path with the on-device sampling front-end (rwkv_infer_sample: 8 bytes
+    # per slot over PCIe); and the embeddings job.  Each is bracketed by barrier + synchronize like `value`, aggregated over the
+    # slowest rank, with every rank's own rate beside it.
     pcie = sampled = emb = None
-    if single and not args.decode_only:
+    if not args.decode_only:
         nst = max(5, min(40, args.steps))
-        pcie = B * nst / eng.serve_loop_logits(first, nst)
+        d_max, d_all, _ = timed_on_all_ranks(job, lambda: eng.serve_loop_logits(first, nst))
+        pcie = {"value": B * nst * world / d_max, "unit": "tokens/s", "per_rank": [B * nst / d for d in d_all], "steps": nst}
         if V <= 65536:
-            sampled = B * nst / eng.serve_loop_sample(first, nst)
-        emb = embed_leg(rt, R, eng, info, B)
-        # the same job at SURVEY config #4's token_chunk_size (256 tokens per rwkv_infer call): a second engine over the same
+            d_max, d_all, _ = timed_on_all_ranks(job, lambda: eng.serve_loop_sample(first, nst))
+            sampled = {"value": B * nst * world / d_max, "unit": "tokens/s", "per_rank": [B * nst / d for d in d_all], "steps": nst}
+        # the embeddings job at SURVEY config #4's token_chunk_size (256 tokens per rwkv_infer call): a second engine over the same
         # checkpoint, since the chunk is a load-time parameter (ReloadRequest::token_chunk_size, lib.rs:221-223)
         e256 = build_engine(rt, st, job.local_rank, ql, qt, B, 256, args.precision)
-        e = embed_leg(rt, R, e256, info, B)
+        emb = embed_job_leg(job, rt, R, e256, info, EMBED_DOCS_PER_RANK)
         e256.close()
-        # chunking is exact for an RNN up to the summation order of the GEMM that a chunk size selects
-        assert abs(e["checksum"] - emb["checksum"]) <= 2e-3 * abs(emb["checksum"]), "embeddings depend on token_chunk_size"
-        emb["at_token_chunk_size_256"] = {"value": e["value"], "prefill_tokens_per_s": e["prefill_tokens_per_s"],
-                                          "embeddings_verified": e["embeddings_verified"]}
+        if single:
+            # the same job on the 2048-row engine of the decode legs (what a deployment that sets a large chunk gets)
+            e = embed_job_leg(job, rt, R, eng, info, EMBED_DOCS_PER_RANK)
+            # chunking is exact for an RNN up to the summation order of the GEMM that a chunk size selects
+            assert abs(e["checksum"] - emb["checksum"]) <= 2e-3 * abs(emb["checksum"]), "embeddings depend on token_chunk_size"
+            emb["at_token_chunk_size_2048"] = {"value": e["value"], "prefill_tokens_per_s": e["prefill_tokens_per_s"],
+                                               "embeddings_verified": e["embeddings_verified"]}
     eng.close()
     del st
 
@@ -532,8 +566,10 @@ def main(argv=None):
                            "parallelism": f"replicas x{world} (no collective)"},
                 "tokens_per_s_per_gpu": value / world, "per_rank_tokens_per_s": [B * args.steps / d for d in dt_all],
                 "device_ms_per_step": dev_ms / args.steps,
-                "roofline": roof, "cpu_baseline": cpu, "embeddings": emb, "pcie_inclusive_tokens_per_s": pcie,
-                "on_device_sampling_tokens_per_s": sampled, "sweep": sweep or None, "tokens_verified": tokens_verified,
+                "roofline": roof, "cpu_baseline": cpu, "embeddings": emb,
+                "pcie_inclusive_tokens_per_s": pcie["value"] if pcie else None, "pcie_inclusive": pcie,
+                "on_device_sampling_tokens_per_s": sampled["value"] if sampled else None, "on_device_sampling": sampled,
+                "sweep": sweep or None, "tokens_verified": tokens_verified,
                 "configs": configs, "load_s": t_load, "synth_s": t_synth}
         print(json.dumps(line), flush=True)
     job.close()

@@ -24,9 +24,10 @@
 extern "C" {
 #endif
 
-#define RWKV_ABI_VERSION 4   /* 2: rwkv_sample_params gained kind/tau; rwkv_engine_save_prefab
+#define RWKV_ABI_VERSION 5   /* 2: rwkv_sample_params gained kind/tau; rwkv_engine_save_prefab
                               * 3: rwkv_sample_params gained allow (formatter mask); rwkv_host_alloc/free; RWKV_OPTION_NONE
-                              * 4: rwkv_engine_token_chunk_size */
+                              * 4: rwkv_engine_token_chunk_size
+                              * 5: rwkv_state_back_layer_async / rwkv_state_sync */
 
 typedef int32_t rwkv_status;
 enum {
@@ -153,6 +154,13 @@ rwkv_status rwkv_state_write(rwkv_engine *e, int32_t slot, const rwkv_dstate *sn
 void rwkv_dstate_free(rwkv_dstate *snap);
 /* f-2 (docs/doc-api/openai.md:376-437): one layer's WKV rows [N][C] of a slot, D2H */
 rwkv_status rwkv_state_back_layer(rwkv_engine *e, int32_t slot, int32_t layer, float *dst);
+/* The same read-back, NOT waited for: the layer's rows are packed on a second stream (ordered behind everything issued so far; later
+ * work on the slot — rwkv_infer, rwkv_state_load / _write — is ordered behind the pack, a few microseconds) and copied to `dst`, which
+ * must be pinned host memory (rwkv_host_alloc), while the engine goes on with the next rwkv_infer.  An embedding job (`/embeddings`,
+ * docs/doc-api/openai.md:376-437; the reference's `state.back(batch).await` yields to the other tasks the same way, run.rs:1101) hands a
+ * finished document's slot to the next document without waiting for PCIe.  `dst` is valid after rwkv_state_sync. */
+rwkv_status rwkv_state_back_layer_async(rwkv_engine *e, int32_t slot, int32_t layer, float *dst);
+rwkv_status rwkv_state_sync(rwkv_engine *e);                       /* wait for every pending rwkv_state_back_layer_async */
 
 /* ---- `vN::read_state(context, info, model)` lib.rs:378-389 --------------------------------- */
 rwkv_status rwkv_read_init_state(const rwkv_engine *e, const uint8_t *st_bytes, size_t st_len, float *dst);

@@ -1,9 +1,9 @@
-//! Raw bindings of `include/rwkv_abi.h` (ABI version 4), one `pub fn` per export, in the header's order.
+//! Raw bindings of `include/rwkv_abi.h` (ABI version 5), one `pub fn` per export, in the header's order.
 //! tests/test_abi_cpu.py diffs this file against the header (names and argument counts) and against the built library.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_float, c_void};
 
-pub const RWKV_ABI_VERSION: i32 = 4;
+pub const RWKV_ABI_VERSION: i32 = 5;
 
 pub type rwkv_status = i32;
 pub const RWKV_OK: rwkv_status = 0;
@@ -83,6 +83,8 @@ extern "C" {
     pub fn rwkv_state_write(e: *mut rwkv_engine, slot: i32, snap: *const rwkv_dstate) -> rwkv_status;
     pub fn rwkv_dstate_free(snap: *mut rwkv_dstate);
     pub fn rwkv_state_back_layer(e: *mut rwkv_engine, slot: i32, layer: i32, dst: *mut f32) -> rwkv_status;
+    pub fn rwkv_state_back_layer_async(e: *mut rwkv_engine, slot: i32, layer: i32, dst: *mut f32) -> rwkv_status;
+    pub fn rwkv_state_sync(e: *mut rwkv_engine) -> rwkv_status;
     pub fn rwkv_read_init_state(e: *const rwkv_engine, st_bytes: *const u8, st_len: usize, dst: *mut f32) -> rwkv_status;
     // softmax task  (run.rs:1178-1183)
     pub fn rwkv_softmax(e: *mut rwkv_engine, inp: *const *const f32, out: *const *mut f32, n_rows: usize) -> rwkv_status;

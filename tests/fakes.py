@@ -8,6 +8,7 @@ from ai00_server_amd.runtime import RnnInput, RnnOption
 class _State:
     def __init__(self, rt):
         self.rt = rt
+        self.pending = []
 
     @property
     def shape(self):
@@ -31,6 +32,17 @@ class _State:
     def embed(self, layer, batch):
         n = self.rt.ref.info.head_size
         return self.rt.states[batch][layer, 1:1 + n].copy()
+
+    def embed_async(self, layer, batch, dst):
+        """The real one returns at once and fills `dst` on the copy stream; here the copy is deferred to `sync()` so that a driver
+        which re-used the slot too early (before the engine ordered the pack) or read `dst` before `sync()` is caught."""
+        self.pending.append((dst, self.embed(layer, batch)))
+        dst[...] = np.nan
+
+    def sync(self):
+        for dst, val in self.pending:
+            dst[...] = val
+        self.pending = []
 
 
 class OracleRuntime:

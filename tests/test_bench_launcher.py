@@ -33,6 +33,14 @@ def test_gpus_2_without_a_launcher_spawns_two_ranks():
     assert d["per_rank_tokens_per_s"][1] < d["per_rank_tokens_per_s"][0]
     assert abs(d["value"] - 2 * min(d["per_rank_tokens_per_s"])) <= 1e-6 * d["value"]
     assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1          # ONE line, from rank 0
+    # the N > 1 line carries the WHOLE metric (BASELINE: decode tokens/s + embeddings/s), each leg per rank and aggregated over the
+    # slowest rank like `value`
+    for key in ("pcie_inclusive", "on_device_sampling"):
+        assert len(d[key]["per_rank"]) == 2 and abs(d[key]["value"] - 2 * min(d[key]["per_rank"])) <= 1e-6 * d[key]["value"]
+        assert d[key + "_tokens_per_s"] == d[key]["value"]
+    e = d["embeddings"]
+    assert e["unit"] == "embeddings/s" and len(e["per_rank_embeddings_per_s"]) == 2 and e["docs"] == 2 * e["docs_per_rank"]
+    assert abs(e["value"] - 2 * min(e["per_rank_embeddings_per_s"])) <= 1e-6 * e["value"]
 
 
 def test_under_torch_distributed_run_as_the_driver_launches_it():
@@ -61,12 +69,19 @@ def test_world_size_and_gpus_flag_must_agree():
 
 @pytest.mark.gpu
 def test_real_bench_as_two_ranks_on_one_device():
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "10", "--warmup", "3", "--decode-only", "--sweep", "", "--verify-steps", "4"],
-                       env=clean_env(BENCH_SHARE_GPU="1"), capture_output=True, text=True, timeout=900)
+    """Two ranks sharing the test box's one device: decode, the serving loops (logits over PCIe; on-device sampling) and the embeddings
+    job (64 documents per rank here instead of 512) on BOTH ranks, each leg aggregated over the slower rank."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "10", "--warmup", "3", "--no-configs", "--no-cpu-baseline", "--sweep", "",
+                        "--verify-steps", "4"], env=clean_env(BENCH_SHARE_GPU="1", BENCH_EMBED_DOCS="64"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = last_json(r.stdout)
     assert d["n_gpus"] == 2 and len(d["per_rank_tokens_per_s"]) == 2 and d["tokens_verified"] is True
     assert d["value"] > 0 and d["config"]["parallelism"].startswith("replicas x2")
+    for key in ("pcie_inclusive", "on_device_sampling"):
+        assert len(d[key]["per_rank"]) == 2 and 0 < d[key]["value"] <= 2 * min(d[key]["per_rank"]) * (1 + 1e-6)
+    e = d["embeddings"]
+    assert e["docs"] == 128 and e["docs_per_rank"] == 64 and len(e["per_rank_embeddings_per_s"]) == 2 and e["embeddings_verified"] is True
+    assert e["token_chunk_size"] == 256 and 0 < e["value"] <= 2 * min(e["per_rank_embeddings_per_s"]) * (1 + 1e-6)
 
 
 def test_committed_bench_line_keeps_the_contract():

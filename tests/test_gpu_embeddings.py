@@ -167,3 +167,42 @@ def test_one_step_mixes_none_last_and_full_slots(ver, quant):
     for b in range(nb):
         np.testing.assert_array_equal(eng.state.back(b), silent[b])
     eng.close()
+
+
+@pytest.mark.parametrize("ver,quant", [(6, 1), (7, 2)])
+def test_state_job_with_slot_turnover_and_async_read_back(ver, quant):
+    """harness.StateJob — what bench.py's embeddings leg times: more documents than slots, RAGGED lengths (a slot that finishes takes
+    the next document while the others are mid-flight), embeddings leaving through rwkv_state_back_layer_async into pinned memory while
+    the next step runs.  Every embedding against the oracle's state of that document prefilled alone; the asynchronous read-back
+    against the blocking one on a slot that is then overwritten."""
+    from ai00_server_amd.harness import StateJob
+    C, F, V = 2560, (8960 if ver == 6 else 10240), 2048
+    tens = R.synth_checkpoint(ver, 2, C, F, V, seed=61 + ver)
+    ref = R.RwkvRef(tens, 2, quant)
+    nb = 4
+    eng = rt.ModelBuilder(R.st_serialize(tens)).quant(2, rt.Quant(quant)).build(max_batch=nb, token_chunk_size=64, precision=rt.Precision.Fp16)
+    lens = [40, 7, 33, 1, 64, 12, 0, 25, 3, 50, 18]
+    docs = [[t % V for t in R.synth_prompt(1500 + i, n)] for i, n in enumerate(lens)]
+    layer = 1
+    job = StateJob(eng, layer)
+    emb, calls = job.run(docs)
+    assert emb.shape == (len(docs), 64, C)
+    for i, d in enumerate(docs):
+        s = ref.init_state()
+        ref.forward(d if len(d) else [0], s)
+        want = s[layer, 1:65]
+        assert np.abs(emb[i] - want).max() <= tol(want), f"document {i} ({lens[i]} tokens)"
+    # asynchronous == blocking, and the slot may be overwritten as soon as the call returns
+    feed(eng, [docs[4]], [rt.RnnOption.NoOutput])
+    sync_copy = eng.state.embed(layer, 0)
+    arena = rt.PinnedArena((64, C))
+    eng.state.embed_async(layer, 0, arena.array)
+    eng.state.load(eng.state.init(), 0)                                    # ordered behind the pack by the engine
+    feed(eng, [docs[9]], [rt.RnnOption.NoOutput])
+    eng.state.sync()
+    np.testing.assert_array_equal(arena.array, sync_copy)
+    with pytest.raises(rt.RwkvError):                                      # pageable memory is refused, not silently staged
+        eng.state.embed_async(layer, 0, np.empty((64, C), np.float32))
+    arena.close()
+    job.close()
+    eng.close()

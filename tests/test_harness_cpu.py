@@ -140,3 +140,38 @@ def test_router_places_interactive_requests_on_the_least_busy_replica():
         want, _ = ref.greedy(p, 5)
         assert g == want[:len(g)] and (len(g) == 5 or want[len(g)] == 0)
     assert router.busy == [0, 0, 0]
+
+
+class _NumpyArena:                                            # stand-in for runtime.PinnedArena on a machine without a GPU
+    def __init__(self, shape):
+        self.array = np.zeros(shape, np.float32)
+
+    def close(self):
+        self.array = None
+
+
+@pytest.mark.parametrize("name", ["v6-tiny", "v7-tiny"])
+def test_state_job_slot_turnover_equals_one_document_at_a_time(name):
+    """harness.StateJob (the `/embeddings` batch job: GenerateKind::State requests with slot turnover, run.rs:980-989) over more
+    documents than slots and RAGGED lengths: a slot that finishes takes the next document while the others are mid-flight, every
+    embedding equals the document prefilled alone from the initial state, and nothing is read before `sync()`."""
+    from ai00_server_amd.harness import StateJob
+    ref = _ref(name)
+    rt_ = OracleRuntime(ref, max_batch=3, token_chunk_size=8)
+    lens = [5, 17, 1, 9, 0, 12, 3, 8, 20, 2, 6]
+    docs = [_prompt(ref, 40 + i, n) for i, n in enumerate(lens)]
+    layer = ref.info.num_layer - 1
+    job = StateJob(rt_, layer, arena=_NumpyArena)
+    emb, calls = job.run(docs)
+    assert emb.shape == (len(docs), ref.info.head_size, ref.info.num_emb) and np.isfinite(emb).all()
+    for i, d in enumerate(docs):
+        s = ref.init_state()
+        ref.forward(d if len(d) else [0], s)                      # empty prompt => [0] (run.rs:489-492)
+        np.testing.assert_array_equal(emb[i], s[layer, 1:1 + ref.info.head_size], err_msg=f"document {i}")
+    # turnover really happened: 11 documents through 3 slots in fewer calls than running them in waves of 3 to completion
+    waves = sum(-(-max(max(1, n) for n in lens[i:i + 3]) // (8 // min(3, len(lens[i:i + 3])))) for i in range(0, len(lens), 3))
+    assert calls < waves + 4
+    # a second job on the same object starts from clean slots again
+    emb2, _ = job.run(docs[:4])
+    np.testing.assert_array_equal(emb2, emb[:4])
+    job.close()
