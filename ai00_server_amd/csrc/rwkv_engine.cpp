@@ -959,13 +959,27 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
             const long rounds = (t3 + 511) / 512;
             if (ok3 && fill_min > 0 && t3 >= kn.tile3_min_tiles && t3 * 100 >= fill_min * rounds * 512) shape = GEMM_TILE3;
         }
-        if (f_shape >= 0 && f_shape < GEMM_TILE_SHAPES && (f_shape != GEMM_TILE3 || ok3)) shape = f_shape;
+        // The pipelined kernel on 128 x 64 tiles (shape 11, round 4) for the NON-linear launches of steps the 128-token tile cannot fill:
+        // at 256 rows a 10304-row launch is 160 tiles of 128 x 128 (fewer than CUs) but 324 of 128 x 64, each prefetching four stages
+        // ahead where the 64 x 64 shapes prefetch one chunk: r/k/v/g/decay 49.7 -> 40.8 us, Fk / Fr 45.7 -> 40.0 (Int8, 256 rows).
+        // Measured by row count and weight format (profiles/r4_exp_tile3_128x64.log; V6-3B Int8 / fp16, V7-2.9B NF4, V6-7B fp16):
+        //   quantised: 256 rows +6.5 % / +4.6 % (NF4), 512 rows -5 % / -3 %, 1024 rows +4.7 % / +4 %;  fp16: 256 rows -7.5 % (3 B) / +1.7 % (7 B),
+        //   512 rows +1.6 % / +5.9 %, 1024 rows +4.4 % / +3.1 %;  2048 rows: the 128 x 128 tile wins everywhere.
+        // The linear launches (Wo, Fv) stay on K copies of 64 x 64 tiles (22 us at 256 rows against 30).  RWKV_TILE3_64=0 turns the rule off.
+        {
+            const bool linear_launch = ps.size() == 1 && ps[0].partial;
+            bool big_f16 = false;
+            for (auto &sp : ps) big_f16 = big_f16 || (sp.W->fmt == W_F16 && sp.W->rows > 256);
+            const bool in_range = big_f16 ? (T > 320 && T <= 1280) : (T <= 320 || (T > 768 && T <= 1280));
+            if (ok3 && kn.tile3_64 && !linear_launch && in_range) shape = GEMM_TILE3_64;
+        }
+        if (f_shape >= 0 && f_shape < GEMM_TILE_SHAPES && ((f_shape != GEMM_TILE3 && f_shape != GEMM_TILE3_64) || ok3)) shape = f_shape;
         // K split of a linear launch on the pipelined kernel (Wo, Fv: one `partial` problem whose output the next row kernel sums
         // anyway): a grid of fewer than 512 tiles costs a whole round of the kernel, so the tiles are replicated over `ksb` K ranges
         // until the rounds are full — 3 x 320 tiles (V6-3B at 2048 rows) fill 94 % of two rounds a third as long (tg3_body).
         int ksplit = 1;
         if (ok3 && kn.tile_ksplit && ps.size() == 1 && ps[0].partial && ps[0].post != POST_MIX && ps[0].act == ACT_NONE && !ps[0].bias &&
-            !ps[0].oh.hi && (f_shape < 0 || f_shape == GEMM_TILE3) && kn.tile3_fill > 0) {
+            !ps[0].oh.hi && (f_shape < 0 || f_shape == GEMM_TILE3 || f_shape == GEMM_TILE3_64) && kn.tile3_fill > 0) {
             const long t3 = gemm_tile_blocks(GEMM_TILE3, ps[0].W->rows, T);
             const int G = ps[0].W->K / 128;
             double best = shape == GEMM_TILE3 ? (double)t3 / (((t3 + 511) / 512) * 512) : 0.0;
@@ -977,7 +991,12 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
                     if (fill > best + 0.10 && fill >= 0.80) { best = fill; ksplit = b; }
                 }
             }
-            if (ksplit > 1) shape = GEMM_TILE3;
+            if (shape == GEMM_TILE3_64) {
+                // copies over K until the launch has about one block per CU, a copy keeping >= 768 k
+                const long t11 = gemm_tile_blocks(GEMM_TILE3_64, ps[0].W->rows, T);
+                ksplit = 1;
+                for (int b = 2; b <= 4 && ps[0].W->K / b >= 768 && t11 * (b - 1) < 224; ++b) ksplit = b;
+            } else if (ksplit > 1) shape = GEMM_TILE3;
             else if (shape != GEMM_TILE3) {
                 // the 64x64 shapes on a step of a few hundred rows: Wo / Fv have fewer tiles than the chip has CUs (160 at 256 rows of
                 // the 3 B model); copies over K fill it
@@ -1921,10 +1940,10 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
                 if (T >= GEMM_TILE_MIN_T) {                      // prefill path; `spb` selects the tile shape (0..3), -1 = auto
                     int shape = spb;
                     if (shape < 0 || shape >= GEMM_TILE_SHAPES) {
-                        shape = GEMM_TILE_SHAPES - 1;
+                        shape = GEMM_TILE3;
                         for (int sh = 0; sh < GEMM_TILE_SHAPES; ++sh) if (gemm_tile_blocks(sh, rows, T) >= 1024) { shape = sh; break; }
                     }
-                    if (shape == GEMM_TILE3 && !gemm_tile3_supported(hilo != 0, K)) throw RwkvError(RWKV_ERR_INVALID, "bench_gemm: shape 10 needs K % 128 == 0 and no hi/lo operand");
+                    if ((shape == GEMM_TILE3 || shape == GEMM_TILE3_64) && !gemm_tile3_supported(hilo != 0, K)) throw RwkvError(RWKV_ERR_INVALID, "bench_gemm: shapes 10 / 11 need K % 128 == 0 and no hi/lo operand");
                     Lh = GemmLaunch{};
                     Lh.nprob = 1; Lh.T = T;
                     GemmProb &g = Lh.p[0];

@@ -22,6 +22,7 @@ struct Knobs {
     int tile_ksplit = 1;             // RWKV_TILE_KSPLIT: K split of linear launches on the pipelined prefill kernel (0 = off)
     int no_dense = 0;                // RWKV_NO_DENSE: general row metadata on dense decode steps
     int ln_256 = 0;                  // RWKV_LN_256: 256-thread ln_shift everywhere
+    int tile3_64 = 1;                // RWKV_TILE3_64: the pipelined kernel on 128 x 64 tiles for non-linear launches of 256- / 1024-row steps (0 = never)
     int tile3_min_tiles = 300;       // RWKV_TILE3_MIN_TILES: fewest tiles for which the pipelined prefill kernel is considered
     int nf4_kc128_min = 512;         // RWKV_NF4_KC128_MIN: 64x64 tiles of an all-NF4 launch walk K in 128-k chunks from this many tiles
     int v6_split_min_t = 512;        // RWKV_V6_SPLIT_MIN_T: rows from which the wide V6 mix runs as two launches (v6_mix_apply_kernel)
@@ -137,9 +138,10 @@ void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s);
 int gemm_max_rounds(int fmt, int NT, bool hilo);
 // prefill path (T >= GEMM_TILE_MIN_T): LDS-tiled MFMA GEMM, no K split; uses p[].block_begin and total_blocks only
 constexpr int GEMM_TILE_MIN_T = 193;                     // measured crossover (V6-3B Int8): up to 192 rows the decode kernel's 64-row passes win or tie
-constexpr int GEMM_TILE_SHAPES = 11;                      // 256x128, 128x128, 64x128, 64x64 (rows x tokens, 128-k chunks); 64x64 and 128x128 with 256-k chunks
+constexpr int GEMM_TILE_SHAPES = 12;                      // 256x128, 128x128, 64x128, 64x64 (rows x tokens, 128-k chunks); 64x64 and 128x128 with 256-k chunks
 int gemm_tile_blocks(int shape, int rows, int T);
 constexpr int GEMM_TILE3 = 10;                            // the pipelined 128x128 kernel (non-hi/lo operands, K % 128 == 0)
+constexpr int GEMM_TILE3_64 = 11;                         // the same pipeline on 128 rows x 64 tokens (steps of a few hundred rows)
 bool gemm_tile3_supported(bool hilo, int K);
 void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s);                             // rounds of 256 k a wave can hold at once (single-shot)
 

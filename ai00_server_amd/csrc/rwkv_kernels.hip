@@ -485,6 +485,7 @@ Knobs Knobs::from_env() {
     k.v6_split_min_t = knob_env("RWKV_V6_SPLIT_MIN_T", 512);
     k.tile3_min_tiles = knob_env("RWKV_TILE3_MIN_TILES", 300);
     k.nf4_kc128_min = knob_env("RWKV_NF4_KC128_MIN", 512);
+    k.tile3_64 = knob_env("RWKV_TILE3_64", 1);
     return k;
 }
 static thread_local Knobs t_knobs;
@@ -1557,7 +1558,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tile_kernel(const GemmLaunch 
 // Host guarantees K % 128 == 0 and a non-hi/lo operand.  vmcnt is in-order, so a count that is too SMALL only waits longer; the
 // weight-group constant below is therefore the number of 16-byte tile loads (scale loads not counted).
 // =====================================================================================
-constexpr int T3_NB = 4, T3_STAGE_HALFS = 16 * 512;
+constexpr int T3_NB = 4;
 // Every VMEM instruction of the K loop is inline asm: hipcc then keeps no vmcnt bookkeeping for the loop (its own bookkeeping
 // degrades to vmcnt(0) as soon as a load sits behind a branch or an LDS-DMA is pending), and the counted waits below are exact.
 // A register written by such a load is used only after (1) a counted wait that retires the load and (2) t3_arrived(), an empty
@@ -1610,9 +1611,13 @@ __device__ __forceinline__ f16x8 t3_frag(const T3Set<FMT> &w, int h, int ks, int
     return tg_frag<FMT, 1, 128>(r, 0, ks, k0, lut);
 }
 
-template <int FMT>
+// NTL = token tiles per block: 8 = the 128 x 128 tile; 4 = 128 rows x 64 tokens for steps of a few hundred rows (round 4: at 256 rows
+// the 128-token tile leaves 160 blocks for a 10304-row launch; this one 324, each moving half the operand)
+template <int FMT, int NTL>
 __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
-    constexpr int SPW = 2, NTL = 8, BT = 128, STRIPS = 8, NA = T3Set<FMT>::NLOAD;
+    constexpr int SPW = 2, BT = NTL * 16, STRIPS = 8, NA = T3Set<FMT>::NLOAD;
+    constexpr int DPW = NTL / 2;                                  // X tiles (DMAs) per wave per stage: 2 NTL tiles over 4 waves
+    constexpr int STAGE_HALFS = NTL * 2 * 512;                    // [token tile][k-step][lane][8]
     using Set = T3Set<FMT>;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1650,23 +1655,23 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) acc[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // the four X tiles of a stage this wave fetches: i = m*4 + wave -> (token tile i >> 1, k-step i & 1); tiles past the step
+    // the DPW X tiles of a stage this wave fetches: i = m*4 + wave -> (token tile i >> 1, k-step i & 1); tiles past the step
     // are clamped to its last tile (their columns are never stored)
-    const _Float16 *xsrc[4];
+    const _Float16 *xsrc[DPW];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < DPW; ++m) {
         const int i = m * 4 + wave;
         const int ttile = min((t0 >> 4) + (i >> 1), last_tile);
         xsrc[m] = P.xhi + ((long)ttile * (P.ldx >> 5) + (kofs >> 5) + (i & 1)) * 512 + lane * 8;
     }
     auto dma = [&](int s) {
-        const unsigned dst = xs_byte + (unsigned)(((s & (T3_NB - 1)) * T3_STAGE_HALFS + wave * 512) * 2);
+        const unsigned dst = xs_byte + (unsigned)(((s & (T3_NB - 1)) * STAGE_HALFS + wave * 512) * 2);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) t3_dma16(xsrc[m] + (long)s * 1024, dst + m * 4 * 1024);
+        for (int m = 0; m < DPW; ++m) t3_dma16(xsrc[m] + (long)s * 1024, dst + m * 4 * 1024);
     };
     auto stage = [&](const Set &w, int s, auto half) {
         constexpr int H = decltype(half)::value;
-        const _Float16 *bh = xs + (s & (T3_NB - 1)) * T3_STAGE_HALFS + lane * 8;
+        const _Float16 *bh = xs + (s & (T3_NB - 1)) * STAGE_HALFS + lane * 8;
         const int k0 = kofs + (s >> 1) * 128;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -1684,9 +1689,9 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
     };
     // End of stage s: stage s+1 must be complete in LDS for every wave, and (s odd) the weight group of the next two stages in
     // this wave's registers.  Steady state (s + 4 < nst): younger than both are exactly DMA(s+2), DMA(s+3) and ONE weight group
-    // (issued at the start of whichever of s-1, s is even) = 8 + NA instructions; the last four stages drain instead.
+    // (issued at the start of whichever of s-1, s is even) = 2 DPW + NA instructions; the last four stages drain instead.
     auto publish = [&](int s) {
-        if (s + 4 < nst) t3_wait_barrier<8 + NA>();
+        if (s + 4 < nst) t3_wait_barrier<2 * DPW + NA>();
         else if (s + 1 < nst) t3_wait_barrier<0>();
     };
     auto super = [&](Set &cur, Set &refill, int sc) {
@@ -1709,7 +1714,7 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
     dma(0);
     if (nst > 1) dma(1);
     if (nst > 2) dma(2);
-    if (nst > 2) t3_wait_barrier<8>(); else t3_wait_barrier<0>();   // DMA(0) and the three weight groups have landed
+    if (nst > 2) t3_wait_barrier<2 * DPW>(); else t3_wait_barrier<0>();   // DMA(0) and the three weight groups have landed
     for (int sc = 0; sc < nsc; sc += 3) {
         super(a0, a2, sc);
         if (sc + 1 < nsc) super(a1, a0, sc + 1);
@@ -1724,21 +1729,22 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
     }
 }
 
+template <int NTL>
 __global__ __launch_bounds__(256, 2) void gemm_tile3_kernel(const GemmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int pi = 0;
     for (int i = 1; i < L.nprob; ++i)
         if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
     const GemmProb &P = L.p[pi];
-    if (P.fmt == W_F16) tg3_body<W_F16>(L, P, smem);
-    else if (P.fmt == W_INT8) tg3_body<W_INT8>(L, P, smem);
-    else tg3_body<W_NF4>(L, P, smem);
+    if (P.fmt == W_F16) tg3_body<W_F16, NTL>(L, P, smem);
+    else if (P.fmt == W_INT8) tg3_body<W_INT8, NTL>(L, P, smem);
+    else tg3_body<W_NF4, NTL>(L, P, smem);
 }
 bool gemm_tile3_supported(bool hilo, int K) { return !hilo && K % 128 == 0; }
 
 // tile shapes, largest first: {waves, strips per wave, n-tiles, k per chunk}
 static const int kTileShapes[GEMM_TILE_SHAPES][5] = {{8, 2, 8, 128, 0}, {8, 1, 8, 128, 0}, {4, 1, 8, 128, 0}, {4, 1, 4, 128, 0}, {4, 1, 4, 256, 0}, {8, 1, 8, 256, 0},
-                                                     {4, 1, 4, 256, 1}, {4, 2, 4, 128, 1}, {4, 2, 8, 128, 1}, {8, 2, 8, 128, 1}, {4, 2, 8, 128, 2}};
+                                                     {4, 1, 4, 256, 1}, {4, 2, 4, 128, 1}, {4, 2, 8, 128, 1}, {8, 2, 8, 128, 1}, {4, 2, 8, 128, 2}, {4, 2, 4, 128, 2}};
 // (128 rows x 64 tokens with 8 waves, 256-k and 128-k chunks — half the operand re-reads of the 64x64 shapes on steps of a few hundred
 // rows — was built and measured in round 3: slower on every matrix but one, profiles/r3_exp_tile_128x64.log; removed.)
 int gemm_tile_blocks(int shape, int rows, int T) {
@@ -1752,10 +1758,12 @@ void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s) 
         int dev3 = 0;
         (void)hipGetDevice(&dev3);
         if (!attr3[dev3 & 15]) {
-            (void)hipFuncSetAttribute((const void *)gemm_tile3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)gemm_tile3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)gemm_tile3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr3[dev3 & 15] = true;
         }
-        hipLaunchKernelGGL(gemm_tile3_kernel, dim3(L.total_blocks), dim3(256), (size_t)T3_NB * T3_STAGE_HALFS * 2, s, L);
+        if (kTileShapes[shape][2] == 8) hipLaunchKernelGGL(gemm_tile3_kernel<8>, dim3(L.total_blocks), dim3(256), (size_t)T3_NB * 8 * 2 * 512 * 2, s, L);
+        else hipLaunchKernelGGL(gemm_tile3_kernel<4>, dim3(L.total_blocks), dim3(256), (size_t)T3_NB * 4 * 2 * 512 * 2, s, L);
         return;
     }
     const int bt = kTileShapes[shape][2] * 16, kc = kTileShapes[shape][3];

@@ -128,9 +128,9 @@ def wide3b():
 
 
 @pytest.mark.parametrize("shape,qt", [(3, 0), (3, 1), (3, 2), (7, 0), (7, 1), (7, 2), (4, 1), (0, 1), (1, 1), (2, 1), (5, 1),
-                                       (6, 1), (8, 1), (9, 1), (9, 0), (10, 0), (10, 1), (10, 2)])
+                                       (6, 1), (8, 1), (9, 1), (9, 0), (10, 0), (10, 1), (10, 2), (11, 0), (11, 1), (11, 2)])
 def test_every_prefill_tile_shape_at_3b_width(wide3b, shape, qt):
-    """gemm_tile_kernel in each of its ten shapes and the pipelined 128x128 kernel (shape 10) (rwkv_engine.cpp picks by grid
+    """gemm_tile_kernel in each of its ten shapes and the pipelined kernel on 128x128 (shape 10) and 128x64 tiles (shape 11) (rwkv_engine.cpp picks by grid
     size; the rest are reachable through RWKV_TILE_SHAPE) on a 548-row ragged step of 3B-wide matrices, plus `wkv_chunk_kernel<6,64>` at H = 40."""
     st, ps, ref = wide3b
     want, states = ref[qt]
@@ -147,12 +147,13 @@ def test_every_prefill_tile_shape_at_3b_width(wide3b, shape, qt):
 
 
 def test_pipelined_tile_kernel_is_bit_identical_to_the_64x64_shape_over_repeated_runs(wide3b):
-    """Race screen for the counted-vmcnt K loop of shape 10 (inline-asm loads, LDS-DMA ring, raw barriers): both kernels add the
+    """Race screen for the counted-vmcnt K loop of shapes 10 and 11 (inline-asm loads, LDS-DMA ring, raw barriers): all three kernels add the
     k-steps of a row in the same order into fp32 MFMA accumulators, so logits and state must be BIT-identical to the 64x64
     shape's, on every one of several runs (a landed-too-late tile would show up as a differing run)."""
     st, ps, _ = wide3b
     outs = {}
-    for shape in (4, 10):
+    os.environ["RWKV_TILE_KSPLIT"] = "0"              # K copies of the linear launches change the summation order, by design
+    for shape in (4, 10, 11):
         os.environ["RWKV_TILE_SHAPE"] = str(shape)
         try:
             for qt in (0, 1, 2):
@@ -167,9 +168,10 @@ def test_pipelined_tile_kernel_is_bit_identical_to_the_64x64_shape_over_repeated
                 eng.close()
         finally:
             os.environ.pop("RWKV_TILE_SHAPE", None)
+    os.environ.pop("RWKV_TILE_KSPLIT", None)
     for qt in (0, 1, 2):
         ref_l, ref_s = outs[(4, qt)][0]
-        for shape in (4, 10):
+        for shape in (4, 10, 11):
             for rep, (lg, stt) in enumerate(outs[(shape, qt)]):
                 assert np.array_equal(lg, ref_l), f"logits differ: shape {shape} quant {qt} run {rep}"
                 assert np.array_equal(stt, ref_s), f"state differs: shape {shape} quant {qt} run {rep}"
