@@ -962,15 +962,19 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         // The pipelined kernel on 128 x 64 tiles (shape 11, round 4) for the NON-linear launches of steps the 128-token tile cannot fill:
         // at 256 rows a 10304-row launch is 160 tiles of 128 x 128 (fewer than CUs) but 324 of 128 x 64, each prefetching four stages
         // ahead where the 64 x 64 shapes prefetch one chunk: r/k/v/g/decay 49.7 -> 40.8 us, Fk / Fr 45.7 -> 40.0 (Int8, 256 rows).
-        // Measured by row count and weight format (profiles/r4_exp_tile3_128x64.log; V6-3B Int8 / fp16, V7-2.9B NF4, V6-7B fp16):
-        //   quantised: 256 rows +6.5 % / +4.6 % (NF4), 512 rows -5 % / -3 %, 1024 rows +4.7 % / +4 %;  fp16: 256 rows -7.5 % (3 B) / +1.7 % (7 B),
-        //   512 rows +1.6 % / +5.9 %, 1024 rows +4.4 % / +3.1 %;  2048 rows: the 128 x 128 tile wins everywhere.
+        // Where it pays, measured after the epilogue rewrite (profiles/r4_exp_tile3_128x64.log, last section; V6-3B Int8 / fp16, V7-2.9B
+        // NF4, V6-7B fp16): quantised launches at 256 rows (Int8 +5.8 %, NF4 even) and NF4 at 1024 rows (+2.7 %); fp16 at 512 rows (7 B
+        // +8 %, 3 B +1 %); everywhere else the 64 x 64 shapes or the 128 x 128 tile are as fast or faster (fp16 at 1024 rows -3 %).
         // The linear launches (Wo, Fv) stay on K copies of 64 x 64 tiles (22 us at 256 rows against 30).  RWKV_TILE3_64=0 turns the rule off.
         {
             const bool linear_launch = ps.size() == 1 && ps[0].partial;
-            bool big_f16 = false;
-            for (auto &sp : ps) big_f16 = big_f16 || (sp.W->fmt == W_F16 && sp.W->rows > 256);
-            const bool in_range = big_f16 ? (T > 320 && T <= 1280) : (T <= 320 || (T > 768 && T <= 1280));
+            bool big_f16 = false, big_not_nf4 = false;
+            for (auto &sp : ps) {
+                if (sp.W->rows <= 256) continue;                       // (the decay LoRA's 64 fp16 rows ride along)
+                big_f16 = big_f16 || sp.W->fmt == W_F16;
+                big_not_nf4 = big_not_nf4 || sp.W->fmt != W_NF4;
+            }
+            const bool in_range = big_f16 ? (T > 320 && T <= 768) : (T <= 320 || (!big_not_nf4 && T > 768 && T <= 1280));
             if (ok3 && kn.tile3_64 && !linear_launch && in_range) shape = GEMM_TILE3_64;
         }
         if (f_shape >= 0 && f_shape < GEMM_TILE_SHAPES && ((f_shape != GEMM_TILE3 && f_shape != GEMM_TILE3_64) || ok3)) shape = f_shape;

@@ -54,6 +54,18 @@ __device__ __forceinline__ float apply_act(int act, float v) {
     }
 }
 
+// the switch outside, four values inside: one pass over the branches per output fragment instead of one per element (same arithmetic)
+__device__ __forceinline__ void apply_act4(int act, float (&v)[4]) {
+    switch (act) {
+        case ACT_NONE: break;
+        case ACT_TANH: for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]); break;
+        case ACT_SIGMOID: for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]); break;
+        case ACT_RELU2: for (int r = 0; r < 4; ++r) { const float q = fmaxf(v[r], 0.0f); v[r] = q * q; } break;
+        case ACT_SILU: for (int r = 0; r < 4; ++r) v[r] = v[r] * sigmoidf_(v[r]); break;
+        case ACT_DECAY7: for (int r = 0; r < 4; ++r) v[r] = expf(-0.606531f * sigmoidf_(v[r])); break;
+        default: break;
+    }
+}
 // fp32 -> (hi, lo) f16 pair: hi = rn(v) saturated, lo = rn(v - hi).  hi+lo carries ~22 mantissa bits.
 __device__ __forceinline__ void split_hilo(float v, _Float16 &hi, _Float16 &lo) {
     float c = fminf(fmaxf(v, -65504.0f), 65504.0f);
@@ -513,18 +525,6 @@ __device__ __forceinline__ const void *pin_p(const void *p) {
     const unsigned long long v = (unsigned long long)p;
     const unsigned lo = (unsigned)pin_s((int)(unsigned)v), hi = (unsigned)pin_s((int)(unsigned)(v >> 32));
     return (const void *)(((unsigned long long)hi << 32) | lo);
-}
-// the switch outside, four values inside: one pass over the branches per output fragment instead of one per element (same arithmetic)
-__device__ __forceinline__ void apply_act4(int act, float (&v)[4]) {
-    switch (act) {
-        case ACT_NONE: break;
-        case ACT_TANH: for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]); break;
-        case ACT_SIGMOID: for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]); break;
-        case ACT_RELU2: for (int r = 0; r < 4; ++r) { const float q = fmaxf(v[r], 0.0f); v[r] = q * q; } break;
-        case ACT_SILU: for (int r = 0; r < 4; ++r) v[r] = v[r] * sigmoidf_(v[r]); break;
-        case ACT_DECAY7: for (int r = 0; r < 4; ++r) v[r] = expf(-0.606531f * sigmoidf_(v[r])); break;
-        default: break;
-    }
 }
 template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, int FMT, bool LNP>
 __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
@@ -1290,36 +1290,44 @@ __device__ __forceinline__ void glds16(const _Float16 *g, _Float16 *lds) {
                                      (__attribute__((address_space(3))) void *)(uintptr_t)(uint32_t)(uintptr_t)lds, 16, 0, 0);
 }
 
-// Epilogue of the tile kernels: acc[h][nt][r] = row (strip+h)*16 + (lane>>4)*4 + r, token t0 + nt*16 + (lane&15)
+// Epilogue of the tile kernels: acc[h][nt][r] = row (strip+h)*16 + (lane>>4)*4 + r, token t0 + nt*16 + (lane&15).
+// The problem's parameters are read once, the activation switch is taken once per (strip, token tile) fragment and the bias / POST operands
+// come as one 16-byte load each: the per-element form (a bias test, a six-way switch and three scalar loads per output, inlined SPW x NTL x 4
+// times) was ~10 k instructions of straight-line code per weight format at the end of every block — 2/3 of the pipelined kernel's 536 KB.
 template <int SPW, int NTL>
 __device__ __forceinline__ void tg_epilogue(const GemmLaunch &L, const GemmProb &P, f32x4 (&acc)[SPW][NTL], int strip, int nstrips, int t0, int lane) {
+    const int act = P.act, post = P.post, ldm = P.ldm, ldo = P.ldo, ldh = P.ldh;
+    const float *bias = P.bias, *m0 = P.m0, *m1 = P.m1;
+    float *out32 = P.out_f32;
+    _Float16 *ohi = P.out_hi, *olo = P.out_lo;
 #pragma unroll
     for (int h = 0; h < SPW; ++h) {
         if (strip + h < nstrips) {
             const int row0 = (strip + h) * 16 + (lane >> 4) * 4;
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) b4 = *(const float4 *)(bias + row0);
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt) {
                 const int t = t0 + nt * 16 + (lane & 15);
                 if (t < L.T) {
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float x = acc[h][nt][r];
-                        if (P.bias) x += P.bias[row0 + r];
-                        x = apply_act(P.act, x);
-                        if (P.post == POST_MUL) x *= P.m0[(long)t * P.ldm + row0 + r];
-                        else if (P.post == POST_MIX)
-                            x = P.m0[(long)t * P.ldm + row0 + r] + P.m1[(long)t * P.ldm + row0 + r] * x;
-                        v[r] = x;
+                    float v[4] = {acc[h][nt][0], acc[h][nt][1], acc[h][nt][2], acc[h][nt][3]};
+                    if (bias) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+                    apply_act4(act, v);
+                    if (post == POST_MUL) {
+                        const float4 m = *(const float4 *)(m0 + (long)t * ldm + row0);
+                        v[0] *= m.x; v[1] *= m.y; v[2] *= m.z; v[3] *= m.w;
+                    } else if (post == POST_MIX) {
+                        const float4 m = *(const float4 *)(m0 + (long)t * ldm + row0), n = *(const float4 *)(m1 + (long)t * ldm + row0);
+                        v[0] = m.x + n.x * v[0]; v[1] = m.y + n.y * v[1]; v[2] = m.z + n.z * v[2]; v[3] = m.w + n.w * v[3];
                     }
-                    if (P.out_f32) *(float4 *)(P.out_f32 + (long)t * P.ldo + row0) = make_float4(v[0], v[1], v[2], v[3]);
-                    if (P.out_hi) {
+                    if (out32) *(float4 *)(out32 + (long)t * ldo + row0) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (ohi) {
                         f16x4 hh, ll;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { _Float16 a, b; split_hilo(v[r], a, b); hh[r] = a; ll[r] = b; }
-                        const long oo = opd_off(t, row0, P.ldh);
-                        *(f16x4 *)(P.out_hi + oo) = hh;
-                        if (P.out_lo) *(f16x4 *)(P.out_lo + oo) = ll;
+                        const long oo = opd_off(t, row0, ldh);
+                        *(f16x4 *)(ohi + oo) = hh;
+                        if (olo) *(f16x4 *)(olo + oo) = ll;
                     }
                 }
             }
@@ -1615,8 +1623,8 @@ __device__ __forceinline__ f16x8 t3_frag(const T3Set<FMT> &w, int h, int ks, int
 // the 128-token tile leaves 160 blocks for a 10304-row launch; this one 324, each moving half the operand)
 template <int FMT, int NTL>
 __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
-    constexpr int SPW = 2, BT = NTL * 16, STRIPS = 8, NA = T3Set<FMT>::NLOAD;
-    constexpr int DPW = NTL / 2;                                  // X tiles (DMAs) per wave per stage: 2 NTL tiles over 4 waves
+    constexpr int SPW = 2, BT = NTL * 16, STRIPS = 8, NA = T3Set<FMT>::NLOAD, WAVES = 4, NTW = NTL;
+    constexpr int DPW = 2 * NTL / WAVES;                          // X tiles (DMAs) per wave per stage: 2 NTL tiles over the block's four waves
     constexpr int STAGE_HALFS = NTL * 2 * 512;                    // [token tile][k-step][lane][8]
     using Set = T3Set<FMT>;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1649,25 +1657,25 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
     Nf4Lut lut;
     if constexpr (FMT == W_NF4) lut = make_nf4_lut();
 
-    f32x4 acc[SPW][NTL];
+    f32x4 acc[SPW][NTW];
 #pragma unroll
     for (int h = 0; h < SPW; ++h)
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt) acc[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NTW; ++nt) acc[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // the DPW X tiles of a stage this wave fetches: i = m*4 + wave -> (token tile i >> 1, k-step i & 1); tiles past the step
+    // the DPW X tiles of a stage this wave fetches: i = m*WAVES + wave -> (token tile i >> 1, k-step i & 1); tiles past the step
     // are clamped to its last tile (their columns are never stored)
     const _Float16 *xsrc[DPW];
 #pragma unroll
     for (int m = 0; m < DPW; ++m) {
-        const int i = m * 4 + wave;
+        const int i = m * WAVES + wave;
         const int ttile = min((t0 >> 4) + (i >> 1), last_tile);
         xsrc[m] = P.xhi + ((long)ttile * (P.ldx >> 5) + (kofs >> 5) + (i & 1)) * 512 + lane * 8;
     }
     auto dma = [&](int s) {
         const unsigned dst = xs_byte + (unsigned)(((s & (T3_NB - 1)) * STAGE_HALFS + wave * 512) * 2);
 #pragma unroll
-        for (int m = 0; m < DPW; ++m) t3_dma16(xsrc[m] + (long)s * 1024, dst + m * 4 * 1024);
+        for (int m = 0; m < DPW; ++m) t3_dma16(xsrc[m] + (long)s * 1024, dst + m * WAVES * 1024);
     };
     auto stage = [&](const Set &w, int s, auto half) {
         constexpr int H = decltype(half)::value;
@@ -1675,14 +1683,14 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
         const int k0 = kofs + (s >> 1) * 128;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            f16x8 xv[NTL];
+            f16x8 xv[NTW];
 #pragma unroll
-            for (int nt = 0; nt < NTL; ++nt) xv[nt] = *(const f16x8 *)(bh + (nt * 2 + q) * 512);
+            for (int nt = 0; nt < NTW; ++nt) xv[nt] = *(const f16x8 *)(bh + (nt * 2 + q) * 512);
             f16x8 af[SPW];
 #pragma unroll
             for (int h = 0; h < SPW; ++h) af[h] = t3_frag<FMT>(w, h, H * 2 + q, k0, lut);
 #pragma unroll
-            for (int nt = 0; nt < NTL; ++nt)
+            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                 for (int h = 0; h < SPW; ++h) acc[h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[h], xv[nt], acc[h][nt], 0, 0, 0);
         }
@@ -1723,9 +1731,9 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
     if (P.ksb > 1) {                                              // partial slab kb (host: out_f32 only, linear epilogue)
         GemmProb Q = P;
         Q.out_f32 = P.out_f32 + (long)kb * P.partial_stride;
-        tg_epilogue<SPW, NTL>(L, Q, acc, strip, nstrips, t0, lane);
+        tg_epilogue<SPW, NTW>(L, Q, acc, strip, nstrips, t0, lane);
     } else {
-        tg_epilogue<SPW, NTL>(L, P, acc, strip, nstrips, t0, lane);
+        tg_epilogue<SPW, NTW>(L, P, acc, strip, nstrips, t0, lane);
     }
 }
 
@@ -1753,7 +1761,7 @@ int gemm_tile_blocks(int shape, int rows, int T) {
 }
 
 void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s) {
-    if (kTileShapes[shape][4] == 2) {                          // pipelined 128x128 kernel (caller checked gemm_tile3_supported)
+    if (kTileShapes[shape][4] == 2) {                          // pipelined kernel (caller checked gemm_tile3_supported)
         static bool attr3[16] = {false};
         int dev3 = 0;
         (void)hipGetDevice(&dev3);
