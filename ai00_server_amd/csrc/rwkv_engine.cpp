@@ -235,6 +235,8 @@ struct rwkv_engine {
     bool hilo = false;
     int quant_layers = 0, quant_type = 0;
     hipStream_t s_main = nullptr, s_soft = nullptr;
+    FILE *launch_log = nullptr;                                // RWKV_LAUNCH_LOG=<path> (dev): one JSON line per GEMM launch of layer 0 / the head
+    int cur_layer = -1;                                        //   (grid, rows, K, stored bytes, flops): scripts/roofline_table.py joins it with rocprofv3's CSV
     hipStream_t s_copy = nullptr;                              // rwkv_state_back_layer_async: pack + device-to-host copy beside the compute stream
     hipEvent_t ev_copy_a = nullptr, ev_copy_b = nullptr;
     float *emb_stage = nullptr;                                // [max_batch][64 * C]: one packed layer slice per slot
@@ -339,6 +341,7 @@ struct rwkv_engine {
         if (s_main) (void)hipStreamDestroy(s_main);
         if (s_soft) (void)hipStreamDestroy(s_soft);
         if (s_copy) (void)hipStreamDestroy(s_copy);
+        if (launch_log) std::fclose(launch_log);
         if (ev_copy_a) (void)hipEventDestroy(ev_copy_a);
         if (ev_copy_b) (void)hipEventDestroy(ev_copy_b);
         if (emb_stage) (void)hipFree(emb_stage);
@@ -381,6 +384,7 @@ struct rwkv_engine {
 
     void load(const rwkv_load_desc &d);
     int gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs *lnp = nullptr, const ShiftCommit *commit = nullptr);
+    void log_gemm(const std::vector<ProbSpec> &ps, int T, int fam, const char *kind, int variant, int grid, int ksplit);
     bool ln_fusable(std::vector<ProbSpec> &ps, int T, int np);
     float *lnp_xx_att = nullptr, *lnp_xx_ffn = nullptr;   // normalised rows published by an LN-prologue launch (for the commit)
     void plan_step(const rwkv_slot_input *in, StepPlan &pl);
@@ -470,6 +474,7 @@ void rwkv_engine::save_prefab(const char *path) {
 }
 
 void rwkv_engine::load(const rwkv_load_desc &d) {
+    if (const char *lp = std::getenv("RWKV_LAUNCH_LOG")) if (*lp) launch_log = std::fopen(lp, "a");
     const bool pf = prefab_sniff(d.st_bytes, d.st_len);      // lib.rs:585-588: the file is sniffed, not named
     Prefab prefab;
     SafeTensors st;
@@ -970,7 +975,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
             const bool linear_launch = ps.size() == 1 && ps[0].partial;
             bool big_f16 = false, big_not_nf4 = false;
             for (auto &sp : ps) {
-                if (sp.W->rows <= 256) continue;                       // (the decay LoRA's 64 fp16 rows ride along)
+                if (sp.W->rows <= 512) continue;                       // (the fp16 LoRA stages — V6's decay, V7's w / a / g / v: 64..320 rows — ride along)
                 big_f16 = big_f16 || sp.W->fmt == W_F16;
                 big_not_nf4 = big_not_nf4 || sp.W->fmt != W_NF4;
             }
@@ -1025,14 +1030,36 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         }
         Lh.total_blocks = blocks;
         Lh.xcd_map = kn.tile_xcd;                                   // A/B switch
+        log_gemm(ps, T, fam, "tile", shape, blocks, ksplit);
         launch(fam, [&] { launch_gemm_tile(Lh, shape, hilo, s_main); });
         return ksplit;
     }
     const int np = plan_gemm(Lh, ps, T, hilo, pstride);
     if (lnp) Lh.lnp = *lnp;
     if (commit) Lh.commit = *commit;
+    log_gemm(ps, T, fam, "decode", Lh.single_shot, Lh.total_blocks + (Lh.commit.src ? 1 : 0), np);
     launch(fam, [&] { launch_gemm(Lh, hilo, s_main); });
     return np;
+}
+
+// RWKV_LAUNCH_LOG (dev): what a launch of layer 0 (or the head) streams and computes, so that a profile can be priced without guessing which
+// grid size is which launch: {"kind","variant","T","grid","ksplit","rows","bytes","flops","mats"}
+void rwkv_engine::log_gemm(const std::vector<ProbSpec> &ps, int T, int fam, const char *kind, int variant, int grid, int ksplit) {
+    if (!launch_log || (cur_layer != 0 && fam != FAM_HEAD)) return;
+    uint64_t bytes = 0;
+    double flops = 0;
+    long rows = 0;
+    std::string names;
+    for (auto &sp : ps) {
+        bytes += sp.W->bytes;
+        rows += sp.W->rows;
+        flops += 2.0 * T * (double)sp.W->rows * sp.W->K;
+        for (auto &kv : mats)
+            if (&kv.second == sp.W) { names += (names.empty() ? "" : "+") + kv.first; break; }
+    }
+    std::fprintf(launch_log, "{\"kind\": \"%s\", \"variant\": %d, \"T\": %d, \"grid\": %d, \"ksplit\": %d, \"rows\": %ld, \"bytes\": %llu, \"flops\": %.0f, \"mats\": \"%s\"}\n",
+                 kind, variant, T, grid, ksplit, rows, (unsigned long long)bytes, flops, names.c_str());
+    std::fflush(launch_log);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1155,6 +1182,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
     }
     for (int l = 0; l < L; ++l) {
         const LayerW &w = layers[l];
+        cur_layer = l;
         // ---- time mix
         LnShiftArgs a{};
         a.x_in = cur; a.x_out = oth; a.P = P; a.np = np; a.pstride = pstride;

@@ -12,10 +12,14 @@ cd /tmp
 run_stats () {   # name, then the command
   local name=$1; shift
   rm -rf $O/prof_$name
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o p -- "$@" > $O/prof_$name.log 2>&1
+  rm -f $P/${TAG}_launch_log_$name.jsonl
+  RWKV_LAUNCH_LOG=$P/${TAG}_launch_log_$name.jsonl timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o p -- "$@" > $O/prof_$name.log 2>&1
+  [ -f $P/${TAG}_launch_log_$name.jsonl ] && sort -u $P/${TAG}_launch_log_$name.jsonl -o $P/${TAG}_launch_log_$name.jsonl
   local tr=$(find $O/prof_$name -name "*kernel_trace.csv" | head -1)
   [ -n "$tr" ] && python $R/scripts/summarize_trace.py $tr $P/${TAG}_kernel_stats_$name.csv --skip-load
-  grep -h '"metric"' $O/prof_$name.log | tail -1 > $P/${TAG}_bench_line_$name.json
+  # what the profiled command itself reported: the bench's JSON line, or (prefill_probe.py) its "... prefill tok/s" lines — never an empty file
+  if grep -q '"metric"' $O/prof_$name.log; then grep -h '"metric"' $O/prof_$name.log | tail -1 > $P/${TAG}_bench_line_$name.json
+  else grep -h "prefill tok/s" $O/prof_$name.log > $P/${TAG}_probe_line_$name.txt; fi
   echo "stats $name rc=$?"
 }
 BENCH="python $R/bench.py --decode-only --no-cpu-baseline --sweep= --verify-steps 0 --steps 50 --warmup 5"
