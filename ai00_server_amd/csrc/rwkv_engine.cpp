@@ -1045,7 +1045,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
 // RWKV_LAUNCH_LOG (dev): what a launch of layer 0 (or the head) streams and computes, so that a profile can be priced without guessing which
 // grid size is which launch: {"kind","variant","T","grid","ksplit","rows","bytes","flops","mats"}
 void rwkv_engine::log_gemm(const std::vector<ProbSpec> &ps, int T, int fam, const char *kind, int variant, int grid, int ksplit) {
-    if (!launch_log || (cur_layer != 0 && fam != FAM_HEAD)) return;
+    if (!launch_log || (cur_layer > 1 && fam != FAM_HEAD)) return;       // layers 0 and 1 (V7's layer 0 has no value-residual LoRA) + the head
     uint64_t bytes = 0;
     double flops = 0;
     long rows = 0;
