@@ -85,10 +85,10 @@ def test_real_bench_as_two_ranks_on_one_device():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The line the driver parses (profiles/r3_bench_default.json is the last one measured on the GPU box): every key of the bench
+    """The line the driver parses (profiles/r4_bench_default.json is the last one measured on the GPU box): every key of the bench
     contract, the roofline and cpu_baseline objects with their fields, value = tokens of all ranks / the slowest rank's time."""
     import json
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r3_bench_default.json")).readline())
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r4_bench_default.json")).readline())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in line, k
     assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None and line["data"] == "synthetic"
@@ -105,3 +105,6 @@ def test_committed_bench_line_keeps_the_contract():
     B = line["config"]["batch_per_gpu"]
     assert abs(line["value"] - line["n_gpus"] * B * 1000.0 / line["ms_per_step"]) / line["value"] < 1e-6
     assert line["tokens_verified"] is True and line["embeddings"]["embeddings_verified"] is True
+    e = line["embeddings"]                                  # 512 documents x 256 tokens per rank at token_chunk_size 256
+    assert e["unit"] == "embeddings/s" and e["docs_per_rank"] == 512 and e["doc_tokens"] == 256 and e["token_chunk_size"] == 256
+    assert len(e["per_rank_embeddings_per_s"]) == line["n_gpus"] and len(line["pcie_inclusive"]["per_rank"]) == line["n_gpus"]
