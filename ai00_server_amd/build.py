@@ -41,7 +41,7 @@ def _sources_digest() -> str:
 
 def needs_build() -> bool:
     """Content-based (mtimes do not survive the copy to a GPU box): rebuild when a source differs from the stamp."""
-    if not all(os.path.exists(p) for p in (LIB, HARNESS_BIN, SERVE_BIN, ROUTER_BIN, STAMP)):
+    if not all(os.path.exists(p) for p in (LIB, HARNESS_BIN, SERVE_BIN, ROUTER_BIN, EMBED_BIN, STAMP)):
         return True
     return open(STAMP).read().strip() != _sources_digest()
 
@@ -92,11 +92,13 @@ SERVE_SRC = os.path.join(HERE, "..", "harness", "serve_loop.cpp")
 SERVE_BIN = os.path.join(HERE, "..", "harness", "serve_loop")
 ROUTER_SRC = os.path.join(HERE, "..", "harness", "router_loop.cpp")
 ROUTER_BIN = os.path.join(HERE, "..", "harness", "router_loop")
+EMBED_SRC = os.path.join(HERE, "..", "harness", "embed_job.cpp")
+EMBED_BIN = os.path.join(HERE, "..", "harness", "embed_job")
 
 
 def build_harness(verbose: bool = True) -> str:
     """C++ mirror of ai00-core's infer task + greedy loop (harness/decode_loop.cpp), linked against the .so."""
-    for src, exe in ((HARNESS_SRC, HARNESS_BIN), (SERVE_SRC, SERVE_BIN), (ROUTER_SRC, ROUTER_BIN)):
+    for src, exe in ((HARNESS_SRC, HARNESS_BIN), (SERVE_SRC, SERVE_BIN), (ROUTER_SRC, ROUTER_BIN), (EMBED_SRC, EMBED_BIN)):
         cmd = ["g++", "-O2", "-std=c++17", "-pthread", src, "-o", exe, "-L" + HERE, "-lrwkv_hip", "-Wl,-rpath," + HERE]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)

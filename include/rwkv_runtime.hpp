@@ -3,6 +3,7 @@
 //   Loader::info                    lib.rs:587            ModelBuilder(...).quant().lora().build()   lib.rs:484-516
 //   Runtime::infer(RnnInput&)       run.rs:1143           RnnInput / RnnInputBatch / RnnOption        run.rs:1128-1132
 //   State::{init,load,back,read,write}  run.rs:477,1099-1106     softmax(runtime, rows)               run.rs:1179
+//   State::{embed,embed_async,sync}  the `/embeddings` read-back (docs/doc-api/openai.md:376-437): one layer's WKV rows of a slot
 //   Tokenizer::{encode,decode}      run.rs:157,856
 // Errors surface as rwkv::Error (std::runtime_error) carrying the rwkv_status — the analogue of `anyhow ?`.
 #pragma once
@@ -50,6 +51,21 @@ class TensorGpu {                            // device-resident state snapshot (
     std::shared_ptr<rwkv_dstate> h_;         // clone == share, like the Rust `backed.clone()` (run.rs:962)
 };
 
+// float32 block in pinned host memory (rwkv_host_alloc): where asynchronous read-backs (State::embed_async) land
+class PinnedBuffer {
+   public:
+    explicit PinnedBuffer(size_t n) : n_(n) {
+        void *p = nullptr;
+        check(rwkv_host_alloc((n ? n : 1) * sizeof(float), &p));
+        p_.reset((float *)p, rwkv_host_free);
+    }
+    float *data() const { return p_.get(); }
+    size_t size() const { return n_; }
+   private:
+    std::shared_ptr<float> p_;
+    size_t n_;
+};
+
 class State {
    public:
     explicit State(rwkv_engine *e) : e_(e) {}
@@ -62,6 +78,13 @@ class State {
     std::vector<float> back(int batch) { std::vector<float> v(rwkv_state_len(e_)); check(rwkv_state_back(e_, batch, v.data())); return v; }
     TensorGpu read(int batch) { rwkv_dstate *h = nullptr; check(rwkv_state_read(e_, batch, &h)); return TensorGpu(h); }
     void write(const TensorGpu &t, int batch) { check(rwkv_state_write(e_, batch, t.get())); }
+    // one layer's WKV rows of a slot, [head_size][num_emb] floats (rwkv_state_shape = [C, N + 2, L, 1]: the N rows between the two
+    // token-shift rows) — what `/embeddings` returns for the chosen layer
+    size_t layer_len() const { auto s = shape(); return s[0] * (s[1] - 2); }
+    void embed(int layer, int batch, float *dst) { check(rwkv_state_back_layer(e_, batch, layer, dst)); }
+    // not waited for: `dst` is pinned memory (PinnedBuffer), valid after sync(); the slot may take its next request at once
+    void embed_async(int layer, int batch, float *dst) { check(rwkv_state_back_layer_async(e_, batch, layer, dst)); }
+    void sync() { check(rwkv_state_sync(e_)); }
    private:
     rwkv_engine *e_;
 };

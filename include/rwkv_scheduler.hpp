@@ -279,7 +279,7 @@ class Scheduler {
         const size_t len = co.hit ? co.prefix_len : 0;
         if (co.hit) e_.state.load(*co.state, batch);
         else if (state_id != 0) e_.state.load(init_states_[state_id], batch);       // `state.unwrap_or_else(|| self.state.init())`, run.rs:476-477
-        else e_.state.load(e_.state.init(), batch);
+        else load_init(batch);
         Request r;
         r.prefix.assign(tokens.begin(), tokens.begin() + (long)len);
         r.suffix.assign(tokens.begin() + (long)len, tokens.end());
@@ -389,6 +389,44 @@ class Scheduler {
         slots_[batch].since = clock_;
     }
 
+    // The `/embeddings` route (docs/doc-api/openai.md:376-437; `GenerateKind::State` run.rs:980-989, api/oai/state.rs:29-40) fed a
+    // LIST of documents, as a batch job with slot turnover: every document is queued as a request of its own (RnnOption::None: the
+    // state is all it wants — no head GEMM, nothing for the prefix cache), an idle slot takes the next waiting one, all busy slots ride
+    // the same device steps, and a slot whose document has been read in hands over layer `layer`'s WKV rows ([head_size][num_emb]
+    // floats at out + doc * layer_len) and is free again.  With an engine whose State has embed_async / sync (rwkv::State) the rows
+    // leave on the copy stream into `out` (PINNED memory then) while the next documents prefill; otherwise the copy is waited for.
+    // Slots busy with other requests keep riding the steps.  Returns the number of device steps.  (Python twin: harness.StateJob.)
+    size_t embed_documents(const std::vector<Tokens> &docs, int layer, float *out) {
+        const size_t L = e_.state.layer_len();
+        std::vector<long> owner(slots_.size(), -1);
+        size_t next = 0, busy = 0, calls = 0;
+        try {
+            while (next < docs.size() || busy) {
+                while (next < docs.size()) {
+                    int b = -1;
+                    if (queue(docs[next], b, RnnOption::None) == SlotResult::Failure) break;
+                    owner[(size_t)b] = (long)next++;
+                    ++busy;
+                }
+                if (!busy) throw std::runtime_error("embed_documents(): every slot is held by another request");
+                step();
+                ++calls;
+                for (size_t b = 0; b < owner.size(); ++b) {
+                    if (owner[b] < 0 || !reqs_[b].suffix.empty()) continue;
+                    embed_out(e_.state, layer, (int)b, out + (size_t)owner[b] * L, 0);
+                    abort((int)b);                                                  // Idle with no content: the next document finds it Empty
+                    owner[b] = -1;
+                    --busy;
+                }
+            }
+            embed_sync(e_.state, 0);
+        } catch (...) {
+            for (size_t b = 0; b < owner.size(); ++b) if (owner[b] >= 0) abort((int)b);
+            throw;
+        }
+        return calls;
+    }
+
     // give a busy slot up without caching anything (its engine call failed, or the request was cancelled): Idle, no content
     void abort(int batch) {
         if (batch < 0 || batch >= (int)slots_.size()) return;
@@ -467,11 +505,25 @@ class Scheduler {
         }
         return riders;
     }
+    // the initial state into a slot: uploaded once, device-resident afterwards (`state.write(backed.clone(), batch)`, run.rs:1104) — a
+    // request that misses the cache does not pay a slab over PCIe
+    void load_init(int batch) {
+        if (!init_snap_) {
+            e_.state.load(e_.state.init(), batch);
+            init_snap_ = std::make_unique<InitSnap>(snapshot(e_.state, batch, 0));
+        } else restore(e_.state, *init_snap_, batch, 0);
+    }
+    template <class S> static auto embed_out(S &s, int layer, int b, float *dst, int) -> decltype(s.embed_async(layer, b, dst)) { return s.embed_async(layer, b, dst); }
+    template <class S> static void embed_out(S &s, int layer, int b, float *dst, long) { s.embed(layer, b, dst); }
+    template <class S> static auto embed_sync(S &s, int) -> decltype(s.sync()) { return s.sync(); }
+    template <class S> static void embed_sync(S &, long) {}
     // device-resident snapshot when the engine's State has read / write (rwkv::State), host round trip otherwise
     template <class S> static auto snapshot(S &s, int b, int) -> decltype(s.read(b)) { return s.read(b); }
     template <class S> static std::vector<float> snapshot(S &s, int b, long) { return s.back(b); }
     template <class S, class T> static auto restore(S &s, const T &t, int b, int) -> decltype(s.write(t, b)) { return s.write(t, b); }
     template <class S> static void restore(S &s, const std::vector<float> &t, int b, long) { s.load(t, b); }
+    using InitSnap = decltype(snapshot(std::declval<decltype(std::declval<Engine &>().state) &>(), 0, 0));
+    std::unique_ptr<InitSnap> init_snap_;
     void need_busy(int batch) const {
         if (batch < 0 || batch >= (int)slots_.size() || slots_[(size_t)batch].kind != SlotKind::Busy) throw std::invalid_argument("slot is not busy");
     }

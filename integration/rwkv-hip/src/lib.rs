@@ -169,6 +169,18 @@ impl Engine {
         let mut v = vec![0f32; (self.info.head_size * self.info.num_emb) as usize];
         check(unsafe { sys::rwkv_state_back_layer(self.raw, slot as i32, layer as i32, v.as_mut_ptr()) })?; Ok(v)
     }
+    /// The same rows, not waited for: they land in `dst` (pinned: `PinnedLogits`) at float offset `at`, valid after `state_sync()`.
+    /// The slot may take its next request at once — a finished document's read-back overlaps the prefill of the following ones.
+    /// `&mut` keeps safe code from reading the block before the sync that follows.
+    pub fn state_back_layer_async(&self, slot: usize, layer: usize, dst: &mut PinnedLogits, at: usize) -> Result<()> {
+        let n = (self.info.head_size * self.info.num_emb) as usize;
+        if at.checked_add(n).map_or(true, |end| end > dst.floats) {
+            return Err(Error { code: sys::RWKV_ERR_INVALID, message: format!("pinned block holds {} floats, rows need {}..{}", dst.floats, at, at.saturating_add(n)) });
+        }
+        check(unsafe { sys::rwkv_state_back_layer_async(self.raw, slot as i32, layer as i32, dst.ptr.add(at)) })
+    }
+    /// waits for every pending `state_back_layer_async`
+    pub fn state_sync(&self) -> Result<()> { check(unsafe { sys::rwkv_state_sync(self.raw) }) }
     /// `vN::read_state` (lib.rs:378-389); `Error.code == RWKV_ERR_NO_STATE` <-> the warning at lib.rs:442
     pub fn read_init_state(&self, st: &[u8]) -> Result<Vec<f32>> {
         let mut v = vec![0f32; unsafe { sys::rwkv_state_len(self.raw) }];

@@ -11,6 +11,9 @@ struct FakeState {
     std::vector<float> init() const { return {1.0f, 0.0f}; }
     void load(const std::vector<float> &t, int b) { slots.at((size_t)b) = t; }
     std::vector<float> back(int b) { return slots.at((size_t)b); }
+    // one "layer" of the state: (hash + layer, count)
+    size_t layer_len() const { return 2; }
+    void embed(int layer, int b, float *dst) { dst[0] = slots.at((size_t)b)[0] + (float)layer; dst[1] = slots.at((size_t)b)[1]; }
 };
 // state = (hash, count); a token updates hash = fmod(hash * 31 + tok + 1, 65521); logits[i] = fmod(hash + 7 i, 13)
 struct FakeEngine {
@@ -39,6 +42,7 @@ struct FakeEngine {
                 s[0] = std::fmod(s[0] * 31.0f + (float)t[i] + 1.0f, 65521.0f);
                 s[1] += 1.0f;
                 const bool last = i + 1 == t.size();
+                if (in.batches[(size_t)b].option == rwkv::RnnOption::None) continue;         // state only: no rows
                 if (in.batches[(size_t)b].option == rwkv::RnnOption::Full || last)
                     for (int v = 0; v < 8; ++v) out[(size_t)b].push_back(std::fmod(s[0] + 7.0f * v, 13.0f));
             }

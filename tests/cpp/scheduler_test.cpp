@@ -267,6 +267,41 @@ int main() {
         try { s.choose(c, choices, false); } catch (const std::logic_error &) { threw = true; }
         CHECK(threw);
     }
+    // --- embed_documents: more documents than slots, ragged lengths (some longer than a step's chunk), an empty one, and a slot held by
+    //     another request throughout.  Every document's rows == the fake engine run over that document alone from the initial state.
+    {
+        FakeEngine e(3, 4);
+        Scheduler<FakeEngine> s(e);
+        int held = -1;
+        CHECK(s.queue({9, 9}, held) == SlotResult::Success);
+        while (s.pending()) s.step();
+        const std::vector<float> held_state = s.state(held);
+        std::vector<Tokens> docs;
+        for (uint32_t d = 0; d < 9; ++d) {
+            Tokens t;
+            for (uint32_t i = 0; i < (d * 5) % 13; ++i) t.push_back((d * 7 + i * 3) % 8);
+            docs.push_back(t);                                               // lengths 0, 5, 10, 2, 7, 12, 4, 9, 1
+        }
+        std::vector<float> out(docs.size() * 2, -1.f);
+        const int calls_before = e.calls.load();
+        const size_t steps = s.embed_documents(docs, 3, out.data());
+        CHECK((int)steps == e.calls.load() - calls_before && steps >= 9);    // two free slots, 50 tokens + the empty document's [0], 4 per slot and step
+        for (size_t d = 0; d < docs.size(); ++d) {
+            float h = 1.0f, n = 0.0f;
+            Tokens t = docs[d].empty() ? Tokens{0} : docs[d];                 // run.rs:489-492
+            for (uint32_t tok : t) { h = std::fmod(h * 31.0f + (float)tok + 1.0f, 65521.0f); n += 1.0f; }
+            CHECK(out[2 * d] == h + 3.0f && out[2 * d + 1] == n);
+        }
+        CHECK(s.state(held) == held_state);                                  // the other request's slot was not touched
+        CHECK(s.cache().size() == 0);                                        // documents leave nothing in the prefix cache
+        for (int b = 0; b < 3; ++b) CHECK(b == held || (s.slot(b).kind == SlotKind::Idle && s.slot(b).content.empty()));
+        // every slot held: the job refuses instead of spinning
+        int x = -1, y = -1;
+        CHECK(s.queue({1}, x) != SlotResult::Failure && s.queue({2}, y) != SlotResult::Failure);
+        bool threw = false;
+        try { s.embed_documents(docs, 0, out.data()); } catch (const std::runtime_error &) { threw = true; }
+        CHECK(threw);
+    }
     std::printf("scheduler_test: ok\n");
     return 0;
 }
