@@ -1582,6 +1582,41 @@ __device__ __forceinline__ void t3_dma16(const void *g, unsigned lds_byte) {    
 template <int N> __device__ __forceinline__ void t3_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
+// ds_read_b128 whose completion the compiler does not track (see tg3_body's stage): paired with t3_lgkm_wait<N>, which retires
+// everything but the N youngest LGKM operations and hands the register back to the compiler
+template <int OFF> __device__ __forceinline__ void t3_lds16(f16x8 &d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void t3_lgkm_wait(f16x8 &x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N)); }
+// the NTW fragment reads of k-step Q of a stage ([token tile][k-step][lane][8] halfs: tile nt, k-step q at byte (2 nt + q) * 1024)
+template <int NTW, int Q, int NT = 0> __device__ __forceinline__ void t3_reads(f16x8 (&x)[NTW], unsigned xa) {
+    if constexpr (NT < NTW) {
+        t3_lds16<(NT * 2 + Q) * 1024>(x[NT], xa);
+        t3_reads<NTW, Q, NT + 1>(x, xa);
+    }
+}
+// first k-step: the read of the second k-step's tile nt goes out in front of the MFMA pair on tile nt — NTW reads in flight behind it
+template <int NTW, int SPW, int NT = 0>
+__device__ __forceinline__ void t3_head(f32x4 (&acc)[SPW][NTW], const f16x8 (&a)[SPW], f16x8 (&x0)[NTW], f16x8 (&x1)[NTW], unsigned xa) {
+    if constexpr (NT < NTW) {
+        t3_lds16<(NT * 2 + 1) * 1024>(x1[NT], xa);
+        t3_lgkm_wait<NTW>(x0[NT]);
+#pragma unroll
+        for (int h = 0; h < SPW; ++h) acc[h][NT] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h], x0[NT], acc[h][NT], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        t3_head<NTW, SPW, NT + 1>(acc, a, x0, x1, xa);
+    }
+}
+// second k-step: tile nt's fragment has NTW - 1 - nt younger reads behind it
+template <int NTW, int SPW, int NT = 0>
+__device__ __forceinline__ void t3_tail(f32x4 (&acc)[SPW][NTW], const f16x8 (&a)[SPW], f16x8 (&x)[NTW]) {
+    if constexpr (NT < NTW) {
+        t3_lgkm_wait<NTW - 1 - NT>(x[NT]);
+#pragma unroll
+        for (int h = 0; h < SPW; ++h) acc[h][NT] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h], x[NT], acc[h][NT], 0, 0, 0);
+        t3_tail<NTW, SPW, NT + 1>(acc, a, x);
+    }
+}
 // weight group of 128 k for two strips: tile loads + (quantised) one scale word per strip; NLOAD = VMEM instructions issued
 template <int FMT> struct T3Set {
     static constexpr int NQ = 4 / Fmt<FMT>::KS, NLOAD = 2 * NQ + (FMT == W_F16 ? 0 : 2);
@@ -1679,21 +1714,25 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
     };
     auto stage = [&](const Set &w, int s, auto half) {
         constexpr int H = decltype(half)::value;
-        const _Float16 *bh = xs + (s & (T3_NB - 1)) * STAGE_HALFS + lane * 8;
         const int k0 = kofs + (s >> 1) * 128;
+        // Fragment reads as inline asm with counted lgkmcnt waits (LDS returns in order; a scalar load the compiler may have in
+        // flight only makes a counted wait stricter): the stage's first NTW reads go out together, the dequantisation of the first
+        // k-step runs under them, and the read of the second k-step's tile nt is issued in front of the MFMA pair on the first
+        // k-step's tile nt — NTW reads are always in flight behind the one being waited for.  (Left to itself hipcc sinks every
+        // ds_read to its use and waits lgkmcnt(0) per MFMA pair.)
+        const unsigned xa = xs_byte + (unsigned)(((s & (T3_NB - 1)) * STAGE_HALFS + lane * 8) * 2);
+        f16x8 x0[NTW], x1[NTW];
+        t3_reads<NTW, 0>(x0, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        f16x8 a0[SPW], a1[SPW];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            f16x8 xv[NTW];
+        for (int h = 0; h < SPW; ++h) a0[h] = t3_frag<FMT>(w, h, H * 2, k0, lut);
+        __builtin_amdgcn_sched_barrier(0);
+        t3_head<NTW, SPW>(acc, a0, x0, x1, xa);
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) xv[nt] = *(const f16x8 *)(bh + (nt * 2 + q) * 512);
-            f16x8 af[SPW];
-#pragma unroll
-            for (int h = 0; h < SPW; ++h) af[h] = t3_frag<FMT>(w, h, H * 2 + q, k0, lut);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int h = 0; h < SPW; ++h) acc[h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[h], xv[nt], acc[h][nt], 0, 0, 0);
-        }
+        for (int h = 0; h < SPW; ++h) a1[h] = t3_frag<FMT>(w, h, H * 2 + 1, k0, lut);
+        __builtin_amdgcn_sched_barrier(0);
+        t3_tail<NTW, SPW>(acc, a1, x1);
     };
     // End of stage s: stage s+1 must be complete in LDS for every wave, and (s odd) the weight group of the next two stages in
     // this wave's registers.  Steady state (s + 4 < nst): younger than both are exactly DMA(s+2), DMA(s+3) and ONE weight group
