@@ -3,7 +3,7 @@
 // engine, no collective), `0` or `0,0` puts them all on one device so the N>1 path can be exercised on a one-GPU box.
 // Requests are routed by prefix affinity then least busy.  Prints one line per request: "<replica> <generated token ids...>"
 // (tests/test_gpu_parity.py compares with the oracle), then the follow-up request, "meta ..." and, on stderr, the wall time and
-// the aggregate rate of the first wave.
+// the aggregate rate of the first wave; then the prompts once more as an `/embeddings` batch job over the replicas ("emb ..." lines).
 // Usage: router_loop <model.st> <n_replicas> <device[,device...]> <max_batch> <chunk> <n_new> <prompt ...> [/ <prompt ...>]...
 #include <chrono>
 #include <cstdio>
@@ -72,6 +72,20 @@ int main(int argc, char **argv) {
             std::printf("%d", again.replica);
             for (auto t : again.generated) std::printf(" %u", t);
             std::printf("\nmeta %d %zu %d\n", where.first, where.second, reqs[0].replica);
+            // the `/embeddings` batch job over the replicas: the prompts as documents, State-kind requests routed like any other, the last
+            // layer's WKV rows read back asynchronously into one pinned block.  One line per document: "emb <sum> <v[0]> <v[L/3]> <v[L-1]>"
+            const size_t L = rts[0].state.layer_len();
+            rwkv::PinnedBuffer emb(prompts.size() * L);
+            const uint64_t steps_before[2] = {router.steps(0), router.steps(n_rep > 1 ? 1 : 0)};
+            router.embed_documents(prompts, rts[0].info.num_layer - 1, emb.data(), L);
+            for (size_t d = 0; d < prompts.size(); ++d) {
+                const float *v = emb.data() + d * L;
+                double sum = 0.0;
+                for (size_t i = 0; i < L; ++i) sum += v[i];
+                std::printf("emb %.9e %.9e %.9e %.9e\n", sum, v[0], v[L / 3], v[L - 1]);
+            }
+            std::printf("embsteps %llu %llu\n", (unsigned long long)(router.steps(0) - steps_before[0]),
+                        (unsigned long long)(router.steps(n_rep > 1 ? 1 : 0) - steps_before[1]));
         }
         return 0;
     } catch (const std::exception &e) {

@@ -22,6 +22,7 @@
 // rwkv::Scheduler needs (include/rwkv_scheduler.hpp), so the CPU test runs it over fake engines.
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -37,6 +38,11 @@ struct RoutedRequest {
     Tokens tokens;                                // the prompt (run.rs:489-492: empty => [0])
     int max_new = 0;                              // greedy tokens to generate after the prompt (0: prefill only)
     std::function<uint32_t(const std::vector<float> &)> sample;   // logits -> token; default arg-max (Nucleus top_k = 1)
+    // GenerateKind::State (run.rs:980-989) for the `/embeddings` route: embed_layer >= 0 makes this a state-only request (no logits, nothing
+    // sampled, nothing cached); when its tokens have been read in, that layer's WKV rows ([head_size][num_emb] floats) are written to
+    // `embed_dst` (pinned memory for rwkv::Runtime engines) before the request is reported done
+    int embed_layer = -1;
+    float *embed_dst = nullptr;
     // filled in by the replica thread
     Tokens generated;
     std::vector<float> last_output;
@@ -54,6 +60,7 @@ class ReplicaRouter {
         for (auto &r : reps_) {
             r->eject_after = std::max(1, eject_after);
             r->reroute = [this](RoutedRequest *rq) { return submit(rq); };
+            r->freed = [rm = room_] { { std::lock_guard<std::mutex> g(rm->mu); ++rm->epoch; } rm->cv.notify_all(); };
             r->thread = std::thread([p = r.get()] { p->run(); });
         }
     }
@@ -112,6 +119,43 @@ class ReplicaRouter {
             r->idle_cv.wait(g, [&] { return r->inflight == 0; });
         }
     }
+    // The `/embeddings` batch job over replicas (documents handed out request by request, results gathered on the host; no
+    // collective): every document becomes a State-kind request routed like any other (least busy replica with room), `out` receives
+    // document d's rows at out + d * layer_len.  Documents whose replica failed under them are handed out again while a healthy replica is
+    // left (at most `retries` times each); throws when a document cannot be placed or keeps failing.  Other traffic may be submitted
+    // concurrently.  Returns the number of documents that needed a retry.
+    size_t embed_documents(const std::vector<Tokens> &docs, int layer, float *out, size_t layer_len, int retries = 2) {
+        std::vector<RoutedRequest> reqs(docs.size());
+        std::vector<size_t> todo(docs.size());
+        for (size_t d = 0; d < docs.size(); ++d) todo[d] = d;
+        size_t retried = 0;
+        for (int round = 0; !todo.empty(); ++round) {
+            for (size_t d : todo) {
+                RoutedRequest &rq = reqs[d];
+                rq = RoutedRequest();
+                rq.tokens = docs[d];
+                rq.embed_layer = layer;
+                rq.embed_dst = out + d * layer_len;
+                for (;;) {
+                    uint64_t seen;
+                    { std::lock_guard<std::mutex> g(room_->mu); seen = room_->epoch; }
+                    if (submit(&rq) >= 0) break;
+                    if (healthy_count() == 0) { drain(); throw std::runtime_error("embed_documents(): no healthy replica left"); }
+                    std::unique_lock<std::mutex> g(room_->mu);                      // every replica full: wait until a request completes somewhere
+                    // (system_clock: pthread_cond_timedwait, which thread sanitizers of this toolchain intercept; steady_clock's clockwait they do not)
+                    room_->cv.wait_until(g, std::chrono::system_clock::now() + std::chrono::milliseconds(50), [&] { return room_->epoch != seen; });
+                }
+            }
+            drain();
+            std::vector<size_t> again;
+            std::string why;
+            for (size_t d : todo) if (reqs[d].failed) { again.push_back(d); why = reqs[d].error; }
+            if (!again.empty() && round >= retries) throw std::runtime_error("embed_documents(): " + std::to_string(again.size()) + " document(s) failed: " + why);
+            retried += again.size();
+            todo.swap(again);
+        }
+        return retried;
+    }
     int busy(int replica) { std::lock_guard<std::mutex> g(reps_[(size_t)replica]->mu); return reps_[(size_t)replica]->load(); }
     bool healthy(int replica) { std::lock_guard<std::mutex> g(reps_[(size_t)replica]->mu); return reps_[(size_t)replica]->healthy; }
     int healthy_count() { int n = 0; for (size_t i = 0; i < reps_.size(); ++i) n += healthy((int)i) ? 1 : 0; return n; }
@@ -137,6 +181,7 @@ class ReplicaRouter {
         int engine_failures = 0;                  // consecutive; a successful step resets it (guarded by mu)
         int eject_after = 2;
         std::function<int(RoutedRequest *)> reroute;   // the router's submit(): where unstarted requests of an ejected replica go
+        std::function<void()> freed;                   // tells the router that a request completed here (someone may be waiting for room)
         std::atomic<uint64_t> steps{0};
         std::thread thread;
         Replica(Engine &e, size_t max_cached) : sched(e, max_cached), capacity(e.max_batch) {}
@@ -165,7 +210,8 @@ class ReplicaRouter {
                     while (!fresh.empty()) {
                         RoutedRequest *rq = fresh.front();
                         int b = -1;
-                        if (sched.queue(rq->tokens, b) == SlotResult::Failure) break;   // every slot busy: park the rest until one frees
+                        const RnnOption opt = rq->embed_layer >= 0 ? RnnOption::None : RnnOption::Last;
+                        if (sched.queue(rq->tokens, b, opt) == SlotResult::Failure) break;   // every slot busy: park the rest until one frees
                         fresh.pop_front();
                         owner[(size_t)b] = rq;
                     }
@@ -180,9 +226,33 @@ class ReplicaRouter {
                 }
                 if (!engine_ok) continue;
                 if (stepped) { std::lock_guard<std::mutex> g(mu); engine_failures = 0; }
+                // State-kind requests whose tokens have been read in: the rows leave (asynchronously where the engine can), one wait for
+                // all of them, then the slots are given up without caching and the requests are done
+                try {
+                    std::vector<int> leaving;
+                    for (int b = 0; b < capacity; ++b) {
+                        RoutedRequest *rq = owner[(size_t)b];
+                        if (!rq || rq->embed_layer < 0 || !sched.request(b).suffix.empty()) continue;
+                        sched.embed(b, rq->embed_layer, rq->embed_dst);
+                        leaving.push_back(b);
+                    }
+                    if (!leaving.empty()) sched.embed_sync();
+                    for (int b : leaving) {
+                        RoutedRequest *rq = owner[(size_t)b];
+                        sched.abort(b);
+                        owner[(size_t)b] = nullptr;
+                        complete(rq, nullptr);
+                    }
+                } catch (const std::exception &ex) {
+                    engine_failed(owner, fresh, parked, ex.what());
+                    continue;
+                } catch (...) {
+                    engine_failed(owner, fresh, parked, "unknown exception while reading embeddings back");
+                    continue;
+                }
                 for (int b = 0; b < capacity; ++b) {
                     RoutedRequest *rq = owner[(size_t)b];
-                    if (!rq) continue;
+                    if (!rq || rq->embed_layer >= 0) continue;
                     try {
                         auto &r = sched.request(b);
                         if (!r.suffix.empty() || r.output.empty()) continue;           // still reading tokens in
@@ -249,10 +319,13 @@ class ReplicaRouter {
                 --inflight;
             }
             idle_cv.notify_all();
+            if (freed) freed();
         }
         static bool active(const std::vector<RoutedRequest *> &o) { for (auto *p : o) if (p) return true; return false; }
     };
     std::vector<std::unique_ptr<Replica>> reps_;
+    struct Room { std::mutex mu; std::condition_variable cv; uint64_t epoch = 0; };   // epoch advances whenever a request completes on any replica
+    std::shared_ptr<Room> room_ = std::make_shared<Room>();                           // shared with the replicas' `freed` callbacks
 };
 
 }  // namespace rwkv

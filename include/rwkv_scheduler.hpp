@@ -427,6 +427,12 @@ class Scheduler {
         return calls;
     }
 
+    // One layer's WKV rows of a busy slot to `dst` — through the engine's asynchronous read-back when it has one (valid after
+    // embed_sync(); `dst` pinned then), else copied before the call returns.  What the router's State-kind requests use.
+    void embed(int batch, int layer, float *dst) { need_busy(batch); embed_out(e_.state, layer, batch, dst, 0); }
+    void embed_sync() { embed_sync(e_.state, 0); }
+    size_t embed_len() const { return e_.state.layer_len(); }
+
     // give a busy slot up without caching anything (its engine call failed, or the request was cancelled): Idle, no content
     void abort(int batch) {
         if (batch < 0 || batch >= (int)slots_.size()) return;

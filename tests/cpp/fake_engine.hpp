@@ -1,7 +1,9 @@
 // A deterministic stand-in for rwkv::Runtime (no GPU, no HIP) for the CPU tests of the scheduling core and the router.
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <thread>
 #include <stdexcept>
 
 #include "../../include/rwkv_scheduler.hpp"
@@ -25,8 +27,10 @@ struct FakeEngine {
     std::vector<int> riders;
     std::atomic<int> fail_at{-1};   // infer call number that throws (a device error in the middle of a serving loop); -1: never
     std::atomic<int> fail_from{-1}; // every infer call from this number on throws (a STICKY device fault: HIP errors do not go away); -1: never
+    std::atomic<bool> hold{false};  // while set, infer() does not return (a test submits several requests "at the same instant")
     FakeEngine(int B, int chunk_) : max_batch(B), chunk(chunk_) { info.num_vocab = 8; state.slots.assign((size_t)B, state.init()); }
     std::vector<rwkv::RnnOutputBatch> infer(rwkv::RnnInput &in) {
+        while (hold.load()) std::this_thread::sleep_for(std::chrono::microseconds(20));
         const int call = ++calls;
         if (call == fail_at.load()) throw std::runtime_error("fake device error");
         if (fail_from.load() >= 0 && call >= fail_from.load()) throw std::runtime_error("fake sticky device fault");

@@ -1,6 +1,7 @@
 // CPU test of include/rwkv_router.hpp over fake engines (no GPU, no HIP): prefix affinity, least-busy placement, full
 // replicas skipped, per-replica threads, results identical to a single-engine run.
 #include <cassert>
+#include <cmath>
 #include <chrono>
 #include <thread>
 #include <cstdio>
@@ -101,7 +102,9 @@ int main() {
         RoutedRequest a, b, c, d;
         a.tokens = {1, 2, 3}; a.max_new = 50; b.tokens = {4, 5}; b.max_new = 50; c.tokens = {6}; c.max_new = 10; d.tokens = {7, 7}; d.max_new = 4;
         ReplicaRouter<FakeEngine> router(es);
+        e0.hold = true;                                                  // replica 0 cannot fail (and empty) before b and c are placed
         CHECK(router.submit(&a) == 0 && router.submit(&b) == 1 && router.submit(&c) >= 0);
+        e0.hold = false;
         router.drain();
         CHECK(a.done && a.failed && a.error.find("fake device error") != std::string::npos);
         CHECK(b.done && !b.failed && b.generated == greedy_alone(b.tokens, 50));
@@ -192,6 +195,69 @@ int main() {
         router.drain();
         CHECK(over.load() == 0);
         for (auto &q : reqs) CHECK(q.done && !q.failed && q.generated == greedy_alone(q.tokens, q.max_new));
+    }
+    // --- the `/embeddings` batch job over replicas: 40 ragged documents (an empty one among them) over 3 replicas x 2 slots while ordinary
+    //     requests are in flight; every document's rows equal the fake engine run over that document alone; every replica took part;
+    //     nothing is left in a slot or a prefix cache
+    {
+        std::vector<std::unique_ptr<FakeEngine>> engines;
+        std::vector<FakeEngine *> es;
+        for (int i = 0; i < 3; ++i) { engines.emplace_back(new FakeEngine(2, 4)); es.push_back(engines.back().get()); }
+        auto expect = [](const Tokens &doc, int layer, float *o) {
+            float h = 1.0f, n = 0.0f;
+            const Tokens t = doc.empty() ? Tokens{0} : doc;
+            for (uint32_t tok : t) { h = std::fmod(h * 31.0f + (float)tok + 1.0f, 65521.0f); n += 1.0f; }
+            o[0] = h + (float)layer; o[1] = n;
+        };
+        std::vector<Tokens> docs;
+        for (uint32_t d = 0; d < 40; ++d) {
+            Tokens t;
+            for (uint32_t i = 0; i < (d * 7) % 23; ++i) t.push_back((d * 5 + i * 3) % 8);
+            docs.push_back(t);
+        }
+        {
+            ReplicaRouter<FakeEngine> router(es);
+            RoutedRequest other;
+            other.tokens = Tokens{3, 1, 4}; other.max_new = 200;
+            CHECK(router.submit(&other) >= 0);
+            std::vector<float> out(docs.size() * 2, -1.f);
+            CHECK(router.embed_documents(docs, 5, out.data(), 2) == 0);
+            for (size_t d = 0; d < docs.size(); ++d) {
+                float want[2];
+                expect(docs[d], 5, want);
+                CHECK(out[2 * d] == want[0] && out[2 * d + 1] == want[1]);
+            }
+            CHECK(other.done && !other.failed && other.generated == greedy_alone(other.tokens, 200));
+            for (int i = 0; i < 3; ++i) CHECK(router.steps(i) > 0 && router.busy(i) == 0);
+        }
+        // a replica dies under the job (sticky fault from its third call on): it is ejected, its documents are handed out again, the
+        // job still returns every embedding
+        {
+            std::vector<std::unique_ptr<FakeEngine>> e2;
+            std::vector<FakeEngine *> es2;
+            for (int i = 0; i < 3; ++i) { e2.emplace_back(new FakeEngine(2, 4)); es2.push_back(e2.back().get()); }
+            e2[1]->fail_from = 3;
+            ReplicaRouter<FakeEngine> router(es2, 256, 2);
+            std::vector<float> out(docs.size() * 2, -1.f);
+            const size_t retried = router.embed_documents(docs, 0, out.data(), 2, 4);
+            CHECK(retried > 0 && !router.healthy(1) && router.healthy_count() == 2);
+            for (size_t d = 0; d < docs.size(); ++d) {
+                float want[2];
+                expect(docs[d], 0, want);
+                CHECK(out[2 * d] == want[0] && out[2 * d + 1] == want[1]);
+            }
+        }
+        // no healthy replica: the job reports it instead of waiting forever
+        {
+            FakeEngine bad(2, 4);
+            bad.fail_from = 1;
+            std::vector<FakeEngine *> es3{&bad};
+            ReplicaRouter<FakeEngine> router(es3, 256, 1);
+            std::vector<float> out(docs.size() * 2, -1.f);
+            bool threw = false;
+            try { router.embed_documents(docs, 0, out.data(), 2); } catch (const std::runtime_error &) { threw = true; }
+            CHECK(threw);
+        }
     }
     std::printf("router_test: ok\n");
     return 0;

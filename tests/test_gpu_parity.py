@@ -784,6 +784,20 @@ def test_cpp_router_over_two_real_engines_on_one_device(tmp_path):
     assert rows[6][1:] == want
     meta = [int(x) for x in lines[7].split()[1:]]
     assert meta[0] == meta[2] == rows[6][0] and meta[1] == len(follow) - 1   # routed to the replica that cached prompt + output
+    # the prompts again as an `/embeddings` batch job over both replicas (ReplicaRouter::embed_documents: State-kind requests, asynchronous
+    # read-back): the last layer's WKV rows of each document against the oracle's state of that document prefilled alone
+    emb = [[float(x) for x in ln.split()[1:]] for ln in lines if ln.startswith("emb ")]
+    assert len(emb) == 6
+    for i, p in enumerate(ps):
+        st = ref.init_state()
+        ref.forward(p, st)
+        rows_ = st[-1, 1:-1].reshape(-1)
+        tol = 1e-3 * max(1.0, float(np.abs(rows_).max()))
+        n = rows_.size
+        assert abs(emb[i][1] - rows_[0]) <= tol and abs(emb[i][2] - rows_[n // 3]) <= tol and abs(emb[i][3] - rows_[n - 1]) <= tol, i
+        assert abs(emb[i][0] - float(rows_.sum(dtype=np.float64))) <= tol * np.sqrt(n) , i
+    esteps = [int(x) for x in [ln for ln in lines if ln.startswith("embsteps")][0].split()[1:]]
+    assert min(esteps) > 0                                                # both replicas took documents
 
 
 def test_on_device_typical_sampling_matches_reference_sampler():
