@@ -108,3 +108,12 @@ def test_committed_bench_line_keeps_the_contract():
     e = line["embeddings"]                                  # 512 documents x 256 tokens per rank at token_chunk_size 256
     assert e["unit"] == "embeddings/s" and e["docs_per_rank"] == 512 and e["doc_tokens"] == 256 and e["token_chunk_size"] == 256
     assert len(e["per_rank_embeddings_per_s"]) == line["n_gpus"] and len(line["pcie_inclusive"]["per_rank"]) == line["n_gpus"]
+
+
+def test_committed_roofline_table_is_what_the_script_generates():
+    """profiles/r4_roofline_table.md is GENERATED from the committed rocprofv3 summaries and launch logs (scripts/roofline_table.py): the
+    per-launch fractions DESIGN.md quotes cannot drift from the evidence without this test noticing."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "roofline_table.py"), "r4"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == open(os.path.join(ROOT, "profiles", "r4_roofline_table.md")).read()
+    assert "0.6" in r.stdout and "(HBM)" in r.stdout and "(MFMA)" in r.stdout
