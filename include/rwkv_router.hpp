@@ -60,7 +60,8 @@ class ReplicaRouter {
         for (auto &r : reps_) {
             r->eject_after = std::max(1, eject_after);
             r->reroute = [this](RoutedRequest *rq) { return submit(rq); };
-            r->freed = [rm = room_] { { std::lock_guard<std::mutex> g(rm->mu); ++rm->epoch; } rm->cv.notify_all(); };
+            r->freed = [rm = room_] { { std::lock_guard<std::mutex> g(rm->mu); ++rm->epoch; --rm->inflight; } rm->cv.notify_all(); };
+            r->moved = [rm = room_] { { std::lock_guard<std::mutex> g(rm->mu); --rm->inflight; } rm->cv.notify_all(); };
             r->thread = std::thread([p = r.get()] { p->run(); });
         }
     }
@@ -104,6 +105,8 @@ class ReplicaRouter {
                 std::lock_guard<std::mutex> g(r.mu);
                 if (r.inflight >= r.capacity || r.stop || !r.healthy) continue;
                 req->replica = where.first;
+                // router-wide count first (drain() waits on it): the replica thread may complete the request the moment it is in the inbox
+                { std::lock_guard<std::mutex> gr(room_->mu); ++room_->inflight; }
                 r.inbox.push_back(req);
                 ++r.inflight;
             }
@@ -112,12 +115,13 @@ class ReplicaRouter {
         }
         return -1;
     }
-    // Block until every submitted request has completed.
+    // Block until every submitted request has completed — on WHATEVER replica it ends up: an ejected replica hands its unstarted requests
+    // to healthy ones (engine_failed -> reroute), possibly to a replica a per-replica walk has already found idle, so completion is
+    // counted router-wide: submit() adds one, complete() takes one off, and a re-routed request is submitted to its new replica BEFORE
+    // its old count is given back (the count never touches zero while the request lives).
     void drain() {
-        for (auto &r : reps_) {
-            std::unique_lock<std::mutex> g(r->mu);
-            r->idle_cv.wait(g, [&] { return r->inflight == 0; });
-        }
+        std::unique_lock<std::mutex> g(room_->mu);
+        room_->cv.wait(g, [&] { return room_->inflight == 0; });
     }
     // The `/embeddings` batch job over replicas (documents handed out request by request, results gathered on the host; no
     // collective): every document becomes a State-kind request routed like any other (least busy replica with room), `out` receives
@@ -182,6 +186,7 @@ class ReplicaRouter {
         int eject_after = 2;
         std::function<int(RoutedRequest *)> reroute;   // the router's submit(): where unstarted requests of an ejected replica go
         std::function<void()> freed;                   // tells the router that a request completed here (someone may be waiting for room)
+        std::function<void()> moved;                   // a request of this replica was re-routed: the router-wide count it held here is released
         std::atomic<uint64_t> steps{0};
         std::thread thread;
         Replica(Engine &e, size_t max_cached) : sched(e, max_cached), capacity(e.max_batch) {}
@@ -225,7 +230,6 @@ class ReplicaRouter {
                     engine_failed(owner, fresh, parked, "unknown exception in the replica thread");
                 }
                 if (!engine_ok) continue;
-                if (stepped) { std::lock_guard<std::mutex> g(mu); engine_failures = 0; }
                 // State-kind requests whose tokens have been read in: the rows leave (asynchronously where the engine can), one wait for
                 // all of them, then the slots are given up without caching and the requests are done
                 try {
@@ -250,6 +254,9 @@ class ReplicaRouter {
                     engine_failed(owner, fresh, parked, "unknown exception while reading embeddings back");
                     continue;
                 }
+                // the failure count is consecutive ITERATIONS that failed: reset only when the step AND the read-back went through (a replica
+                // whose steps succeed but whose embed / embed_sync throws every time must still reach `eject_after`)
+                if (stepped) { std::lock_guard<std::mutex> g(mu); engine_failures = 0; }
                 for (int b = 0; b < capacity; ++b) {
                     RoutedRequest *rq = owner[(size_t)b];
                     if (!rq || rq->embed_layer >= 0) continue;
@@ -305,8 +312,10 @@ class ReplicaRouter {
                 { std::lock_guard<std::mutex> g(mu); --inflight; }
                 rq->replica = -1;
                 if (!reroute || reroute(rq) < 0) {
-                    { std::lock_guard<std::mutex> g(mu); ++inflight; }             // complete() takes it off again
+                    { std::lock_guard<std::mutex> g(mu); ++inflight; }             // complete() takes it off again (and the router-wide count)
                     complete(rq, (std::string(what) + " (replica ejected; no healthy replica has room)").c_str());
+                } else if (moved) {
+                    moved();                                                       // placed elsewhere (counted there): give this replica's router-wide count back
                 }
             }
             idle_cv.notify_all();
@@ -324,7 +333,7 @@ class ReplicaRouter {
         static bool active(const std::vector<RoutedRequest *> &o) { for (auto *p : o) if (p) return true; return false; }
     };
     std::vector<std::unique_ptr<Replica>> reps_;
-    struct Room { std::mutex mu; std::condition_variable cv; uint64_t epoch = 0; };   // epoch advances whenever a request completes on any replica
+    struct Room { std::mutex mu; std::condition_variable cv; uint64_t epoch = 0; long inflight = 0; };   // epoch advances whenever a request completes on any replica; inflight: submitted, not completed, router-wide
     std::shared_ptr<Room> room_ = std::make_shared<Room>();                           // shared with the replicas' `freed` callbacks
 };
 

@@ -290,6 +290,11 @@ class Scheduler {
         // run.rs:794-803: prompts longer than MIN_PROMPT_CACHE_TOKENS that are not cached yet get a cache entry as soon as
         // they have been read in (so a second request with the same long prompt skips its prefill even while this one decodes)
         r.cache_prompt = tokens.size() > kMinPromptCacheTokens && !cached_whole;
+        // A state-only request (RnnOption::None, the `/embeddings` job) never receives an output row from the engine: the row copied
+        // from the cache above belongs to the SHORTER cached prefix, and caching the whole document under it would hand a later
+        // completion with the same prompt the wrong logits (and cost a full slab read-back per document).  The reference runs State
+        // requests with `Last`, so its cache entries always carry their own row; here such requests neither carry nor create one.
+        if (option == RnnOption::None) { r.output.clear(); r.cache_prompt = false; }
         reqs_[batch] = std::move(r);
         const bool back = best.kind == SlotChoice::Back;
         slots_[batch].kind = SlotKind::Busy;

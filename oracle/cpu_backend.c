@@ -52,7 +52,18 @@ static void master_leave(void);
 /* Called by EVERY thread of the step's team (orphaned worksharing loop, implicit barrier at its end): one persistent team per step
  * instead of a fork per GEMM.  The static schedule over rows is the one rwkv_cpu_place used to first-touch W, so a thread reads the
  * rows that live on its own NUMA node. */
-static void gemm_f16(const uint16_t *W, long rows, long K, const float *X, long ldx, float *Y, long ldy, int B) {
+/* Error-attribution switch (scripts/fp16_error_attribution.py; off = 0 in every parity test and in the bench): bit `cls` set ->
+ * the X operand of the GEMMs of that class is rounded to fp16 on the way in, which is what `Precision::Fp16` does on the GPU
+ * (reload.rs:89-94: f16 operands, fp32 accumulate).  Lets the CPU say WHICH operand class carries a model's Fp16 error. */
+enum { CLS_ATT = 0, CLS_LORA1 = 1, CLS_LORA2 = 2, CLS_WO = 3, CLS_FFN1 = 4, CLS_FV = 5, CLS_MIX1 = 6, CLS_MIX2 = 7, CLS_DECAY2 = 8, CLS_HEAD = 9 };
+static int g_f16_mask = 0;
+void rwkv_cpu_set_operand_rounding(int mask) { g_f16_mask = mask; }
+static inline __m256 round_f16(__m256 x) {
+    x = _mm256_min_ps(_mm256_max_ps(x, _mm256_set1_ps(-65504.0f)), _mm256_set1_ps(65504.0f));
+    return _mm256_cvtph_ps(_mm256_cvtps_ph(x, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+}
+static void gemm_f16(const uint16_t *W, long rows, long K, const float *X, long ldx, float *Y, long ldy, int B, int cls) {
+    const int rnd = (g_f16_mask >> cls) & 1;
 #pragma omp for schedule(static)
     for (long r = 0; r < rows; ++r) {
         const uint16_t *w = W + r * K;
@@ -62,7 +73,8 @@ static void gemm_f16(const uint16_t *W, long rows, long K, const float *X, long 
             for (int i = 0; i < 8; ++i) acc[i] = _mm256_setzero_ps();
             for (long k = 0; k < K; k += 8) {
                 const __m256 wv = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(w + k)));
-                for (int i = 0; i < nb; ++i) acc[i] = _mm256_fmadd_ps(wv, _mm256_loadu_ps(X + (long)(b0 + i) * ldx + k), acc[i]);
+                if (rnd) for (int i = 0; i < nb; ++i) acc[i] = _mm256_fmadd_ps(wv, round_f16(_mm256_loadu_ps(X + (long)(b0 + i) * ldx + k)), acc[i]);
+                else for (int i = 0; i < nb; ++i) acc[i] = _mm256_fmadd_ps(wv, _mm256_loadu_ps(X + (long)(b0 + i) * ldx + k), acc[i]);
             }
             for (int i = 0; i < nb; ++i) {
                 __m128 s = _mm_add_ps(_mm256_castps256_ps128(acc[i]), _mm256_extractf128_ps(acc[i], 1));
@@ -140,24 +152,24 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
                     xr[i] = xx[i] + d * p->mix_r[c]; xw[i] = xx[i] + d * p->mix_w[c]; xk[i] = xx[i] + d * p->mix_k[c];
                     xv[i] = xx[i] + d * p->mix_v[c]; xa[i] = xx[i] + d * p->mix_a[c]; xg[i] = xx[i] + d * p->mix_g[c];
                 }
-            gemm_f16(p->Wr, C, C, xr, C, r, C, B);
-            gemm_f16(p->Wk, C, C, xk, C, k, C, B);
-            gemm_f16(p->Wv, C, C, xv, C, v, C, B);
+            gemm_f16(p->Wr, C, C, xr, C, r, C, B, CLS_ATT);
+            gemm_f16(p->Wk, C, C, xk, C, k, C, B, CLS_ATT);
+            gemm_f16(p->Wv, C, C, xv, C, v, C, B, CLS_ATT);
             float *wdec = hid2;
-            gemm_f16(p->w1, p->Dw, C, xw, C, lora, p->Dw, B);
+            gemm_f16(p->w1, p->Dw, C, xw, C, lora, p->Dw, B, CLS_LORA1);
 #pragma omp for
             for (long i = 0; i < (long)B * p->Dw; ++i) lora[i] = tanhf(lora[i]);
-            gemm_f16(p->w2, C, p->Dw, lora, p->Dw, wdec, C, B);
-            gemm_f16(p->a1, p->Da, C, xa, C, lora, p->Da, B);
-            gemm_f16(p->a2, C, p->Da, lora, p->Da, aa, C, B);
-            gemm_f16(p->g1, p->Dg, C, xg, C, lora, p->Dg, B);
+            gemm_f16(p->w2, C, p->Dw, lora, p->Dw, wdec, C, B, CLS_LORA2);
+            gemm_f16(p->a1, p->Da, C, xa, C, lora, p->Da, B, CLS_LORA1);
+            gemm_f16(p->a2, C, p->Da, lora, p->Da, aa, C, B, CLS_LORA2);
+            gemm_f16(p->g1, p->Dg, C, xg, C, lora, p->Dg, B, CLS_LORA1);
 #pragma omp for
             for (long i = 0; i < (long)B * p->Dg; ++i) lora[i] = sigmoidf(lora[i]);
-            gemm_f16(p->g2, C, p->Dg, lora, p->Dg, g, C, B);
+            gemm_f16(p->g2, C, p->Dg, lora, p->Dg, g, C, B, CLS_LORA2);
             float *vgate = hid;                                      /* [B][C] */
             if (l > 0) {
-                gemm_f16(p->v1, p->Dv, C, xv, C, lora, p->Dv, B);
-                gemm_f16(p->v2, C, p->Dv, lora, p->Dv, vgate, C, B);
+                gemm_f16(p->v1, p->Dv, C, xv, C, lora, p->Dv, B, CLS_LORA1);
+                gemm_f16(p->v2, C, p->Dv, lora, p->Dv, vgate, C, B, CLS_LORA2);
             }
             float *out = t0;
 #pragma omp for collapse(2)
@@ -208,7 +220,7 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
                         out[o + j] = ((oo[j] - mean) * inv * p->lnxw[c] + p->lnxb[c] + dot * vh[j]) * g[o + j];
                     }
                 }
-            gemm_f16(p->Wo, C, C, out, C, t1, C, B);
+            gemm_f16(p->Wo, C, C, out, C, t1, C, B, CLS_WO);
         } else {
         if (m->version == 5) {
 #pragma omp for
@@ -228,13 +240,13 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
                     const long i = (long)b * C + c;
                     hid[i] = xx[i] + (sx[i] - xx[i]) * p->mix_x[c];
                 }
-            gemm_f16(p->mix_w1, 5L * Dm, C, hid, C, mm, 5L * Dm, B);
+            gemm_f16(p->mix_w1, 5L * Dm, C, hid, C, mm, 5L * Dm, B, CLS_MIX1);
 #pragma omp for
             for (long i = 0; i < (long)B * 5 * Dm; ++i) mm[i] = tanhf(mm[i]);
             float *dst[5] = {xw, xk, xv, xr, xg};
             const float *mu[5] = {p->mix_w, p->mix_k, p->mix_v, p->mix_r, p->mix_g};
             for (int c5 = 0; c5 < 5; ++c5) {
-                gemm_f16(p->mix_w2 + (long)c5 * C * Dm, C, Dm, mm + (long)c5 * Dm, 5L * Dm, hid, C, B);
+                gemm_f16(p->mix_w2 + (long)c5 * C * Dm, C, Dm, mm + (long)c5 * Dm, 5L * Dm, hid, C, B, CLS_MIX2);
 #pragma omp for
                 for (int b = 0; b < B; ++b)
                     for (int c = 0; c < C; ++c) {
@@ -243,20 +255,20 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
                     }
             }
         }
-        gemm_f16(p->Wr, C, C, xr, C, r, C, B);
-        gemm_f16(p->Wk, C, C, xk, C, k, C, B);
-        gemm_f16(p->Wv, C, C, xv, C, v, C, B);
-        gemm_f16(p->Wg, C, C, xg, C, g, C, B);
+        gemm_f16(p->Wr, C, C, xr, C, r, C, B, CLS_ATT);
+        gemm_f16(p->Wk, C, C, xk, C, k, C, B, CLS_ATT);
+        gemm_f16(p->Wv, C, C, xv, C, v, C, B, CLS_ATT);
+        gemm_f16(p->Wg, C, C, xg, C, g, C, B, CLS_ATT);
         float *wdec = hid2;                                         /* [B][C] */
         if (m->version == 5) {
 #pragma omp for
             for (int b = 0; b < B; ++b)
                 for (int c = 0; c < C; ++c) wdec[(long)b * C + c] = expf(-expf(p->decay[c]));
         } else {
-            gemm_f16(p->decay_w1, Dd, C, xw, C, td, Dd, B);
+            gemm_f16(p->decay_w1, Dd, C, xw, C, td, Dd, B, CLS_ATT);
 #pragma omp for
             for (long i = 0; i < (long)B * Dd; ++i) td[i] = tanhf(td[i]);
-            gemm_f16(p->decay_w2, C, Dd, td, Dd, wdec, C, B);
+            gemm_f16(p->decay_w2, C, Dd, td, Dd, wdec, C, B, CLS_DECAY2);
 #pragma omp for
             for (int b = 0; b < B; ++b)
                 for (int c = 0; c < C; ++c) wdec[(long)b * C + c] = expf(-expf(p->decay[c] + wdec[(long)b * C + c]));
@@ -293,7 +305,7 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
                     out[(long)b * C + c] = ((o[j] - mean) * inv * p->lnxw[c] + p->lnxb[c]) * (gg * sigmoidf(gg));
                 }
             }
-        gemm_f16(p->Wo, C, C, out, C, t1, C, B);
+        gemm_f16(p->Wo, C, C, out, C, t1, C, B, CLS_WO);
         }
         /* ---- channel mix */
 #pragma omp for
@@ -317,16 +329,16 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
                 }
             }
         }
-        gemm_f16(p->Fk, F, C, t2, C, hid, F, B);
+        gemm_f16(p->Fk, F, C, t2, C, hid, F, B, CLS_FFN1);
 #pragma omp for schedule(static)
         for (long i = 0; i < (long)B * F; ++i) { const float a = hid[i] > 0.f ? hid[i] : 0.f; hid[i] = a * a; }
-        gemm_f16(p->Fv, C, F, hid, F, t4, C, B);
+        gemm_f16(p->Fv, C, F, hid, F, t4, C, B, CLS_FV);
         if (m->version == 7) {
 #pragma omp for
             for (int b = 0; b < B; ++b)
                 for (int c = 0; c < C; ++c) x[(long)b * C + c] += t4[(long)b * C + c];
         } else {
-            gemm_f16(p->Fr, C, C, t3, C, r, C, B);
+            gemm_f16(p->Fr, C, C, t3, C, r, C, B, CLS_FFN1);
 #pragma omp for
             for (int b = 0; b < B; ++b)
                 for (int c = 0; c < C; ++c) x[(long)b * C + c] += sigmoidf(r[(long)b * C + c]) * t4[(long)b * C + c];
@@ -335,7 +347,7 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
     if (logits) {
 #pragma omp for
         for (int b = 0; b < B; ++b) layernorm(x + (long)b * C, m->lnow, m->lnob, xx + (long)b * C, C, LN_EPS);
-        gemm_f16(m->head, m->V, C, xx, C, logits, m->V, B);
+        gemm_f16(m->head, m->V, C, xx, C, logits, m->V, B, CLS_HEAD);
     }
     }   /* omp parallel */
     master_leave();

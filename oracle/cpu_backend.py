@@ -200,6 +200,14 @@ class CpuBackend:
         """Weight bytes one step streams (every matrix once, the embedding row excluded) x steps/s: what the host's DRAM delivered."""
         return self.weight_bytes * steps_per_s / 1e9
 
+    OPERAND_CLASSES = ("att", "lora1", "lora2", "wo", "ffn1", "fv", "mix1", "mix2", "decay2", "head")
+
+    def set_operand_rounding(self, mask: int) -> None:
+        """Error attribution only (scripts/fp16_error_attribution.py): bit i set -> the GEMM operands of OPERAND_CLASSES[i] are rounded to
+        fp16 on the way in, as `Precision::Fp16` does on the GPU.  0 (the default) is the oracle every parity test uses."""
+        self.lib.rwkv_cpu_set_operand_rounding.argtypes = [C.c_int]
+        self.lib.rwkv_cpu_set_operand_rounding(int(mask))
+
     def init_states(self, B: int) -> np.ndarray:
         i = self.info
         return np.zeros((B, i.num_layer, i.head_size + 2, i.num_emb), dtype=np.float32)

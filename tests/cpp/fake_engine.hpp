@@ -15,7 +15,12 @@ struct FakeState {
     std::vector<float> back(int b) { return slots.at((size_t)b); }
     // one "layer" of the state: (hash + layer, count)
     size_t layer_len() const { return 2; }
-    void embed(int layer, int b, float *dst) { dst[0] = slots.at((size_t)b)[0] + (float)layer; dst[1] = slots.at((size_t)b)[1]; }
+    bool embed_fails = false;                     // the read-back throws (steps keep succeeding): a replica that is broken only on this path
+    void embed(int layer, int b, float *dst) {
+        if (embed_fails) throw std::runtime_error("fake read-back failure");
+        dst[0] = slots.at((size_t)b)[0] + (float)layer;
+        dst[1] = slots.at((size_t)b)[1];
+    }
 };
 // state = (hash, count); a token updates hash = fmod(hash * 31 + tok + 1, 65521); logits[i] = fmod(hash + 7 i, 13)
 struct FakeEngine {

@@ -259,6 +259,61 @@ int main() {
             CHECK(threw);
         }
     }
+    // --- drain() is router-wide (advisor, round 4): a request re-routed off an ejected replica may land on a replica a per-replica walk
+    //     has already seen idle.  Replica 1 is blocked inside its step with b in a slot and c still in its inbox; it then fails for good
+    //     (ejected at once): b fails, c moves to replica 0, whose engine is held.  drain() must not return before c has completed there.
+    {
+        FakeEngine e0(3, 100), e1(2, 100);
+        std::vector<FakeEngine *> es{&e0, &e1};
+        ReplicaRouter<FakeEngine> router(es, 256, 1);
+        // every CHECK of this block runs with the holds released again: a failed CHECK must fail the test, not hang its threads
+        RoutedRequest warm1, warm2, b, c;
+        warm1.tokens = {9}; warm2.tokens = {8}; b.tokens = {3, 4}; b.max_new = 3; c.tokens = {5, 6}; c.max_new = 3;
+        e0.hold = true; e1.hold = true;
+        const int w1 = router.submit(&warm1);                                // replica 0 (least busy, lowest index)
+        const int pb = router.submit(&b);                                    // replica 1 (0 in flight against 1)
+        const int w2 = router.submit(&warm2);                                // tie 1 : 1 -> replica 0
+        std::this_thread::sleep_for(std::chrono::milliseconds(30));         // replica 1's thread now sits inside infer() with b in a slot
+        const int pc = router.submit(&c);                                    // 2 : 1 -> replica 1, where it stays in the inbox
+        e0.hold = false;                                                     // replica 0 finishes its two requests and is IDLE when drain() looks at it
+        for (int i = 0; i < 200 && router.busy(0) > 0; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        const bool idle0 = router.busy(0) == 0;
+        e0.hold = true;                                                      // whatever arrives there from now on stays in flight until released
+        std::thread later([&] {
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));     // drain() is by now waiting on replica 1
+            e1.fail_from = 1;
+            e1.hold = false;                                                 // the step throws: replica 1 is ejected at once, c is re-routed to replica 0 (held)
+            std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            e0.hold = false;
+        });
+        router.drain();
+        const bool c_done_at_drain = c.done, w_done_at_drain = warm1.done && warm2.done;
+        later.join();
+        router.drain();
+        CHECK(idle0);
+        CHECK(w1 == 0 && pb == 1 && w2 == 0 && pc == 1);
+        CHECK(b.done && b.failed && !router.healthy(1));
+        CHECK(c_done_at_drain && w_done_at_drain);                           // drain() returned only after the re-routed request had completed
+        CHECK(c.done && !c.failed && c.replica == 0 && c.generated == greedy_alone(c.tokens, 3));
+    }
+    // --- a replica whose STEPS succeed but whose embedding read-back throws every time is ejected too (the failure count is reset only by
+    //     an iteration that went through completely), and the job finishes on the healthy replica
+    {
+        FakeEngine good(2, 8), flaky(2, 8);
+        flaky.state.embed_fails = true;
+        std::vector<FakeEngine *> es{&good, &flaky};
+        ReplicaRouter<FakeEngine> router(es, 256, 2);
+        std::vector<Tokens> docs;
+        for (uint32_t d = 0; d < 12; ++d) docs.push_back(Tokens{d % 7 + 1, (d * 3) % 5 + 1, 2});
+        std::vector<float> out(docs.size() * 2, -1.f);
+        router.embed_documents(docs, 1, out.data(), 2, 6);
+        CHECK(!router.healthy(1) && router.healthy(0));
+        for (size_t d = 0; d < docs.size(); ++d) {
+            float h = 1.0f, n = 0.0f;
+            for (uint32_t tok : docs[d]) { h = std::fmod(h * 31.0f + (float)tok + 1.0f, 65521.0f); n += 1.0f; }
+            CHECK(out[2 * d] == h + 1.0f && out[2 * d + 1] == n);
+        }
+    }
     std::printf("router_test: ok\n");
     return 0;
 }

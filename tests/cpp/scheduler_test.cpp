@@ -302,6 +302,35 @@ int main() {
         try { s.embed_documents(docs, 0, out.data()); } catch (const std::runtime_error &) { threw = true; }
         CHECK(threw);
     }
+    // --- a state-only job must not poison the prefix cache (advisor, round 4): a chat request caches its long prompt P; the embeddings
+    //     job then runs P + X (a cache hit on P, whose logits ride along in `output`).  The document must NOT be cached under P's row:
+    //     a later completion of P + X has to go through the engine and get its own logits.
+    {
+        FakeEngine e(2, 64);
+        Scheduler<FakeEngine> s(e);
+        Tokens P;
+        for (uint32_t i = 0; i < 40; ++i) P.push_back(i % 7 + 1);             // > MIN_PROMPT_CACHE_TOKENS
+        int b = -1;
+        CHECK(s.queue(P, b) == SlotResult::Success);
+        while (s.pending()) s.step();
+        s.finish(b);
+        const size_t cached = s.cache().size();
+        CHECK(cached >= 1 && s.cache().contains(P));
+        Tokens PX = P;
+        for (uint32_t i = 0; i < 5; ++i) PX.push_back(i + 1);
+        std::vector<float> out(2, -1.f);
+        s.embed_documents({PX}, 0, out.data());
+        CHECK(s.cache().size() == cached && !s.cache().contains(PX));
+        int c = -1;
+        const int calls = e.calls.load();
+        CHECK(s.queue(PX, c) != SlotResult::Failure);
+        while (s.pending()) s.step();
+        CHECK(e.calls.load() > calls);                                       // the suffix X went through the engine
+        float h = 1.0f;
+        for (uint32_t tok : PX) h = std::fmod(h * 31.0f + (float)tok + 1.0f, 65521.0f);
+        CHECK(!s.request(c).output.empty() && s.request(c).output[0] == std::fmod(h, 13.0f));   // its own logits, not P's
+        s.finish(c);
+    }
     std::printf("scheduler_test: ok\n");
     return 0;
 }
