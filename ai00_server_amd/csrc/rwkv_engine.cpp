@@ -233,6 +233,12 @@ struct rwkv_engine {
     int device = 0;
     int max_batch = 8, chunk = 128;
     bool hilo = false;
+    // Operand promotion (Knobs::promote, RWKV_PROMOTE): in Precision::Fp16 the GEMM launches of the classes whose bit is set read hi + lo f16
+    // operands like Precision::Fp32 does everywhere — the price of exactness is paid only where a model's error comes from
+    // (profiles/r5_fp16_error_attribution_*.jsonl: V7's Wr / Wk / Wv inputs carry 4.7e-3 of its 4.9e-3 at 32 layers).
+    enum OpdClass { CLS_ATT = 0, CLS_LORA2 = 1, CLS_WO = 2, CLS_FFN1 = 3, CLS_FV = 4, CLS_HEAD = 5, CLS_NONE = 31 };
+    int promote = 0;
+    bool wide(int cls) const { return hilo || (cls < 31 && ((promote >> cls) & 1)); }
     int quant_layers = 0, quant_type = 0;
     hipStream_t s_main = nullptr, s_soft = nullptr;
     FILE *launch_log = nullptr;                                // RWKV_LAUNCH_LOG=<path> (dev): one JSON line per GEMM launch of layer 0 / the head
@@ -315,7 +321,7 @@ struct rwkv_engine {
         o.ld = ld;
         const size_t cap = (size_t)((chunk + 15) / 16 * 16) * ld;      // whole (16 token x 32 k) tiles
         o.hi = dalloc<_Float16>(cap);
-        o.lo = hilo ? dalloc<_Float16>(cap) : nullptr;
+        o.lo = (hilo || promote) ? dalloc<_Float16>(cap) : nullptr;
         HIP_CHECK(hipMemset(o.hi, 0, cap * 2));                        // lanes of a partly filled token tile are read (never used)
         if (o.lo) HIP_CHECK(hipMemset(o.lo, 0, cap * 2));
         return o;
@@ -336,6 +342,7 @@ struct rwkv_engine {
         if (h_tok) (void)hipHostFree(h_tok);
         if (h_samp) (void)hipHostFree(h_samp);
         if (h_allow) (void)hipHostFree(h_allow);
+        if (h_err) (void)hipHostFree(h_err);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (s_main) (void)hipStreamDestroy(s_main);
@@ -382,10 +389,18 @@ struct rwkv_engine {
         prof_fam.clear();
     }
 
+    // after a step has drained: did an in-launch hand-off (RowJob) run out of its bounded wait?  The step's results are then invalid.
+    void sync_main() {
+        HIP_CHECK(hipStreamSynchronize(s_main));
+        if (h_err && *h_err) { *h_err = 0; throw RwkvError(RWKV_ERR_DEVICE, "an in-launch hand-off of the step timed out (row job): results discarded"); }
+    }
     void load(const rwkv_load_desc &d);
-    int gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs *lnp = nullptr, const ShiftCommit *commit = nullptr);
+    int gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs *lnp = nullptr, const ShiftCommit *commit = nullptr, int cls = CLS_NONE);
+    // the row job of dense decode steps (RowJob, rwkv_kernels.h): `r`'s row work inside the launch of `ps`; false = not eligible (nothing launched)
+    bool gemm_with_rows(std::vector<ProbSpec> &ps, int T, int fam, const LnShiftArgs &r, int slot, int cls);
+    unsigned *d_sync = nullptr, *d_epoch = nullptr, *h_err = nullptr, *dv_err = nullptr;   // hand-off words: [layer][att | ffn] x (counter + 8 XCD flags), 128-byte lines
     void log_gemm(const std::vector<ProbSpec> &ps, int T, int fam, const char *kind, int variant, int grid, int ksplit);
-    bool ln_fusable(std::vector<ProbSpec> &ps, int T, int np);
+    bool ln_fusable(std::vector<ProbSpec> &ps, int T, int np, int cls = CLS_NONE);
     float *lnp_xx_att = nullptr, *lnp_xx_ffn = nullptr;   // normalised rows published by an LN-prologue launch (for the commit)
     void plan_step(const rwkv_slot_input *in, StepPlan &pl);
     void upload_plan(const StepPlan &pl);
@@ -486,6 +501,7 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
     kn = Knobs::from_env();                                  // frozen for the engine's lifetime (and for every graph it captures)
     use_knobs(kn);
     hilo = d.precision == RWKV_PRECISION_FP32;
+    promote = hilo ? 0 : (kn.promote & 63);
     quant_layers = std::max(0, std::min(d.quant_layers, L));
     quant_type = d.quant_type;
     if (pf) {                                                // a prefab is already quantised / blended: its settings win
@@ -798,6 +814,13 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
     d_allow = dalloc<unsigned char>((size_t)max_batch * V); d_allow_row = dalloc<int>(max_batch);
     HIP_CHECK(hipHostMalloc((void **)&h_allow, (size_t)max_batch * V + (size_t)max_batch * 4 + 16, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **)&h_samp, (size_t)chunk * (sizeof(SampleRow) + 8) + ADJ_CAP * 12, hipHostMallocDefault));
+    d_sync = dalloc<unsigned>((size_t)L * 2 * 9 * 32);
+    d_epoch = dalloc<unsigned>(32);
+    HIP_CHECK(hipMemset(d_sync, 0, (size_t)L * 2 * 9 * 32 * 4));
+    HIP_CHECK(hipMemset(d_epoch, 0, 32 * 4));
+    HIP_CHECK(hipHostMalloc((void **)&h_err, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *h_err = 0;
+    HIP_CHECK(hipHostGetDevicePointer((void **)&dv_err, h_err, 0));
     d_amax_v = dalloc<float>((size_t)chunk * 32);
     d_amax_i = dalloc<int>((size_t)chunk * 32);
     HIP_CHECK(hipDeviceSynchronize());
@@ -810,7 +833,7 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
 // Decomposition of one launch (DESIGN.md "GEMM planning"): every wave owns KW = KSW*32 k of the block's K range;
 // linear ("partial") problems may split K across `ksb` blocks (the consumer row kernel sums the partials);
 // a block walks `spb` strips.  Aim: >= ~1.5 blocks per CU in flight, whole matrix in flight at once.
-static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo, long pstride, int force_spb = 0) {
+static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo, long pstride, int force_spb = 0, bool want_shot = false) {
     if (ps.empty() || ps.size() > GEMM_MAXP) throw RwkvError(RWKV_ERR_INVALID, "gemm: bad problem count");
     Lh = GemmLaunch{};
     Lh.nprob = (int)ps.size();
@@ -846,7 +869,7 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
         }
         const int Kb = K / ksb;
         const int nslice = (Kb + KW - 1) / KW;                 // balanced: every wave owns the same number of slices
-        const int maxw = gemm_variant_max_waves(NT, KSW), per_wave = (nslice + maxw - 1) / maxw;
+        const int maxw = gemm_variant_max_waves(NT, KSW, hilo), per_wave = (nslice + maxw - 1) / maxw;
         const int nw = (nslice + per_wave - 1) / per_wave;
         // strips per block: the whole grid should be resident at once (~164 VGPRs -> 12 waves per CU), and a wave's
         // rounds should fit in registers so that every load is issued up-front (single shot); the head matrix is too
@@ -886,7 +909,7 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
     {
         bool all_quant = true;
         for (auto &sp : ps) all_quant = all_quant && (sp.W->fmt != W_F16 || sp.W->rows <= 256);   // (the decay LoRA's 64 fp16 rows ride along)
-        if (NT == 2 && all_quant && !hilo) shot = false;
+        if (NT == 2 && all_quant && !hilo && !want_shot) shot = false;
     }
     Lh.single_shot = shot ? 1 : 0;
     Lh.tail = tail ? 1 : 0;
@@ -896,9 +919,9 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
 // Can this launch carry the LayerNorm + token-shift prologue (rwkv_kernels.h LnProArgs)?  Single-token steps in
 // Fp16 mode whose every problem walks K = C with one slice per wave and the same wave count (the prologue is a
 // block-wide cooperative pass), with room in LDS for the rows.
-bool rwkv_engine::ln_fusable(std::vector<ProbSpec> &ps, int T, int np) {
+bool rwkv_engine::ln_fusable(std::vector<ProbSpec> &ps, int T, int np, int cls) {
     const int off = kn.no_ln_fuse;
-    if (off || hilo || T > LNP_MAX_T || np > LNP_MAX_NP) return false;
+    if (off || wide(cls) || T > LNP_MAX_T || np > LNP_MAX_NP) return false;
     int NT, KSW;
     gemm_variant(T, hilo, NT, KSW);
     if (NT != 1 || KSW != 16) return false;
@@ -914,8 +937,10 @@ bool rwkv_engine::ln_fusable(std::vector<ProbSpec> &ps, int T, int np) {
     return (size_t)Lh.lds_items * NT * 1024 + lnp_lds_bytes(T, C, hilo) <= 150 * 1024;
 }
 
-int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs *lnp, const ShiftCommit *commit) {
+int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs *lnp, const ShiftCommit *commit, int cls) {
     GemmLaunch Lh;
+    const bool hilo = wide(cls);                                 // shadows the engine-wide flag: this launch's operand width
+    if (hilo && !lnp) for (auto &sp : ps) if (!sp.x.lo) throw RwkvError(RWKV_ERR_INVALID, "gemm: a hi + lo launch needs the lo part of every operand");
     const int no_tile = kn.no_tile;
     if (T >= GEMM_TILE_MIN_T && !no_tile) {
         // prefill: LDS-tiled MFMA GEMM, no K split (partial problems write one slab)
@@ -1040,6 +1065,30 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
     log_gemm(ps, T, fam, "decode", Lh.single_shot, Lh.total_blocks + (Lh.commit.src ? 1 : 0), np);
     launch(fam, [&] { launch_gemm(Lh, hilo, s_main); });
     return np;
+}
+
+// A dense decode step's row work (LayerNorm + token shift + operand emit of `r`) inside the launch that consumes it.  Eligible: the
+// switch is on, f16 operands, 1..32 rows, every problem single shot with one K slice per wave and whole rounds, as many workgroups as
+// rows, the whole grid resident at once (one workgroup per CU), C <= 4 * threads, partial slabs within the row job's register budget.
+bool rwkv_engine::gemm_with_rows(std::vector<ProbSpec> &ps, int T, int fam, const LnShiftArgs &r, int slot, int cls) {
+    if (!kn.rowjob || wide(cls) || !r.rm.dense || T < 1 || T > 32 || r.np > LNP_MAX_NP || r.nmix > 6 || r.xcd_rows) return false;
+    GemmLaunch Lh;
+    const int np = plan_gemm(Lh, ps, T, false, pstride, 0, true);
+    (void)np;
+    int NT, KSW;
+    gemm_variant(T, false, NT, KSW);
+    if (KSW != 8 || NT > 2 || !Lh.single_shot || Lh.tail || Lh.total_blocks < T || Lh.total_blocks > 248 || r.C > 4 * Lh.threads || r.C % 4) return false;
+    for (int i = 0; i < Lh.nprob; ++i) if (Lh.p[i].ksb != 1 || Lh.p[i].nslice > Lh.p[i].nw) return false;
+    RowJob &j = Lh.rowjob;
+    j.T = T; j.x_in = r.x_in; j.x_out = r.x_out; j.P = r.P; j.np = r.np; j.pstride = r.pstride;
+    j.lnw = r.lnw; j.lnb = r.lnb; j.sx = r.sx; j.sx_slot_stride = r.sx_slot_stride;
+    j.mode = r.mode; j.nmix = r.nmix;
+    for (int m = 0; m < 6; ++m) { j.mu[m] = r.mu[m]; j.ohi[m] = r.ohi[m]; }
+    j.ldh = r.ldh; j.xx_out = r.xx_out; j.dx_out = r.dx_out; j.C = r.C;
+    j.sync = d_sync + (size_t)slot * 9 * 32; j.epoch = d_epoch; j.err = dv_err;
+    log_gemm(ps, T, fam, "decode+rows", 1, Lh.total_blocks, 1);
+    launch(fam, [&] { launch_gemm(Lh, false, s_main); });
+    return true;
 }
 
 // RWKV_LAUNCH_LOG (dev): what a launch of layer 0 (or the head) streams and computes, so that a profile can be priced without guessing which
@@ -1177,7 +1226,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
     float *cur = xA, *oth = xB;
     int np = 0;
     {
-        EmbedArgs e{emb, ln0w, ln0b, d_token, cur, C, V};
+        EmbedArgs e{emb, ln0w, ln0b, d_token, cur, C, V, d_epoch};
         launch(FAM_ROW, [&] { launch_embed(e, T, s_main); });
     }
     for (int l = 0; l < L; ++l) {
@@ -1193,6 +1242,12 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
         auto prob = [&](const DMat *W, const Opd &x, int act, float *out, int ldo) {
             ProbSpec s; s.W = W; s.x = x; s.act = act; s.out = out; s.ldo = ldo; return s;
         };
+        // an operand as ITS CONSUMER's class sees it: the lo part exists only for launches that read hi + lo (Precision::Fp32, or promoted)
+        auto as = [&](const Opd &o, int cls) { Opd r = o; if (!wide(cls)) r.lo = nullptr; return r; };
+        const Opd aA[6] = {as(opA[0], CLS_ATT), as(opA[1], CLS_ATT), as(opA[2], CLS_ATT), as(opA[3], CLS_ATT), as(opA[4], CLS_ATT), as(opA[5], CLS_ATT)};
+        const Opd aL[4] = {as(opL[0], CLS_LORA2), as(opL[1], CLS_LORA2), as(opL[2], CLS_LORA2), as(opL[3], CLS_LORA2)};
+        const Opd aF[2] = {as(opA[0], CLS_FFN1), as(opA[1], CLS_FFN1)};
+        const Opd aY = as(opY, CLS_WO), aK = as(opK, CLS_FV), aZ = as(opA[0], CLS_NONE), aM = as(opM, CLS_NONE);
         // single-token steps: the LayerNorm + token shift rides as a prologue of the GEMM that consumes it, and the launch
         // after that commits the shift state (LnProArgs / ShiftCommit in rwkv_kernels.h)
         auto ln_pro = [&](const LnShiftArgs &r, float *xx_pub) {
@@ -1210,19 +1265,21 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
         bool att_fused = false;                                    // a commit of the time-mix shift state is pending
         if (info.version == 5) {
             a.mode = 0; a.nmix = 4;
-            for (int i = 0; i < 4; ++i) { a.mu[i] = w.mu[i]; a.ohi[i] = opA[i].hi; a.olo[i] = opA[i].lo; }
-            ps = {prob(w.Wk, opA[0], ACT_NONE, fk, C), prob(w.Wv, opA[1], ACT_NONE, fv, C),
-                  prob(w.Wr, opA[2], ACT_NONE, fr, C), prob(w.Wg, opA[3], ACT_SILU, fg, C)};
+            for (int i = 0; i < 4; ++i) { a.mu[i] = w.mu[i]; a.ohi[i] = aA[i].hi; a.olo[i] = aA[i].lo; }
+            ps = {prob(w.Wk, aA[0], ACT_NONE, fk, C), prob(w.Wv, aA[1], ACT_NONE, fv, C),
+                  prob(w.Wr, aA[2], ACT_NONE, fr, C), prob(w.Wg, aA[3], ACT_SILU, fg, C)};
             for (int i = 0; i < 4; ++i) ps[i].lnp_mu = w.mu[i];
-            if ((att_fused = ln_fusable(ps, T, np))) {
+            if ((att_fused = ln_fusable(ps, T, np, CLS_ATT))) {
                 LnProArgs lp = ln_pro(a, lnp_xx_att);
-                gemm(ps, T, FAM_GEMM, &lp);
+                gemm(ps, T, FAM_GEMM, &lp, nullptr, CLS_ATT);
+            } else if (gemm_with_rows(ps, T, FAM_GEMM, a, l * 2, CLS_ATT)) {
+                // the rows of this step rode in the launch
             } else {
                 launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
-                gemm(ps, T, FAM_GEMM);
+                gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_ATT);
             }
         } else if (info.version == 6) {
-            a.mode = 1; a.nmix = 1; a.mu[0] = w.mu[0]; a.ohi[0] = opA[0].hi; a.olo[0] = opA[0].lo;
+            a.mode = 1; a.nmix = 1; a.mu[0] = w.mu[0]; a.ohi[0] = aZ.hi; a.olo[0] = aZ.lo;
             a.xx_out = xx; a.dx_out = dx;
             const int no_fuse = kn.no_v6_fuse, no_ln_fuse = kn.no_ln_fuse;
             att_fused = !no_fuse && !no_ln_fuse && v6_mix_ln_supported(T, C, Dm, hilo, np);
@@ -1232,58 +1289,60 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
                 // fused: x_c = xx + dx * (mu_c + W2_c tanh(W1_c z)) in one launch
                 V6MixArgs m{};
                 m.W1 = w.W1->data;
-                for (int c = 0; c < 5; ++c) { m.W2[c] = w.W2[c]->data; m.mu[c] = w.mu[1 + c]; m.ohi[c] = opA[1 + c].hi; m.olo[c] = opA[1 + c].lo; }
-                m.zhi = opA[0].hi; m.zlo = opA[0].lo; m.ldz = C;
+                for (int c = 0; c < 5; ++c) { m.W2[c] = w.W2[c]->data; m.mu[c] = w.mu[1 + c]; m.ohi[c] = aA[1 + c].hi; m.olo[c] = aA[1 + c].lo; }
+                m.zhi = aZ.hi; m.zlo = aZ.lo; m.ldz = C;
                 m.xx = xx; m.dx = dx; m.ldh = C; m.T = T; m.C = C; m.Dm = Dm;
-                m.mg_hi = opM.hi; m.mg_lo = opM.lo;               // scratch of the two-launch form (T x 5 Dm halves, like the unfused path's operand)
+                m.mg_hi = aM.hi; m.mg_lo = aM.lo;               // scratch of the two-launch form (T x 5 Dm halves, like the unfused path's operand)
                 if (att_fused) { m.lnp = ln_pro(a, lnp_xx_att); m.mu_x = w.mu[0]; }
                 launch(FAM_GEMM, [&] { launch_v6_mix(m, hilo, s_main); });
             } else {
                 {   // m = tanh(W1 z)  ->  operand [T][5*Dm]
-                    ProbSpec s = prob(w.W1, opA[0], ACT_TANH, nullptr, 0);
-                    s.oh = opM;
+                    ProbSpec s = prob(w.W1, aZ, ACT_TANH, nullptr, 0);
+                    s.oh = aM;
                     ps = {s};
                     gemm(ps, T, FAM_GEMM);
                 }
                 ps.clear();
                 for (int c = 0; c < 5; ++c) {   // x_c = xx + dx * (mu_c + W2_c m_c),  c in (w,k,v,r,g)
-                    ProbSpec s = prob(w.W2[c], opM, ACT_NONE, nullptr, 0);
+                    ProbSpec s = prob(w.W2[c], aM, ACT_NONE, nullptr, 0);
                     s.xoff = c * Dm;
                     s.bias = w.mu[1 + c]; s.post = POST_MIX; s.m0 = xx; s.m1 = dx; s.ldm = C;
-                    s.oh = opA[1 + c];
+                    s.oh = aA[1 + c];
                     ps.push_back(s);
                 }
                 gemm(ps, T, FAM_GEMM);
             }
-            ps = {prob(w.Wk, opA[2], ACT_NONE, fk, C), prob(w.Wv, opA[3], ACT_NONE, fv, C),
-                  prob(w.Wr, opA[4], ACT_NONE, fr, C), prob(w.Wg, opA[5], ACT_SILU, fg, C),
-                  prob(w.D1, opA[1], ACT_TANH, ftd, Dd)};
-            if (att_fused) { ShiftCommit cm = commit_of(a, lnp_xx_att); gemm(ps, T, FAM_GEMM, nullptr, &cm); att_fused = false; }
-            else gemm(ps, T, FAM_GEMM);
+            ps = {prob(w.Wk, aA[2], ACT_NONE, fk, C), prob(w.Wv, aA[3], ACT_NONE, fv, C),
+                  prob(w.Wr, aA[4], ACT_NONE, fr, C), prob(w.Wg, aA[5], ACT_SILU, fg, C),
+                  prob(w.D1, aA[1], ACT_TANH, ftd, Dd)};
+            if (att_fused) { ShiftCommit cm = commit_of(a, lnp_xx_att); gemm(ps, T, FAM_GEMM, nullptr, &cm, CLS_ATT); att_fused = false; }
+            else gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_ATT);
         } else {
             a.mode = 1; a.nmix = 6;
-            for (int i = 0; i < 6; ++i) { a.mu[i] = w.mu[i]; a.ohi[i] = opA[i].hi; a.olo[i] = opA[i].lo; }
+            for (int i = 0; i < 6; ++i) { a.mu[i] = w.mu[i]; a.ohi[i] = aA[i].hi; a.olo[i] = aA[i].lo; }
             // opA: 0=r 1=w 2=k 3=v 4=a 5=g
-            ps = {prob(w.Wr, opA[0], ACT_NONE, fr, C), prob(w.Wk, opA[2], ACT_NONE, fk, C), prob(w.Wv, opA[3], ACT_NONE, fv, C)};
+            ps = {prob(w.Wr, aA[0], ACT_NONE, fr, C), prob(w.Wk, aA[2], ACT_NONE, fk, C), prob(w.Wv, aA[3], ACT_NONE, fv, C)};
             ps[0].lnp_mu = w.mu[0]; ps[1].lnp_mu = w.mu[2]; ps[2].lnp_mu = w.mu[3];
-            { ProbSpec s = prob(w.w1, opA[1], ACT_TANH, nullptr, 0); s.oh = opL[0]; s.lnp_mu = w.mu[1]; ps.push_back(s); }
-            { ProbSpec s = prob(w.a1, opA[4], ACT_NONE, nullptr, 0); s.oh = opL[1]; s.lnp_mu = w.mu[4]; ps.push_back(s); }
-            { ProbSpec s = prob(w.g1, opA[5], ACT_SIGMOID, nullptr, 0); s.oh = opL[2]; s.lnp_mu = w.mu[5]; ps.push_back(s); }
-            if (l > 0) { ProbSpec s = prob(w.v1, opA[3], ACT_NONE, nullptr, 0); s.oh = opL[3]; s.lnp_mu = w.mu[3]; ps.push_back(s); }
-            if ((att_fused = ln_fusable(ps, T, np))) {
+            { ProbSpec s = prob(w.w1, aA[1], ACT_TANH, nullptr, 0); s.oh = aL[0]; s.lnp_mu = w.mu[1]; ps.push_back(s); }
+            { ProbSpec s = prob(w.a1, aA[4], ACT_NONE, nullptr, 0); s.oh = aL[1]; s.lnp_mu = w.mu[4]; ps.push_back(s); }
+            { ProbSpec s = prob(w.g1, aA[5], ACT_SIGMOID, nullptr, 0); s.oh = aL[2]; s.lnp_mu = w.mu[5]; ps.push_back(s); }
+            if (l > 0) { ProbSpec s = prob(w.v1, aA[3], ACT_NONE, nullptr, 0); s.oh = aL[3]; s.lnp_mu = w.mu[3]; ps.push_back(s); }
+            if ((att_fused = ln_fusable(ps, T, np, CLS_ATT))) {
                 LnProArgs lp = ln_pro(a, lnp_xx_att);
-                gemm(ps, T, FAM_GEMM, &lp);
+                gemm(ps, T, FAM_GEMM, &lp, nullptr, CLS_ATT);
+            } else if (gemm_with_rows(ps, T, FAM_GEMM, a, l * 2, CLS_ATT)) {
+                // the rows of this step rode in the launch
             } else {
                 launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
-                gemm(ps, T, FAM_GEMM);
+                gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_ATT);
             }
             ps.clear();
-            { ProbSpec s = prob(w.w2, opL[0], ACT_DECAY7, fw7, C); s.bias = w.w0; ps.push_back(s); }
-            { ProbSpec s = prob(w.a2, opL[1], ACT_SIGMOID, fa7, C); s.bias = w.a0; ps.push_back(s); }
-            { ProbSpec s = prob(w.g2, opL[2], ACT_NONE, fg, C); ps.push_back(s); }
-            if (l > 0) { ProbSpec s = prob(w.v2, opL[3], ACT_SIGMOID, fvg7, C); s.bias = w.v0; ps.push_back(s); }
-            if (att_fused) { ShiftCommit cm = commit_of(a, lnp_xx_att); gemm(ps, T, FAM_GEMM, nullptr, &cm); att_fused = false; }
-            else gemm(ps, T, FAM_GEMM);
+            { ProbSpec s = prob(w.w2, aL[0], ACT_DECAY7, fw7, C); s.bias = w.w0; ps.push_back(s); }
+            { ProbSpec s = prob(w.a2, aL[1], ACT_SIGMOID, fa7, C); s.bias = w.a0; ps.push_back(s); }
+            { ProbSpec s = prob(w.g2, aL[2], ACT_NONE, fg, C); ps.push_back(s); }
+            if (l > 0) { ProbSpec s = prob(w.v2, aL[3], ACT_SIGMOID, fvg7, C); s.bias = w.v0; ps.push_back(s); }
+            if (att_fused) { ShiftCommit cm = commit_of(a, lnp_xx_att); gemm(ps, T, FAM_GEMM, nullptr, &cm, CLS_LORA2); att_fused = false; }
+            else gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_LORA2);
         }
         std::swap(cur, oth);
         {
@@ -1296,15 +1355,15 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
             k.w7 = fw7; k.a7 = fa7; k.vg7 = fvg7; k.k_k = w.k_k; k.k_a = w.k_a; k.r_k = w.r_k;
             k.v_first = vfirst; k.layer = l;
             k.lnx_w = w.lnxw; k.lnx_b = w.lnxb;
-            k.yhi = opY.hi; k.ylo = opY.lo; k.ldh = C;
+            k.yhi = aY.hi; k.ylo = aY.lo; k.ldh = C;
             launch(FAM_WKV, [&] { launch_wkv(k, T > n_seq, s_main); });
         }
         {
-            ProbSpec s = prob(w.Wo, opY, ACT_NONE, P, C);
+            ProbSpec s = prob(w.Wo, aY, ACT_NONE, P, C);
             s.partial = true;
             ps = {s};
-            if (att_fused) { ShiftCommit cm = commit_of(a, lnp_xx_att); np = gemm(ps, T, FAM_GEMM, nullptr, &cm); }
-            else np = gemm(ps, T, FAM_GEMM);
+            if (att_fused) { ShiftCommit cm = commit_of(a, lnp_xx_att); np = gemm(ps, T, FAM_GEMM, nullptr, &cm, CLS_WO); }
+            else np = gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_WO);
         }
         // ---- channel mix
         LnShiftArgs f{};
@@ -1314,37 +1373,41 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
         f.rm = rm; f.C = C; f.ldh = C;
         f.mode = info.version == 5 ? 0 : 1;
         f.nmix = info.version == 7 ? 1 : 2;
-        for (int i = 0; i < f.nmix; ++i) { f.mu[i] = w.fmu[i]; f.ohi[i] = opA[i].hi; f.olo[i] = opA[i].lo; }
+        for (int i = 0; i < f.nmix; ++i) { f.mu[i] = w.fmu[i]; f.ohi[i] = aF[i].hi; f.olo[i] = aF[i].lo; }
         bool ffn_fused = false;
         {
-            ProbSpec s = prob(w.Fk, opA[0], ACT_RELU2, nullptr, 0);
-            s.oh = opK; s.lnp_mu = w.fmu[0];
+            ProbSpec s = prob(w.Fk, aF[0], ACT_RELU2, nullptr, 0);
+            s.oh = aK; s.lnp_mu = w.fmu[0];
             ps = {s};
-            if (info.version != 7) { ProbSpec r = prob(w.Fr, opA[1], ACT_SIGMOID, frr, C); r.lnp_mu = w.fmu[1]; ps.push_back(r); }
-            if ((ffn_fused = ln_fusable(ps, T, np))) {
+            if (info.version != 7) { ProbSpec r = prob(w.Fr, aF[1], ACT_SIGMOID, frr, C); r.lnp_mu = w.fmu[1]; ps.push_back(r); }
+            if ((ffn_fused = ln_fusable(ps, T, np, CLS_FFN1))) {
                 LnProArgs lp = ln_pro(f, lnp_xx_ffn);
-                gemm(ps, T, FAM_GEMM, &lp);
+                gemm(ps, T, FAM_GEMM, &lp, nullptr, CLS_FFN1);
+            } else if (gemm_with_rows(ps, T, FAM_GEMM, f, l * 2 + 1, CLS_FFN1)) {
+                // the rows of this step rode in the launch
             } else {
                 launch(FAM_ROW, [&] { launch_ln_shift(f, T, s_main); });
-                gemm(ps, T, FAM_GEMM);
+                gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_FFN1);
             }
             std::swap(cur, oth);
         }
         {
-            ProbSpec s = prob(w.Fv, opK, ACT_NONE, P, C);
+            ProbSpec s = prob(w.Fv, aK, ACT_NONE, P, C);
             s.partial = true;
             if (info.version != 7) { s.post = POST_MUL; s.m0 = frr; s.ldm = C; }
             ps = {s};
-            if (ffn_fused) { ShiftCommit cm = commit_of(f, lnp_xx_ffn); np = gemm(ps, T, FAM_GEMM, nullptr, &cm); }
-            else np = gemm(ps, T, FAM_GEMM);
+            if (ffn_fused) { ShiftCommit cm = commit_of(f, lnp_xx_ffn); np = gemm(ps, T, FAM_GEMM, nullptr, &cm, CLS_FV); }
+            else np = gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_FV);
         }
     }
     if (n_out > 0) {
-        LnOutArgs o{cur, P, np, pstride, lnow, lnob, dense ? nullptr : out_rows, opO.hi, opO.lo, C, C};
+        Opd aO = opO;
+        if (!wide(CLS_HEAD)) aO.lo = nullptr;
+        LnOutArgs o{cur, P, np, pstride, lnow, lnob, dense ? nullptr : out_rows, aO.hi, aO.lo, C, C};
         launch(FAM_ROW, [&] { launch_ln_out(o, n_out, s_main); });
         std::vector<ProbSpec> ps(1);
-        ps[0].W = head; ps[0].x = opO; ps[0].out = logits; ps[0].ldo = V;
-        gemm(ps, n_out, FAM_HEAD);
+        ps[0].W = head; ps[0].x = aO; ps[0].out = logits; ps[0].ldo = V;
+        gemm(ps, n_out, FAM_HEAD, nullptr, nullptr, CLS_HEAD);
     } else if (np > 0) {
         // nothing consumes the pending partial sums: fine, the residual stream dies with the step
     }
@@ -1466,7 +1529,7 @@ void rwkv_engine::infer_sample(const rwkv_slot_input *in, const rwkv_sample_para
             launch_logit_mask(logits, info.num_vocab, d_allow_row, d_allow, n_allow, s_main);
         }
         launch_nucleus(logits, pl.n_out, info.num_vocab, rows_ptr, any_nt, any_miro, dv_out_tok, dv_prob, s_main);
-        HIP_CHECK(hipStreamSynchronize(s_main));
+        sync_main();
         for (int b = 0; b < max_batch; ++b) {
             if (pl.slot_out_rows[b] == 0) continue;
             const int r = pl.slot_out_begin[b];
@@ -1475,7 +1538,7 @@ void rwkv_engine::infer_sample(const rwkv_slot_input *in, const rwkv_sample_para
             if (emitted) emitted[b] = 1;
         }
     } else {
-        HIP_CHECK(hipStreamSynchronize(s_main));
+        sync_main();
     }
     if (n_consumed) for (int b = 0; b < max_batch; ++b) n_consumed[b] = (size_t)pl.slot_consumed[b];
 }
@@ -1519,12 +1582,12 @@ void rwkv_engine::infer(const rwkv_slot_input *in, rwkv_slot_output *out) {
     if (direct) {
         for (const Seg &g : segs)
             HIP_CHECK(hipMemcpyAsync(g.dst, logits + g.row0 * V, g.rows * V * 4, hipMemcpyDeviceToHost, s_main));
-        HIP_CHECK(hipStreamSynchronize(s_main));
+        sync_main();
         return;
     }
     if (pl.n_out > 0)
         HIP_CHECK(hipMemcpyAsync(logits_host, logits, (size_t)pl.n_out * V * 4, hipMemcpyDeviceToHost, s_main));
-    HIP_CHECK(hipStreamSynchronize(s_main));
+    sync_main();
     for (const Seg &g : segs) std::memcpy(g.dst, logits_host + g.row0 * V, g.rows * V * 4);
 }
 
@@ -1916,6 +1979,7 @@ rwkv_status rwkv_decode_greedy(rwkv_engine *e, int32_t n_slots, const uint32_t *
         HIP_CHECK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
         if (elapsed_ms) *elapsed_ms = ms;
         HIP_CHECK(hipMemcpy(out_tokens, e->d_hist, need * 4, hipMemcpyDeviceToHost));
+        e->sync_main();                                              // (drained already: the hand-off check)
     });
 }
 

@@ -479,6 +479,131 @@ __device__ __forceinline__ void ln_prologue_finish(const LnProArgs &a, int T, co
     __syncthreads();
 }
 __device__ __forceinline__ size_t lnp_op_off(int T, int k, int tl) { return (size_t)((k >> 3) * T + tl) * 8; }   // k multiple of 8
+// =====================================================================================
+// Row job (RowJob, rwkv_kernels.h): one dense decode row of ln_shift_kernel's work done by a workgroup of the CONSUMING launch, with
+// any block size (C <= 4 * blockDim.x), split in two so that the row's loads are issued in front of the workgroup's weight stream
+// and reduced behind it.  Same arithmetic as ln_shift_kernel (slab sum in slab order, two-pass LayerNorm); the cross-wave sums run
+// over blockDim / 64 waves, so results may differ from the unfused path in the last bit.
+// =====================================================================================
+constexpr int RJ_PT = 1;                               // host: C <= 4 * blockDim.x (2560 on 640 threads, 2048 on 512)
+struct RowRegs { float4 xv[RJ_PT], pv[RJ_PT], wv[RJ_PT], bv[RJ_PT], pp[LNP_MAX_NP][RJ_PT]; };
+__device__ __forceinline__ int xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return (int)(v & 7); }
+__device__ __forceinline__ void rowjob_load(const RowJob &j, int t, RowRegs &r) {
+    const int C = j.C, tid = threadIdx.x, nth = blockDim.x;
+    const act_t bx = act_buf(j.x_in), bP = act_buf(j.P);
+    const float *sx = j.sx + (long)t * j.sx_slot_stride;
+#pragma unroll
+    for (int i = 0; i < RJ_PT; ++i) {
+        const int c = (tid + i * nth) * 4;
+        if (c < C) {
+            r.wv[i] = *(const float4 *)(j.lnw + c); r.bv[i] = *(const float4 *)(j.lnb + c);
+            r.pv[i] = *(const float4 *)(sx + c);
+            r.xv[i] = act_ld4(bx, (long)t * C + c);
+#pragma unroll
+            for (int q = 0; q < LNP_MAX_NP; ++q) r.pp[q][i] = act_ld4(bP, (q < j.np ? q : 0) * j.pstride + (long)t * C + c);
+        }
+    }
+}
+__device__ __forceinline__ float rowjob_block_sum(float v, float *buf) {       // `buf`: 16 floats of LDS not read since the last barrier
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = buf[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s += buf[w];
+    return s;
+}
+__device__ __forceinline__ void rowjob_finish(const RowJob &j, int t, RowRegs &r, float *red, unsigned epoch) {
+    const int C = j.C, tid = threadIdx.x, nth = blockDim.x;
+    const act_t bxo = act_buf(j.x_out), bxx = act_buf(j.xx_out), bdx = act_buf(j.dx_out);
+    float *sx = j.sx + (long)t * j.sx_slot_stride;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < RJ_PT; ++i) {
+        const int c = (tid + i * nth) * 4;
+        if (c < C) {
+#pragma unroll
+            for (int q = 0; q < LNP_MAX_NP; ++q) {
+                const bool on = q < j.np;
+                r.xv[i].x += on ? r.pp[q][i].x : 0.f; r.xv[i].y += on ? r.pp[q][i].y : 0.f;
+                r.xv[i].z += on ? r.pp[q][i].z : 0.f; r.xv[i].w += on ? r.pp[q][i].w : 0.f;
+            }
+            act_st4(bxo, (long)t * C + c, r.xv[i]);
+            sum += (r.xv[i].x + r.xv[i].y) + (r.xv[i].z + r.xv[i].w);
+        }
+    }
+    const float mean = rowjob_block_sum(sum, red) / (float)C;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < RJ_PT; ++i) {
+        const int c = (tid + i * nth) * 4;
+        if (c < C) {
+            const float d0 = r.xv[i].x - mean, d1 = r.xv[i].y - mean, d2 = r.xv[i].z - mean, d3 = r.xv[i].w - mean;
+            q2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(rowjob_block_sum(q2, red + 16) / (float)C + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < RJ_PT; ++i) {
+        const int c = (tid + i * nth) * 4;
+        if (c < C) {
+            float4 &v = r.xv[i];
+            v.x = (v.x - mean) * rstd * r.wv[i].x + r.bv[i].x; v.y = (v.y - mean) * rstd * r.wv[i].y + r.bv[i].y;
+            v.z = (v.z - mean) * rstd * r.wv[i].z + r.bv[i].z; v.w = (v.w - mean) * rstd * r.wv[i].w + r.bv[i].w;
+            *(float4 *)(sx + c) = v;                                       // dense step: this row is its slot's last row
+            const float4 pv = r.pv[i];
+            const float4 dx = make_float4(pv.x - v.x, pv.y - v.y, pv.z - v.z, pv.w - v.w);
+            if (j.xx_out) act_st4(bxx, (long)t * C + c, v);
+            if (j.dx_out) act_st4(bdx, (long)t * C + c, dx);
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                if (m < j.nmix) {
+                    const float4 mu = *(const float4 *)(j.mu[m] + c);
+                    float4 o;
+                    if (j.mode == 0) {
+                        o.x = v.x * mu.x + pv.x * (1.0f - mu.x); o.y = v.y * mu.y + pv.y * (1.0f - mu.y);
+                        o.z = v.z * mu.z + pv.z * (1.0f - mu.z); o.w = v.w * mu.w + pv.w * (1.0f - mu.w);
+                    } else {
+                        o.x = v.x + dx.x * mu.x; o.y = v.y + dx.y * mu.y; o.z = v.z + dx.z * mu.z; o.w = v.w + dx.w * mu.w;
+                    }
+                    {   // the operand is what THIS launch hands over: written through (sc0 sc1) so that no write-back of the XCD's L2 is
+                        // needed in front of the arrival (a release fence here also flushes the 20 KB of residual / state rows this
+                        // workgroup has just dirtied: 2.19 -> 2.24 ms per 32-slot step with it, profiles/r5_exp_rowjob_ab.log)
+                        f16x4 h;
+                        _Float16 hh, ll;
+                        split_hilo(o.x, hh, ll); h[0] = hh; split_hilo(o.y, hh, ll); h[1] = hh;
+                        split_hilo(o.z, hh, ll); h[2] = hh; split_hilo(o.w, hh, ll); h[3] = hh;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), act_buf(j.ohi[m]), (unsigned)(opd_off(t, c, j.ldh) * 2), 0, 17);
+                    }
+                }
+            }
+        }
+    }
+    // publish: every thread's write-through operand stores have been acknowledged before the arrival is counted (MI355X_MICROARCH.md,
+    // valid form "sc0 sc1 stores and loads on both sides": no fence); the last arriver raises the flags
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(j.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)j.T - 1u) {
+            __hip_atomic_store(j.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               // ready for the next step
+#pragma unroll
+            for (int x = 0; x < 8; ++x) __hip_atomic_store(j.sync + 32 * (1 + x), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// one lane polls this XCD's flag (relaxed, sleeping in between), then ONE acquire for the workgroup; bounded: 10 ms of the 100 MHz clock
+__device__ __forceinline__ void rowjob_wait(const RowJob &j, unsigned epoch) {
+    if (threadIdx.x == 0) {
+        const unsigned *flag = j.sync + 32 * (1 + xcc_id());
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            if (wall_clock64() - t0 > 1000000ull) { *(volatile unsigned *)j.err = 1u; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();                                               // (the consumer's X loads are sc0 sc1: no acquire fence)
+}
+
 #if RWKV_PART_ON(0)
 static int knob_env(const char *name, int dflt) {
     const char *v = std::getenv(name);
@@ -498,6 +623,8 @@ Knobs Knobs::from_env() {
     k.tile3_min_tiles = knob_env("RWKV_TILE3_MIN_TILES", 300);
     k.nf4_kc128_min = knob_env("RWKV_NF4_KC128_MIN", 512);
     k.tile3_64 = knob_env("RWKV_TILE3_64", 1);
+    k.promote = knob_env("RWKV_PROMOTE", 0);
+    k.rowjob = knob_env("RWKV_ROWJOB", 1);
     return k;
 }
 static thread_local Knobs t_knobs;
@@ -526,8 +653,9 @@ __device__ __forceinline__ const void *pin_p(const void *p) {
     const unsigned lo = (unsigned)pin_s((int)(unsigned)v), hi = (unsigned)pin_s((int)(unsigned)(v >> 32));
     return (const void *)(((unsigned long long)hi << 32) | lo);
 }
-template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, int FMT, bool LNP>
+template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, int FMT, bool LNP, bool GATE = false>
 __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
+    static_assert(!GATE || (SHOT && !TAIL && !LNP && !HILO), "the gated variant is single shot, whole rounds, f16 operands");
     constexpr int KW = KSW * 32, SUB = KSW / RS, RK = RS * 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches/addresses
@@ -570,7 +698,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
     const act_t boh = act_buf(P.out_hi), bol = act_buf(P.out_lo), bm0 = act_buf(P.m0), bm1 = act_buf(P.m1);
 
     // rounds a wave holds in registers at once (gemm_max_rounds)
-    constexpr int MAXR = NT == 4 ? 2 : (FMT == W_F16 ? 2 : ((NT == 2 || HILO) ? 3 : 4));
+    constexpr int MAXR = (NT == 4 || (NT == 2 && HILO)) ? 2 : (FMT == W_F16 ? 2 : ((NT == 2 || HILO) ? 3 : 4));
     WRound<FMT> cur, nxt, w[SHOT ? MAXR : 1];
     // streamed (not single-shot) quantised weights: a ring of RD rounds in flight per wave.  With only cur/nxt
     // (one round ahead) a wave's K slice is a serial chain of memory latencies — 6 rounds x ~0.9 us at T = 1
@@ -596,8 +724,21 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
     };
 
     TRACE_PT(0);
-    for (int t0 = 0; t0 < L.T; t0 += NT * 16) {
-        for (int sl = wave; sl < nslice && wave < nw; sl += nw) {
+    if constexpr (GATE) {
+        // Row job launch (host: one K slice per wave, one token-tile pass).  A row workgroup does its row FIRST and streams its weights
+        // behind it: they land during the hand-off it has to wait for like everybody else (and the row's registers are dead before the
+        // weight tiles are live — both at once spill); every other workgroup has all its weight tiles in flight from its first cycle.
+        // (the row itself: gemm_kernel, in front of the format dispatch — one copy of that code instead of three)
+        const unsigned epoch = *L.rowjob.epoch;
+        if (wave < nw && wave < nslice) {
+            const int k0 = kbeg + wave * KW, nsub = min(SUB, (kend - k0) / RK);
+            issue_w(k0, nsub, nstrip * nsub, false);
+        }
+        rowjob_wait(L.rowjob, epoch);
+    }
+    // (gated: ONE token-tile pass and ONE slice per wave, said so that the weight tiles issued above are dead after their MFMAs)
+    for (int t0 = 0; t0 < (GATE ? 1 : L.T); t0 += NT * 16) {
+        for (int sl = wave, pass = 0; sl < nslice && wave < nw && (!GATE || pass == 0); sl += nw, ++pass) {
             const int k0 = kbeg + sl * KW;
             // rounds of this slice that lie inside the K range (the last slice may be short)
             const int nsub = TAIL ? SUB : min(SUB, (kend - k0) / RK);
@@ -624,7 +765,8 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                             for (int k8 = 0; k8 < RS; ++k8) {
                                 const int ks = sub * RS + k8;
                                 const bool in = !TAIL || (k0 + ks * 32 < kend);
-                                xb[nt][ks] = in ? act_ldh8(bxh, xo + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                                if constexpr (GATE) xb[nt][ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(bxh, (unsigned)((xo + ks * 512) * 2), 0, 17));   // sc0 sc1: the rows came from this launch
+                                else xb[nt][ks] = in ? act_ldh8(bxh, xo + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                                 if constexpr (HILO) xl[nt][ks] = in ? act_ldh8(bxl, xo + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                             }
                         } else {
@@ -657,6 +799,8 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                     xb[0][ks] = in ? *(const f16x8 *)(oph + (size_t)ks * 4 * L.T * 8) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                     if constexpr (HILO) xl[0][ks] = in ? *(const f16x8 *)(oph + (size_t)L.T * L.lnp.C + (size_t)ks * 4 * L.T * 8) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                 }
+            } else if constexpr (GATE) {
+                load_x();                                      // (the weights were issued in front of the wait)
             } else {
                 load_x();
                 TRACE_PT(7);
@@ -792,8 +936,8 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
     TRACE_PT(4);
 }
 
-template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, bool LNP>
-__global__ __launch_bounds__(((KSW == 16 || NT == 4) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES) * 64) void gemm_kernel(const GemmLaunch L) {
+template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, bool LNP, bool GATE = false>
+__global__ __launch_bounds__(((KSW == 16 || NT == 4 || (NT == 2 && HILO)) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES) * 64) void gemm_kernel(const GemmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x >= L.total_blocks) {                      // the extra block of a launch that carries a commit
         shift_commit(L.commit);
@@ -803,12 +947,19 @@ __global__ __launch_bounds__(((KSW == 16 || NT == 4) ? GEMM_MAX_WAVES_K16 : GEMM
     for (int i = 1; i < L.nprob; ++i)
         if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
     const GemmProb &P = L.p[pi];
-    if (P.fmt == W_F16) gemm_body<NT, KSW, HILO, SHOT, TAIL, W_F16, LNP>(L, P, smem);
-    else if (P.fmt == W_INT8) gemm_body<NT, KSW, HILO, SHOT, false, W_INT8, LNP>(L, P, smem);   // quantised K is a multiple of 256
-    else gemm_body<NT, KSW, HILO, SHOT, false, W_NF4, LNP>(L, P, smem);
+    if constexpr (GATE) {
+        if ((int)blockIdx.x < L.rowjob.T) {
+            RowRegs rr;
+            rowjob_load(L.rowjob, (int)blockIdx.x, rr);
+            rowjob_finish(L.rowjob, (int)blockIdx.x, rr, (float *)smem, *L.rowjob.epoch);
+        }
+    }
+    if (P.fmt == W_F16) gemm_body<NT, KSW, HILO, SHOT, TAIL, W_F16, LNP, GATE>(L, P, smem);
+    else if (P.fmt == W_INT8) gemm_body<NT, KSW, HILO, SHOT, false, W_INT8, LNP, GATE>(L, P, smem);   // quantised K is a multiple of 256
+    else gemm_body<NT, KSW, HILO, SHOT, false, W_NF4, LNP, GATE>(L, P, smem);
 }
 
-int gemm_variant_max_waves(int NT, int KSW) { return (KSW == 16 || NT == 4) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES; }
+int gemm_variant_max_waves(int NT, int KSW, bool hilo) { return (KSW == 16 || NT == 4 || (NT == 2 && hilo)) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES; }
 
 void gemm_variant(int T, bool hilo, int &NT, int &KSW) {
     // T <= 16: ten waves of 256 k per block rather than five of 512 k — a wave's loads return in order and what a CU can pull from
@@ -816,7 +967,9 @@ void gemm_variant(int T, bool hilo, int &NT, int &KSW) {
     // workgroups: 5 waves 8.6-10.8 us, 10 waves 6.9-8.0, 16 waves 6.8-7.1 whatever the depth); on the real launches 9.09 -> 8.85 us
     // (r/k/v/g Int8, T = 1), one-slot step 1.707 -> 1.696 ms, eight slots 1.851 -> 1.827.  Knobs::ksw8 = 0 restores 512-k waves.
     const int ksw8 = knobs().ksw8;
-    if (hilo) { NT = 1; KSW = 8; }
+    // hi + lo operands (Precision::Fp32, or a promoted launch): 17+ rows run two token tiles per pass in 512-thread blocks (128 X registers, the
+    // register shape of the four-tile variant) — one pass over the weights for up to 32 rows instead of one per 16
+    if (hilo) { NT = T <= 16 ? 1 : 2; KSW = 8; }
     else if (T <= 16) { NT = 1; KSW = ksw8 ? 8 : 16; }
     else if (T <= 32) { NT = 2; KSW = 8; }
     else { NT = 4; KSW = 8; }                                    // 33..64 rows in ONE pass over the weights (128 X registers)
@@ -831,7 +984,7 @@ void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
     static bool attr_done[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
-#define GEMM_V3(X, sh, tl) X(1, 8, true, sh, tl, false) X(1, 16, false, sh, tl, false) X(2, 8, false, sh, tl, false) X(1, 8, false, sh, tl, false) X(1, 16, false, sh, tl, true) \
+#define GEMM_V3(X, sh, tl) X(1, 8, true, sh, tl, false) X(2, 8, true, sh, tl, false) X(1, 16, false, sh, tl, false) X(2, 8, false, sh, tl, false) X(1, 8, false, sh, tl, false) X(1, 16, false, sh, tl, true) \
                            X(4, 8, false, sh, tl, false)
 #define GEMM_VARIANTS(X) GEMM_V3(X, true, true) GEMM_V3(X, true, false) GEMM_V3(X, false, true) GEMM_V3(X, false, false)
     if (!attr_done[dev & 15]) {                               // allow > 64 KiB dynamic LDS (gfx950: 160 KiB / CU)
@@ -842,6 +995,17 @@ void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
         attr_done[dev & 15] = true;
     }
     const bool shot = L.single_shot != 0, tail = L.tail != 0;
+    if (L.rowjob.T > 0) {                                      // gated variants: (NT 1 | 2, KSW 8, f16 operands, single shot, whole rounds)
+        static bool gattr[16] = {false};
+        if (!gattr[dev & 15]) {
+            (void)hipFuncSetAttribute((const void *)gemm_kernel<1, 8, false, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)gemm_kernel<2, 8, false, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            gattr[dev & 15] = true;
+        }
+        if (NT == 1) hipLaunchKernelGGL((gemm_kernel<1, 8, false, true, false, false, true>), grid, block, lds, s, L);
+        else hipLaunchKernelGGL((gemm_kernel<2, 8, false, true, false, false, true>), grid, block, lds, s, L);
+        return;
+    }
 #define LAUNCH(a, b, c, d, e, f) if (NT == a && KSW == b && hilo == c && shot == d && tail == e && lnp == f) hipLaunchKernelGGL((gemm_kernel<a, b, c, d, e, f>), grid, block, lds, s, L);
     GEMM_VARIANTS(LAUNCH)
 #undef LAUNCH
@@ -849,7 +1013,7 @@ void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
 #undef GEMM_V3
 }
 
-int gemm_max_rounds(int fmt, int NT, bool hilo) { return NT == 4 ? 2 : (fmt == W_F16 ? 2 : ((NT == 2 || hilo) ? 3 : 4)); }   // X registers vs the VGPR budget
+int gemm_max_rounds(int fmt, int NT, bool hilo) { return (NT == 4 || (NT == 2 && hilo)) ? 2 : (fmt == W_F16 ? 2 : ((NT == 2 || hilo) ? 3 : 4)); }   // X registers vs the VGPR budget
 #endif  // part 0: decode GEMM
 
 
@@ -2034,6 +2198,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
     row_layernorm<PT>(v, C, wv, bv, red);
     const act_t bx = act_buf(a.x);
     ROW_FOR(i, c) act_st4(bx, (long)t * C + c, v[i]);
+    if (a.epoch && blockIdx.x == 0 && threadIdx.x == 0) *a.epoch += 1u;      // the step's hand-off epoch (RowJob): later kernels of the step read it
 }
 void launch_embed(const EmbedArgs &a, int T, hipStream_t s) { ROW_DISPATCH(embed_kernel, a.C, T, a); }
 
@@ -2081,6 +2246,7 @@ __device__ __forceinline__ float row_sum16x4(float o0, float o1, float o2, float
 __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
     __shared__ __attribute__((aligned(16))) float sh_r[64], sh_k[64], sh_v[64], sh_w[64], sh_u[64], sh_kk[64], sh_ka[64];
     __shared__ float sh_out[64];
+    const int version = a.version;
     const int seq = blockIdx.x, h = blockIdx.y;
     const int tid = threadIdx.x, ig = tid >> 4, jg = tid & 15;
     TRACE_K(1, 0);
@@ -2094,18 +2260,18 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
     // (The small activations handed to the next kernel are better off with plain stores — measured both ways.)
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa) T[aa] = __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4 *)(st + (aa * 16 + ig) * 64 + jg * 4)));
-    if (a.version != 7 && tid < 64) sh_u[tid] = a.u[cb + tid];
-    if (a.version == 5 && tid < 64) sh_w[tid] = a.wdec_or_decay[cb + tid];
+    if (version != 7 && tid < 64) sh_u[tid] = a.u[cb + tid];
+    if (version == 5 && tid < 64) sh_w[tid] = a.wdec_or_decay[cb + tid];
 
     // loop-invariant per-channel parameters of wave 0 (tid < 64)
     float lnw = 0.f, lnb = 0.f, kk_p = 0.f, ka_p = 0.f, rk_p = 0.f;
     if (tid < 64) {
         lnw = a.lnx_w[cb + tid]; lnb = a.lnx_b[cb + tid];
-        if (a.version == 7) { kk_p = a.k_k[cb + tid]; ka_p = a.k_a[cb + tid]; rk_p = a.r_k[cb + tid]; }
+        if (version == 7) { kk_p = a.k_k[cb + tid]; ka_p = a.k_a[cb + tid]; rk_p = a.r_k[cb + tid]; }
     }
     const int ch = tid >> 2, part = tid & 3;                 // v6 decay LoRA: 4 threads per channel
     const int per = a.Dd >> 2;
-    const float decay0 = a.version == 6 ? a.wdec_or_decay[cb + ch] : 0.f;
+    const float decay0 = version == 6 ? a.wdec_or_decay[cb + ch] : 0.f;
     const act_t br = act_buf(a.r), bk = act_buf(a.k), bv = act_buf(a.v), bg = act_buf(a.g), btd = act_buf(a.td);
     const act_t ba7 = act_buf(a.a7), bw7 = act_buf(a.w7), bvg7 = act_buf(a.vg7), bvf = act_buf(a.v_first);
     const act_t byh = act_buf(a.yhi), byl = act_buf(a.ylo);
@@ -2118,12 +2284,12 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
         // ---- issue every global load of this token before the first barrier
         if (tid < 64) {
             r = act_ld1(br, rb + tid); k = act_ld1(bk, rb + tid); v = act_ld1(bv, rb + tid); gt = act_ld1(bg, rb + tid);
-            if (a.version == 7) {
+            if (version == 7) {
                 av = act_ld1(ba7, rb + tid); w7 = act_ld1(bw7, rb + tid);
                 if (a.layer != 0) { vg = act_ld1(bvg7, rb + tid); vf = act_ld1(bvf, rb + tid); }
             }
         }
-        if (a.version == 6) {
+        if (version == 6) {
             // decay LoRA stage 2: d_c = time_decay_c + sum_d D2[c][d] td[d];  w = exp(-exp(d))
             const _Float16 *d2 = a.D2 + (long)(cb + ch) * a.Dd + part * per;
             const long tdo = (long)t * a.Dd + part * per;
@@ -2139,7 +2305,7 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
         __syncthreads();                                   // previous iteration's LDS readers done
         TRACE_K(1, 2);
         if (tid < 64) {
-            if (a.version == 7) {
+            if (version == 7) {
                 float kk = k * kk_p;
                 const float ss = wave_sum(kk * kk);        // tid<64 == wave 0: L2 norm over the head
                 kk = kk / fmaxf(sqrtf(ss), 1e-12f);
@@ -2152,13 +2318,13 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
             }
             sh_r[tid] = r; sh_k[tid] = k; sh_v[tid] = v;
         }
-        if (a.version == 6 && part == 0) sh_w[ch] = expf(-expf(decay0 + dsum));
+        if (version == 6 && part == 0) sh_w[ch] = expf(-expf(decay0 + dsum));
         __syncthreads();
         const float4 rq = *(const float4 *)(sh_r + jg * 4);
         const float4 kq = *(const float4 *)(sh_k + jg * 4);
         const float4 wq = *(const float4 *)(sh_w + jg * 4);
         float outp[4];
-        if (a.version != 7) {
+        if (version != 7) {
             const float4 uq = *(const float4 *)(sh_u + jg * 4);
 #pragma unroll
             for (int aa = 0; aa < 4; ++aa) {
@@ -2201,7 +2367,7 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
             const float d = o - mean;
             const float var = wave_sum(d * d) * (1.0f / 64.0f);
             float y = d / sqrtf(var + 64e-5f) * lnw + lnb;
-            if (a.version == 7) {
+            if (version == 7) {
                 const float bonus = wave_sum(sh_r[tid] * sh_k[tid] * rk_p);
                 y += bonus * sh_v[tid];
             }

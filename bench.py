@@ -105,12 +105,90 @@ def spawn_ranks(n: int, argv: list[str]) -> int:
     return rc
 
 
+def gpu_numa_topology(n_gpus: int) -> dict:
+    """{gpu index: {"numa_node": n, "cpus": [...]}} for the GPUs of this host, from the PCI device's sysfs `numa_node` and the node's
+    `cpulist` (what `rocm-smi --showtoponuma` prints).  The GPU's PCI bus id comes from the HIP runtime (hipDeviceGetPCIBusId through
+    ctypes: no torch import, no device context is created before the process has bound itself).  BENCH_FAKE_NUMA='{"0": [0, [0,1]], ...}'
+    (gpu -> [node, cpus]) replaces the probe: the CPU test of the binding.  GPUs whose node is unknown (-1, single-node hosts, no
+    sysfs) are left out: the rank then keeps the affinity it was started with."""
+    fake = os.environ.get("BENCH_FAKE_NUMA")
+    if fake:
+        return {int(k): {"numa_node": int(v[0]), "cpus": [int(c) for c in v[1]]} for k, v in json.loads(fake).items()}
+    topo = {}
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        for g in range(n_gpus):
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, g) != 0:
+                continue
+            bus = buf.value.decode().lower()
+            node = int(open(f"/sys/bus/pci/devices/{bus}/numa_node").read().strip())
+            if node < 0:
+                continue
+            cpus = []
+            for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.extend(range(int(lo), int(hi or lo) + 1))
+            topo[g] = {"numa_node": node, "cpus": cpus, "pci_bus_id": bus}
+    except (OSError, ValueError, AttributeError):
+        pass
+    return topo
+
+
+def bind_to_gpu_numa_node(gpu: int, n_gpus: int) -> dict:
+    """Pin this process (and every thread it starts later: OpenMP, the engine's callers) to the CPUs of its GPU's NUMA node BEFORE anything
+    is allocated, so that the pinned arenas of `rwkv_host_alloc` (logits, embeddings) and the checkpoint pages are first touched on the
+    node the GPU hangs off — on an 8-GPU host the PCIe-inclusive and embeddings legs otherwise cross the socket link.
+    Returns what was done, for the line (`per_rank_numa`)."""
+    info = {"gpu": gpu, "numa_node": None, "cpus_bound": None}
+    t = gpu_numa_topology(n_gpus).get(gpu)
+    if t:
+        allowed = os.sched_getaffinity(0)
+        cpus = sorted(set(t["cpus"]) & allowed)
+        info["numa_node"] = t["numa_node"]
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            info["cpus_bound"] = len(cpus)
+            try:                                                      # memory policy follows first touch; prefer the node explicitly where libnuma exists
+                import ctypes
+                numa = ctypes.CDLL("libnuma.so.1")
+                if numa.numa_available() >= 0:
+                    numa.numa_set_preferred(t["numa_node"])
+                    info["mempolicy"] = "preferred"
+            except OSError:
+                pass
+    return info
+
+
+def shared_synth_st(R, name: str, job):
+    """The synthetic checkpoint ONCE PER NODE: local rank 0 generates the `.st` image and leaves it in /dev/shm, the other ranks map it
+    (8 x 6 GB of numpy synthesis, and 8 private copies of the file image, become one).  Single-rank runs synthesise in place."""
+    if job.world == 1:
+        return R.synth_st(name, fast=True)
+    path = f"/dev/shm/rwkv_bench_{name}_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}.st"
+    if job.local_rank_env == 0:
+        buf, _ = R.synth_st(name, fast=True)
+        with open(path + ".tmp", "wb") as f:
+            f.write(memoryview(buf))
+        os.replace(path + ".tmp", path)
+        del buf
+    job.host_barrier()
+    img = np.memmap(path, dtype=np.uint8, mode="r")
+    tensors = R.st_deserialize(img)
+    job.host_barrier()
+    if job.local_rank_env == 0:
+        os.unlink(path)                                              # the mappings keep the pages; nothing is left behind
+    return img, tensors
+
+
 class Job:
     """Rank bookkeeping + the host-side barrier / MAX reduction (gloo; there is no RCCL communicator in this repo)."""
 
     def __init__(self, args):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.local_rank_env = self.local_rank
         if os.environ.get("BENCH_SHARE_GPU"):       # test hook: all ranks on device 0 (the N > 1 code path on a 1-GPU box)
             self.local_rank = 0
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +196,9 @@ class Job:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: the line would report the wrong n_gpus")
         self.dist = None
         self.torch = None
+        # first thing a rank does, before torch / the engine allocate anything: CPU affinity (and memory preference) of its GPU's NUMA node
+        self.numa = bind_to_gpu_numa_node(self.local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world)))) \
+            if self.world > 1 or os.environ.get("BENCH_FAKE_NUMA") else {"gpu": self.local_rank, "numa_node": None, "cpus_bound": None}
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -138,6 +219,18 @@ class Job:
         if self.dist is not None:
             self.dist.barrier()
         self.sync()
+
+    def host_barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def gather_objects(self, obj):
+        """[every rank's obj] (rank order)"""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
 
     def max_and_all(self, dt: float):
         """(MAX over ranks, [every rank's value])"""
@@ -449,9 +542,11 @@ def selftest_dist(job, args):
     dt = time.perf_counter() - t
     job.barrier()
     dt_max, dt_all = job.max_and_all(dt)
+    numa = job.gather_objects(dict(job.numa, rank=job.rank, affinity=sorted(os.sched_getaffinity(0))))
     if job.rank == 0:
         B = args.batch
-        print(json.dumps({"metric": "decode tokens/sec (whole job)", "value": B * job.world * args.steps / dt_max, "unit": "tokens/s",
+        print(json.dumps({"per_rank_numa": numa,
+                          "metric": "decode tokens/sec (whole job)", "value": B * job.world * args.steps / dt_max, "unit": "tokens/s",
                           "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max * 1e3 / args.steps,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "selftest", "data": "none",
                           "config": {"workload": "launcher self-test (sleep)"},
@@ -482,7 +577,7 @@ def main(argv=None):
     from oracle import rwkv_ref as R   # checkpoint synthesis + byte accounting + the cpu_baseline leg only
 
     t0 = time.time()
-    st, tensors = R.synth_st(args.workload, fast=True)
+    st, tensors = shared_synth_st(R, args.workload, job)
     info = R.model_info(tensors)
     shapes = {k: v.shape for k, v in tensors.items()}
     qt = QT[args.quant]
@@ -542,6 +637,28 @@ def main(argv=None):
             emb["at_token_chunk_size_2048"] = {"value": e["value"], "prefill_tokens_per_s": e["prefill_tokens_per_s"],
                                                "embeddings_verified": e["embeddings_verified"]}
     eng.close()
+
+    # Precision::Fp32 on the record (reload.rs:89-94): the mode that meets north_star's 1e-3 at 32 layers (measured <= 3e-5,
+    # tests/test_gpu_full_depth.py) — hi + lo f16 operands, two MFMAs per k-step, weights streamed once.  Same configuration, same checks.
+    fp32 = None
+    if single and not args.decode_only and args.precision == "fp16":
+        e32 = build_engine(rt, st, job.local_rank, ql, qt, B, max(2048, B), "fp32")
+        fp32 = {"precision": "Precision::Fp32 (hi + lo f16 operands, fp32 accumulate)", "decode": {}}
+        for nb in sorted({B, 8, 1}, reverse=True):
+            if nb > B:
+                continue
+            d2, _, _ = decode_point(job, e32, first[:nb], args.steps, min(args.warmup, 10))
+            abn = R.algorithmic_bytes(info, shapes, ql, qt, nb)
+            fp32["decode"][str(nb)] = {"tokens_per_s": nb * args.steps / d2, "ms_per_step": d2 * 1e3 / args.steps,
+                                       "frac_of_hbm_peak": abn["per_step"] * (args.steps / d2) / HBM_PEAK}
+        fp32["tokens_verified"] = verify_decode(rt, e32, first, args.verify_steps) if args.verify_steps > 0 else None
+        fp32["vs_fp16_ms_per_step"] = fp32["decode"][str(B)]["ms_per_step"] / ms_per_step
+        e32.close()
+        e32 = build_engine(rt, st, job.local_rank, ql, qt, B, 256, "fp32")
+        fp32["embeddings"] = embed_job_leg(job, rt, R, e32, info, EMBED_DOCS_PER_RANK)
+        e32.close()
+        if emb:
+            fp32["embeddings"]["vs_fp16_rate"] = fp32["embeddings"]["value"] / emb["value"]
     del st
 
     cpu = None
@@ -559,6 +676,7 @@ def main(argv=None):
                         ("config5_v6-7b_fp16", dict(name="v6-7b", quant="none", batches=[8], prefill=(4096, [2048, 1024])))]:
             configs[key] = config_leg(job, rt, R, steps=cs, verify_steps=vs, **kw)
 
+    numa = job.gather_objects(dict(job.numa, rank=rank))
     if rank == 0:
         line = {"metric": "decode tokens/sec (whole job)", "value": value, "unit": "tokens/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -567,8 +685,9 @@ def main(argv=None):
                            "quant": args.quant, "batch_per_gpu": B, "precision": args.precision,
                            "parallelism": f"replicas x{world} (no collective)"},
                 "tokens_per_s_per_gpu": value / world, "per_rank_tokens_per_s": [B * args.steps / d for d in dt_all],
+                "per_rank_numa": numa,
                 "device_ms_per_step": dev_ms / args.steps,
-                "roofline": roof, "cpu_baseline": cpu, "embeddings": emb,
+                "roofline": roof, "cpu_baseline": cpu, "embeddings": emb, "precision_fp32": fp32,
                 "pcie_inclusive_tokens_per_s": pcie["value"] if pcie else None, "pcie_inclusive": pcie,
                 "on_device_sampling_tokens_per_s": sampled["value"] if sampled else None, "on_device_sampling": sampled,
                 "sweep": sweep or None, "tokens_verified": tokens_verified,

@@ -43,6 +43,26 @@ def test_gpus_2_without_a_launcher_spawns_two_ranks():
     assert abs(e["value"] - 2 * min(e["per_rank_embeddings_per_s"])) <= 1e-6 * e["value"]
 
 
+def test_each_rank_binds_to_the_numa_node_of_its_gpu():
+    """8-GPU readiness: before anything is allocated a rank pins itself to the CPUs of its GPU's NUMA node, so the pinned
+    arenas of `rwkv_host_alloc` are node-local; the line says what every rank did (`per_rank_numa`).  Faked topology: GPU 0 on node 0
+    with the first allowed CPU, GPU 1 on node 1 with the last one."""
+    cpus = sorted(os.sched_getaffinity(0))
+    fake = {"0": [0, [cpus[0]]], "1": [1, [cpus[-1]]]}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "5", "--selftest-dist"], env=clean_env(BENCH_FAKE_NUMA=json.dumps(fake)),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    numa = last_json(r.stdout)["per_rank_numa"]
+    assert [n["rank"] for n in numa] == [0, 1] and [n["gpu"] for n in numa] == [0, 1]
+    assert [n["numa_node"] for n in numa] == [0, 1] and [n["cpus_bound"] for n in numa] == [1, 1]
+    assert numa[0]["affinity"] == [cpus[0]] and numa[1]["affinity"] == [cpus[-1]]
+    # a GPU the topology does not know keeps the affinity it was started with
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "5", "--selftest-dist"], env=clean_env(BENCH_FAKE_NUMA=json.dumps({"0": fake["0"]})),
+                       capture_output=True, text=True, timeout=120)
+    numa = last_json(r.stdout)["per_rank_numa"]
+    assert numa[1]["numa_node"] is None and numa[1]["affinity"] == cpus
+
+
 def test_under_torch_distributed_run_as_the_driver_launches_it():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29631", BENCH, "--gpus", "2", "--steps", "10", "--selftest-dist"], env=clean_env(),
