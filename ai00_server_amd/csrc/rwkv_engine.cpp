@@ -342,7 +342,6 @@ struct rwkv_engine {
         if (h_tok) (void)hipHostFree(h_tok);
         if (h_samp) (void)hipHostFree(h_samp);
         if (h_allow) (void)hipHostFree(h_allow);
-        if (h_err) (void)hipHostFree(h_err);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (s_main) (void)hipStreamDestroy(s_main);
@@ -389,16 +388,8 @@ struct rwkv_engine {
         prof_fam.clear();
     }
 
-    // after a step has drained: did an in-launch hand-off (RowJob) run out of its bounded wait?  The step's results are then invalid.
-    void sync_main() {
-        HIP_CHECK(hipStreamSynchronize(s_main));
-        if (h_err && *h_err) { *h_err = 0; throw RwkvError(RWKV_ERR_DEVICE, "an in-launch hand-off of the step timed out (row job): results discarded"); }
-    }
     void load(const rwkv_load_desc &d);
     int gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs *lnp = nullptr, const ShiftCommit *commit = nullptr, int cls = CLS_NONE);
-    // the row job of dense decode steps (RowJob, rwkv_kernels.h): `r`'s row work inside the launch of `ps`; false = not eligible (nothing launched)
-    bool gemm_with_rows(std::vector<ProbSpec> &ps, int T, int fam, const LnShiftArgs &r, int slot, int cls);
-    unsigned *d_sync = nullptr, *d_epoch = nullptr, *h_err = nullptr, *dv_err = nullptr;   // hand-off words: [layer][att | ffn] x (counter + 8 XCD flags), 128-byte lines
     void log_gemm(const std::vector<ProbSpec> &ps, int T, int fam, const char *kind, int variant, int grid, int ksplit);
     bool ln_fusable(std::vector<ProbSpec> &ps, int T, int np, int cls = CLS_NONE);
     float *lnp_xx_att = nullptr, *lnp_xx_ffn = nullptr;   // normalised rows published by an LN-prologue launch (for the commit)
@@ -814,13 +805,6 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
     d_allow = dalloc<unsigned char>((size_t)max_batch * V); d_allow_row = dalloc<int>(max_batch);
     HIP_CHECK(hipHostMalloc((void **)&h_allow, (size_t)max_batch * V + (size_t)max_batch * 4 + 16, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **)&h_samp, (size_t)chunk * (sizeof(SampleRow) + 8) + ADJ_CAP * 12, hipHostMallocDefault));
-    d_sync = dalloc<unsigned>((size_t)L * 2 * 9 * 32);
-    d_epoch = dalloc<unsigned>(32);
-    HIP_CHECK(hipMemset(d_sync, 0, (size_t)L * 2 * 9 * 32 * 4));
-    HIP_CHECK(hipMemset(d_epoch, 0, 32 * 4));
-    HIP_CHECK(hipHostMalloc((void **)&h_err, 64, hipHostMallocMapped | hipHostMallocCoherent));
-    *h_err = 0;
-    HIP_CHECK(hipHostGetDevicePointer((void **)&dv_err, h_err, 0));
     d_amax_v = dalloc<float>((size_t)chunk * 32);
     d_amax_i = dalloc<int>((size_t)chunk * 32);
     HIP_CHECK(hipDeviceSynchronize());
@@ -833,7 +817,7 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
 // Decomposition of one launch (DESIGN.md "GEMM planning"): every wave owns KW = KSW*32 k of the block's K range;
 // linear ("partial") problems may split K across `ksb` blocks (the consumer row kernel sums the partials);
 // a block walks `spb` strips.  Aim: >= ~1.5 blocks per CU in flight, whole matrix in flight at once.
-static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo, long pstride, int force_spb = 0, bool want_shot = false) {
+static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo, long pstride, int force_spb = 0) {
     if (ps.empty() || ps.size() > GEMM_MAXP) throw RwkvError(RWKV_ERR_INVALID, "gemm: bad problem count");
     Lh = GemmLaunch{};
     Lh.nprob = (int)ps.size();
@@ -909,7 +893,7 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
     {
         bool all_quant = true;
         for (auto &sp : ps) all_quant = all_quant && (sp.W->fmt != W_F16 || sp.W->rows <= 256);   // (the decay LoRA's 64 fp16 rows ride along)
-        if (NT == 2 && all_quant && !hilo && !want_shot) shot = false;
+        if (NT == 2 && all_quant && !hilo) shot = false;
     }
     Lh.single_shot = shot ? 1 : 0;
     Lh.tail = tail ? 1 : 0;
@@ -1067,30 +1051,6 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
     return np;
 }
 
-// A dense decode step's row work (LayerNorm + token shift + operand emit of `r`) inside the launch that consumes it.  Eligible: the
-// switch is on, f16 operands, 1..32 rows, every problem single shot with one K slice per wave and whole rounds, as many workgroups as
-// rows, the whole grid resident at once (one workgroup per CU), C <= 4 * threads, partial slabs within the row job's register budget.
-bool rwkv_engine::gemm_with_rows(std::vector<ProbSpec> &ps, int T, int fam, const LnShiftArgs &r, int slot, int cls) {
-    if (!kn.rowjob || wide(cls) || !r.rm.dense || T < 1 || T > 32 || r.np > LNP_MAX_NP || r.nmix > 6 || r.xcd_rows) return false;
-    GemmLaunch Lh;
-    const int np = plan_gemm(Lh, ps, T, false, pstride, 0, true);
-    (void)np;
-    int NT, KSW;
-    gemm_variant(T, false, NT, KSW);
-    if (KSW != 8 || NT > 2 || !Lh.single_shot || Lh.tail || Lh.total_blocks < T || Lh.total_blocks > 248 || r.C > 4 * Lh.threads || r.C % 4) return false;
-    for (int i = 0; i < Lh.nprob; ++i) if (Lh.p[i].ksb != 1 || Lh.p[i].nslice > Lh.p[i].nw) return false;
-    RowJob &j = Lh.rowjob;
-    j.T = T; j.x_in = r.x_in; j.x_out = r.x_out; j.P = r.P; j.np = r.np; j.pstride = r.pstride;
-    j.lnw = r.lnw; j.lnb = r.lnb; j.sx = r.sx; j.sx_slot_stride = r.sx_slot_stride;
-    j.mode = r.mode; j.nmix = r.nmix;
-    for (int m = 0; m < 6; ++m) { j.mu[m] = r.mu[m]; j.ohi[m] = r.ohi[m]; }
-    j.ldh = r.ldh; j.xx_out = r.xx_out; j.dx_out = r.dx_out; j.C = r.C;
-    j.sync = d_sync + (size_t)slot * 9 * 32; j.epoch = d_epoch; j.err = dv_err;
-    log_gemm(ps, T, fam, "decode+rows", 1, Lh.total_blocks, 1);
-    launch(fam, [&] { launch_gemm(Lh, false, s_main); });
-    return true;
-}
-
 // RWKV_LAUNCH_LOG (dev): what a launch of layer 0 (or the head) streams and computes, so that a profile can be priced without guessing which
 // grid size is which launch: {"kind","variant","T","grid","ksplit","rows","bytes","flops","mats"}
 void rwkv_engine::log_gemm(const std::vector<ProbSpec> &ps, int T, int fam, const char *kind, int variant, int grid, int ksplit) {
@@ -1226,7 +1186,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
     float *cur = xA, *oth = xB;
     int np = 0;
     {
-        EmbedArgs e{emb, ln0w, ln0b, d_token, cur, C, V, d_epoch};
+        EmbedArgs e{emb, ln0w, ln0b, d_token, cur, C, V};
         launch(FAM_ROW, [&] { launch_embed(e, T, s_main); });
     }
     for (int l = 0; l < L; ++l) {
@@ -1272,8 +1232,6 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
             if ((att_fused = ln_fusable(ps, T, np, CLS_ATT))) {
                 LnProArgs lp = ln_pro(a, lnp_xx_att);
                 gemm(ps, T, FAM_GEMM, &lp, nullptr, CLS_ATT);
-            } else if (gemm_with_rows(ps, T, FAM_GEMM, a, l * 2, CLS_ATT)) {
-                // the rows of this step rode in the launch
             } else {
                 launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
                 gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_ATT);
@@ -1330,8 +1288,6 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
             if ((att_fused = ln_fusable(ps, T, np, CLS_ATT))) {
                 LnProArgs lp = ln_pro(a, lnp_xx_att);
                 gemm(ps, T, FAM_GEMM, &lp, nullptr, CLS_ATT);
-            } else if (gemm_with_rows(ps, T, FAM_GEMM, a, l * 2, CLS_ATT)) {
-                // the rows of this step rode in the launch
             } else {
                 launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
                 gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_ATT);
@@ -1383,8 +1339,6 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
             if ((ffn_fused = ln_fusable(ps, T, np, CLS_FFN1))) {
                 LnProArgs lp = ln_pro(f, lnp_xx_ffn);
                 gemm(ps, T, FAM_GEMM, &lp, nullptr, CLS_FFN1);
-            } else if (gemm_with_rows(ps, T, FAM_GEMM, f, l * 2 + 1, CLS_FFN1)) {
-                // the rows of this step rode in the launch
             } else {
                 launch(FAM_ROW, [&] { launch_ln_shift(f, T, s_main); });
                 gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_FFN1);
@@ -1529,7 +1483,7 @@ void rwkv_engine::infer_sample(const rwkv_slot_input *in, const rwkv_sample_para
             launch_logit_mask(logits, info.num_vocab, d_allow_row, d_allow, n_allow, s_main);
         }
         launch_nucleus(logits, pl.n_out, info.num_vocab, rows_ptr, any_nt, any_miro, dv_out_tok, dv_prob, s_main);
-        sync_main();
+        HIP_CHECK(hipStreamSynchronize(s_main));
         for (int b = 0; b < max_batch; ++b) {
             if (pl.slot_out_rows[b] == 0) continue;
             const int r = pl.slot_out_begin[b];
@@ -1538,7 +1492,7 @@ void rwkv_engine::infer_sample(const rwkv_slot_input *in, const rwkv_sample_para
             if (emitted) emitted[b] = 1;
         }
     } else {
-        sync_main();
+        HIP_CHECK(hipStreamSynchronize(s_main));
     }
     if (n_consumed) for (int b = 0; b < max_batch; ++b) n_consumed[b] = (size_t)pl.slot_consumed[b];
 }
@@ -1582,12 +1536,12 @@ void rwkv_engine::infer(const rwkv_slot_input *in, rwkv_slot_output *out) {
     if (direct) {
         for (const Seg &g : segs)
             HIP_CHECK(hipMemcpyAsync(g.dst, logits + g.row0 * V, g.rows * V * 4, hipMemcpyDeviceToHost, s_main));
-        sync_main();
+        HIP_CHECK(hipStreamSynchronize(s_main));
         return;
     }
     if (pl.n_out > 0)
         HIP_CHECK(hipMemcpyAsync(logits_host, logits, (size_t)pl.n_out * V * 4, hipMemcpyDeviceToHost, s_main));
-    sync_main();
+    HIP_CHECK(hipStreamSynchronize(s_main));
     for (const Seg &g : segs) std::memcpy(g.dst, logits_host + g.row0 * V, g.rows * V * 4);
 }
 
@@ -1979,7 +1933,6 @@ rwkv_status rwkv_decode_greedy(rwkv_engine *e, int32_t n_slots, const uint32_t *
         HIP_CHECK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
         if (elapsed_ms) *elapsed_ms = ms;
         HIP_CHECK(hipMemcpy(out_tokens, e->d_hist, need * 4, hipMemcpyDeviceToHost));
-        e->sync_main();                                              // (drained already: the hand-off check)
     });
 }
 

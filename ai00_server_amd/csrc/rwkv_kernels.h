@@ -26,7 +26,6 @@ struct Knobs {
     int tile3_min_tiles = 300;       // RWKV_TILE3_MIN_TILES: fewest tiles for which the pipelined prefill kernel is considered
     int nf4_kc128_min = 512;         // RWKV_NF4_KC128_MIN: 64x64 tiles of an all-NF4 launch walk K in 128-k chunks from this many tiles
     int v6_split_min_t = 512;        // RWKV_V6_SPLIT_MIN_T: rows from which the wide V6 mix runs as two launches (v6_mix_apply_kernel)
-    int rowjob = 1;                  // RWKV_ROWJOB: row work of dense decode steps inside the consuming GEMM launch (RowJob; 0 = ln_shift launches)
     int promote = 0;                 // RWKV_PROMOTE: bit mask of GEMM launch classes that read hi + lo operands in Precision::Fp16 (1 att r/k/v(/g) + first-stage
                                      // LoRAs, 2 V7 second-stage LoRAs, 4 Wo, 8 Fk / Fr, 16 Fv, 32 head); rwkv_engine.cpp OpdClass
     int ln_threads = 0;              // RWKV_LN_THREADS: threads per row of ln_shift on prefill-shaped steps (0 = 1024 up to 256 rows, 512 above; 256 / 512 / 1024 force)
@@ -96,35 +95,6 @@ struct ShiftCommit {                // sx[slot[t]] = src[last[t]] for rows with 
     int T, C;
 };
 
-// ROW JOB of a decode GEMM launch (dense decode steps, T <= 32 rows): the LayerNorm + token-shift row work that produces the launch's
-// operand runs INSIDE the launch, on its first T workgroups, instead of as the `ln_shift` launch in front of it.  Every workgroup issues
-// its weight loads first (single shot: they land in registers while the rows are normalised), the row workgroups publish their rows
-// (release fence, arrival counter, the last arriver stores one flag per XCD), everybody waits for its XCD's flag with ONE polling lane,
-// acquires, and only then fetches X.  The launch boundary between the row kernel and the GEMM is gone and the weight stream no longer
-// waits for the rows (scripts/runahead_bench.hip: 14.2 -> 12.5 us per pair in isolation; the two-stream form of the same idea loses
-// 5-8 us to the graph's cross-queue dependencies — profiles/r5_exp_runahead_*.log).  All workgroups of the launch are resident at once
-// (grid <= CUs, one workgroup per CU), so a waiting workgroup can never keep a producer from running; every wait is bounded (`err`).
-struct RowJob {
-    int T;                          // rows (0: the launch carries no row job); row t is slot t (dense step)
-    const float *x_in;
-    float *x_out;
-    const float *P;
-    int np;
-    long pstride;
-    const float *lnw, *lnb;
-    float *sx;
-    long sx_slot_stride;
-    int mode, nmix;                 // as LnShiftArgs
-    const float *mu[6];
-    _Float16 *ohi[6];
-    int ldh;
-    float *xx_out, *dx_out;
-    int C;
-    unsigned *sync;                 // [0] arrival counter; [32 * (1 + x)] flag of XCD x (its own 128-byte line): the step's epoch when the rows are out
-    const unsigned *epoch;          // device step counter, bumped by the step's first kernel (embed)
-    unsigned *err;                  // host-visible word, set to 1 when a bounded wait ran out (the step's results are then invalid)
-};
-
 struct GemmProb {
     const void *W;
     const void *S;
@@ -162,7 +132,6 @@ struct GemmLaunch {
     int xcd_map;                    // prefill tile GEMM: XCD-banded tile numbering (rwkv_kernels.hip tg_body)
     LnProArgs lnp;
     ShiftCommit commit;             // grid = total_blocks + 1 when commit.src is set
-    RowJob rowjob;                  // rowjob.T > 0: the gated variant (single shot, one K slice per wave, one token-tile pass)
 };
 
 void gemm_variant(int T, bool hilo, int &NT, int &KSW);   // tile variant used for T rows
@@ -226,7 +195,6 @@ struct EmbedArgs {
     const int *token;
     float *x;
     int C, V;
-    unsigned *epoch;                // step counter of the in-launch hand-offs (RowJob): bumped here, by the step's first kernel
 };
 void launch_embed(const EmbedArgs &a, int T, hipStream_t s);
 

@@ -479,131 +479,6 @@ __device__ __forceinline__ void ln_prologue_finish(const LnProArgs &a, int T, co
     __syncthreads();
 }
 __device__ __forceinline__ size_t lnp_op_off(int T, int k, int tl) { return (size_t)((k >> 3) * T + tl) * 8; }   // k multiple of 8
-// =====================================================================================
-// Row job (RowJob, rwkv_kernels.h): one dense decode row of ln_shift_kernel's work done by a workgroup of the CONSUMING launch, with
-// any block size (C <= 4 * blockDim.x), split in two so that the row's loads are issued in front of the workgroup's weight stream
-// and reduced behind it.  Same arithmetic as ln_shift_kernel (slab sum in slab order, two-pass LayerNorm); the cross-wave sums run
-// over blockDim / 64 waves, so results may differ from the unfused path in the last bit.
-// =====================================================================================
-constexpr int RJ_PT = 1;                               // host: C <= 4 * blockDim.x (2560 on 640 threads, 2048 on 512)
-struct RowRegs { float4 xv[RJ_PT], pv[RJ_PT], wv[RJ_PT], bv[RJ_PT], pp[LNP_MAX_NP][RJ_PT]; };
-__device__ __forceinline__ int xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return (int)(v & 7); }
-__device__ __forceinline__ void rowjob_load(const RowJob &j, int t, RowRegs &r) {
-    const int C = j.C, tid = threadIdx.x, nth = blockDim.x;
-    const act_t bx = act_buf(j.x_in), bP = act_buf(j.P);
-    const float *sx = j.sx + (long)t * j.sx_slot_stride;
-#pragma unroll
-    for (int i = 0; i < RJ_PT; ++i) {
-        const int c = (tid + i * nth) * 4;
-        if (c < C) {
-            r.wv[i] = *(const float4 *)(j.lnw + c); r.bv[i] = *(const float4 *)(j.lnb + c);
-            r.pv[i] = *(const float4 *)(sx + c);
-            r.xv[i] = act_ld4(bx, (long)t * C + c);
-#pragma unroll
-            for (int q = 0; q < LNP_MAX_NP; ++q) r.pp[q][i] = act_ld4(bP, (q < j.np ? q : 0) * j.pstride + (long)t * C + c);
-        }
-    }
-}
-__device__ __forceinline__ float rowjob_block_sum(float v, float *buf) {       // `buf`: 16 floats of LDS not read since the last barrier
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float s = buf[0];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s += buf[w];
-    return s;
-}
-__device__ __forceinline__ void rowjob_finish(const RowJob &j, int t, RowRegs &r, float *red, unsigned epoch) {
-    const int C = j.C, tid = threadIdx.x, nth = blockDim.x;
-    const act_t bxo = act_buf(j.x_out), bxx = act_buf(j.xx_out), bdx = act_buf(j.dx_out);
-    float *sx = j.sx + (long)t * j.sx_slot_stride;
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < RJ_PT; ++i) {
-        const int c = (tid + i * nth) * 4;
-        if (c < C) {
-#pragma unroll
-            for (int q = 0; q < LNP_MAX_NP; ++q) {
-                const bool on = q < j.np;
-                r.xv[i].x += on ? r.pp[q][i].x : 0.f; r.xv[i].y += on ? r.pp[q][i].y : 0.f;
-                r.xv[i].z += on ? r.pp[q][i].z : 0.f; r.xv[i].w += on ? r.pp[q][i].w : 0.f;
-            }
-            act_st4(bxo, (long)t * C + c, r.xv[i]);
-            sum += (r.xv[i].x + r.xv[i].y) + (r.xv[i].z + r.xv[i].w);
-        }
-    }
-    const float mean = rowjob_block_sum(sum, red) / (float)C;
-    float q2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < RJ_PT; ++i) {
-        const int c = (tid + i * nth) * 4;
-        if (c < C) {
-            const float d0 = r.xv[i].x - mean, d1 = r.xv[i].y - mean, d2 = r.xv[i].z - mean, d3 = r.xv[i].w - mean;
-            q2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-        }
-    }
-    const float rstd = 1.0f / sqrtf(rowjob_block_sum(q2, red + 16) / (float)C + 1e-5f);
-#pragma unroll
-    for (int i = 0; i < RJ_PT; ++i) {
-        const int c = (tid + i * nth) * 4;
-        if (c < C) {
-            float4 &v = r.xv[i];
-            v.x = (v.x - mean) * rstd * r.wv[i].x + r.bv[i].x; v.y = (v.y - mean) * rstd * r.wv[i].y + r.bv[i].y;
-            v.z = (v.z - mean) * rstd * r.wv[i].z + r.bv[i].z; v.w = (v.w - mean) * rstd * r.wv[i].w + r.bv[i].w;
-            *(float4 *)(sx + c) = v;                                       // dense step: this row is its slot's last row
-            const float4 pv = r.pv[i];
-            const float4 dx = make_float4(pv.x - v.x, pv.y - v.y, pv.z - v.z, pv.w - v.w);
-            if (j.xx_out) act_st4(bxx, (long)t * C + c, v);
-            if (j.dx_out) act_st4(bdx, (long)t * C + c, dx);
-#pragma unroll
-            for (int m = 0; m < 6; ++m) {
-                if (m < j.nmix) {
-                    const float4 mu = *(const float4 *)(j.mu[m] + c);
-                    float4 o;
-                    if (j.mode == 0) {
-                        o.x = v.x * mu.x + pv.x * (1.0f - mu.x); o.y = v.y * mu.y + pv.y * (1.0f - mu.y);
-                        o.z = v.z * mu.z + pv.z * (1.0f - mu.z); o.w = v.w * mu.w + pv.w * (1.0f - mu.w);
-                    } else {
-                        o.x = v.x + dx.x * mu.x; o.y = v.y + dx.y * mu.y; o.z = v.z + dx.z * mu.z; o.w = v.w + dx.w * mu.w;
-                    }
-                    {   // the operand is what THIS launch hands over: written through (sc0 sc1) so that no write-back of the XCD's L2 is
-                        // needed in front of the arrival (a release fence here also flushes the 20 KB of residual / state rows this
-                        // workgroup has just dirtied: 2.19 -> 2.24 ms per 32-slot step with it, profiles/r5_exp_rowjob_ab.log)
-                        f16x4 h;
-                        _Float16 hh, ll;
-                        split_hilo(o.x, hh, ll); h[0] = hh; split_hilo(o.y, hh, ll); h[1] = hh;
-                        split_hilo(o.z, hh, ll); h[2] = hh; split_hilo(o.w, hh, ll); h[3] = hh;
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), act_buf(j.ohi[m]), (unsigned)(opd_off(t, c, j.ldh) * 2), 0, 17);
-                    }
-                }
-            }
-        }
-    }
-    // publish: every thread's write-through operand stores have been acknowledged before the arrival is counted (MI355X_MICROARCH.md,
-    // valid form "sc0 sc1 stores and loads on both sides": no fence); the last arriver raises the flags
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(j.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == (unsigned)j.T - 1u) {
-            __hip_atomic_store(j.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               // ready for the next step
-#pragma unroll
-            for (int x = 0; x < 8; ++x) __hip_atomic_store(j.sync + 32 * (1 + x), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-// one lane polls this XCD's flag (relaxed, sleeping in between), then ONE acquire for the workgroup; bounded: 10 ms of the 100 MHz clock
-__device__ __forceinline__ void rowjob_wait(const RowJob &j, unsigned epoch) {
-    if (threadIdx.x == 0) {
-        const unsigned *flag = j.sync + 32 * (1 + xcc_id());
-        const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-            if (wall_clock64() - t0 > 1000000ull) { *(volatile unsigned *)j.err = 1u; break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-    }
-    __syncthreads();                                               // (the consumer's X loads are sc0 sc1: no acquire fence)
-}
-
 #if RWKV_PART_ON(0)
 static int knob_env(const char *name, int dflt) {
     const char *v = std::getenv(name);
@@ -624,7 +499,6 @@ Knobs Knobs::from_env() {
     k.nf4_kc128_min = knob_env("RWKV_NF4_KC128_MIN", 512);
     k.tile3_64 = knob_env("RWKV_TILE3_64", 1);
     k.promote = knob_env("RWKV_PROMOTE", 0);
-    k.rowjob = knob_env("RWKV_ROWJOB", 1);
     return k;
 }
 static thread_local Knobs t_knobs;
@@ -653,9 +527,8 @@ __device__ __forceinline__ const void *pin_p(const void *p) {
     const unsigned lo = (unsigned)pin_s((int)(unsigned)v), hi = (unsigned)pin_s((int)(unsigned)(v >> 32));
     return (const void *)(((unsigned long long)hi << 32) | lo);
 }
-template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, int FMT, bool LNP, bool GATE = false>
+template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, int FMT, bool LNP>
 __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
-    static_assert(!GATE || (SHOT && !TAIL && !LNP && !HILO), "the gated variant is single shot, whole rounds, f16 operands");
     constexpr int KW = KSW * 32, SUB = KSW / RS, RK = RS * 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches/addresses
@@ -724,21 +597,8 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
     };
 
     TRACE_PT(0);
-    if constexpr (GATE) {
-        // Row job launch (host: one K slice per wave, one token-tile pass).  A row workgroup does its row FIRST and streams its weights
-        // behind it: they land during the hand-off it has to wait for like everybody else (and the row's registers are dead before the
-        // weight tiles are live — both at once spill); every other workgroup has all its weight tiles in flight from its first cycle.
-        // (the row itself: gemm_kernel, in front of the format dispatch — one copy of that code instead of three)
-        const unsigned epoch = *L.rowjob.epoch;
-        if (wave < nw && wave < nslice) {
-            const int k0 = kbeg + wave * KW, nsub = min(SUB, (kend - k0) / RK);
-            issue_w(k0, nsub, nstrip * nsub, false);
-        }
-        rowjob_wait(L.rowjob, epoch);
-    }
-    // (gated: ONE token-tile pass and ONE slice per wave, said so that the weight tiles issued above are dead after their MFMAs)
-    for (int t0 = 0; t0 < (GATE ? 1 : L.T); t0 += NT * 16) {
-        for (int sl = wave, pass = 0; sl < nslice && wave < nw && (!GATE || pass == 0); sl += nw, ++pass) {
+    for (int t0 = 0; t0 < L.T; t0 += NT * 16) {
+        for (int sl = wave; sl < nslice && wave < nw; sl += nw) {
             const int k0 = kbeg + sl * KW;
             // rounds of this slice that lie inside the K range (the last slice may be short)
             const int nsub = TAIL ? SUB : min(SUB, (kend - k0) / RK);
@@ -765,8 +625,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                             for (int k8 = 0; k8 < RS; ++k8) {
                                 const int ks = sub * RS + k8;
                                 const bool in = !TAIL || (k0 + ks * 32 < kend);
-                                if constexpr (GATE) xb[nt][ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(bxh, (unsigned)((xo + ks * 512) * 2), 0, 17));   // sc0 sc1: the rows came from this launch
-                                else xb[nt][ks] = in ? act_ldh8(bxh, xo + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                                xb[nt][ks] = in ? act_ldh8(bxh, xo + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                                 if constexpr (HILO) xl[nt][ks] = in ? act_ldh8(bxl, xo + ks * 512) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                             }
                         } else {
@@ -799,8 +658,6 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                     xb[0][ks] = in ? *(const f16x8 *)(oph + (size_t)ks * 4 * L.T * 8) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                     if constexpr (HILO) xl[0][ks] = in ? *(const f16x8 *)(oph + (size_t)L.T * L.lnp.C + (size_t)ks * 4 * L.T * 8) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                 }
-            } else if constexpr (GATE) {
-                load_x();                                      // (the weights were issued in front of the wait)
             } else {
                 load_x();
                 TRACE_PT(7);
@@ -936,7 +793,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
     TRACE_PT(4);
 }
 
-template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, bool LNP, bool GATE = false>
+template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, bool LNP>
 __global__ __launch_bounds__(((KSW == 16 || NT == 4 || (NT == 2 && HILO)) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES) * 64) void gemm_kernel(const GemmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x >= L.total_blocks) {                      // the extra block of a launch that carries a commit
@@ -947,16 +804,9 @@ __global__ __launch_bounds__(((KSW == 16 || NT == 4 || (NT == 2 && HILO)) ? GEMM
     for (int i = 1; i < L.nprob; ++i)
         if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
     const GemmProb &P = L.p[pi];
-    if constexpr (GATE) {
-        if ((int)blockIdx.x < L.rowjob.T) {
-            RowRegs rr;
-            rowjob_load(L.rowjob, (int)blockIdx.x, rr);
-            rowjob_finish(L.rowjob, (int)blockIdx.x, rr, (float *)smem, *L.rowjob.epoch);
-        }
-    }
-    if (P.fmt == W_F16) gemm_body<NT, KSW, HILO, SHOT, TAIL, W_F16, LNP, GATE>(L, P, smem);
-    else if (P.fmt == W_INT8) gemm_body<NT, KSW, HILO, SHOT, false, W_INT8, LNP, GATE>(L, P, smem);   // quantised K is a multiple of 256
-    else gemm_body<NT, KSW, HILO, SHOT, false, W_NF4, LNP, GATE>(L, P, smem);
+    if (P.fmt == W_F16) gemm_body<NT, KSW, HILO, SHOT, TAIL, W_F16, LNP>(L, P, smem);
+    else if (P.fmt == W_INT8) gemm_body<NT, KSW, HILO, SHOT, false, W_INT8, LNP>(L, P, smem);   // quantised K is a multiple of 256
+    else gemm_body<NT, KSW, HILO, SHOT, false, W_NF4, LNP>(L, P, smem);
 }
 
 int gemm_variant_max_waves(int NT, int KSW, bool hilo) { return (KSW == 16 || NT == 4 || (NT == 2 && hilo)) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES; }
@@ -995,17 +845,6 @@ void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
         attr_done[dev & 15] = true;
     }
     const bool shot = L.single_shot != 0, tail = L.tail != 0;
-    if (L.rowjob.T > 0) {                                      // gated variants: (NT 1 | 2, KSW 8, f16 operands, single shot, whole rounds)
-        static bool gattr[16] = {false};
-        if (!gattr[dev & 15]) {
-            (void)hipFuncSetAttribute((const void *)gemm_kernel<1, 8, false, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)gemm_kernel<2, 8, false, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            gattr[dev & 15] = true;
-        }
-        if (NT == 1) hipLaunchKernelGGL((gemm_kernel<1, 8, false, true, false, false, true>), grid, block, lds, s, L);
-        else hipLaunchKernelGGL((gemm_kernel<2, 8, false, true, false, false, true>), grid, block, lds, s, L);
-        return;
-    }
 #define LAUNCH(a, b, c, d, e, f) if (NT == a && KSW == b && hilo == c && shot == d && tail == e && lnp == f) hipLaunchKernelGGL((gemm_kernel<a, b, c, d, e, f>), grid, block, lds, s, L);
     GEMM_VARIANTS(LAUNCH)
 #undef LAUNCH
@@ -2198,7 +2037,6 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
     row_layernorm<PT>(v, C, wv, bv, red);
     const act_t bx = act_buf(a.x);
     ROW_FOR(i, c) act_st4(bx, (long)t * C + c, v[i]);
-    if (a.epoch && blockIdx.x == 0 && threadIdx.x == 0) *a.epoch += 1u;      // the step's hand-off epoch (RowJob): later kernels of the step read it
 }
 void launch_embed(const EmbedArgs &a, int T, hipStream_t s) { ROW_DISPATCH(embed_kernel, a.C, T, a); }
 

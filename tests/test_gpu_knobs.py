@@ -21,7 +21,7 @@ SWITCHES = [("RWKV_KSW8", "0"), ("RWKV_NO_LN_FUSE", "1"), ("RWKV_NO_V6_FUSE", "1
             ("RWKV_SPB", "2"), ("RWKV_KSB", "2"), ("RWKV_KSW8+RWKV_NO_LN_FUSE", "0+1"), ("RWKV_TILE_SHAPE", "10"), ("RWKV_TILE_KSPLIT", "0"),
             ("RWKV_LN_THREADS", "256"), ("RWKV_LN_THREADS", "1024"), ("RWKV_TILE3_MIN_TILES", "1"), ("RWKV_NF4_KC128_MIN", "1"),
             ("RWKV_TILE3_64", "0"), ("RWKV_TILE_SHAPE", "11"), ("RWKV_V6_SPLIT_MIN_T", "64"),
-            ("RWKV_ROWJOB", "0"), ("RWKV_PROMOTE", "63"), ("RWKV_PROMOTE", "3"), ("RWKV_PROMOTE", "20")]
+            ("RWKV_PROMOTE", "63"), ("RWKV_PROMOTE", "3"), ("RWKV_PROMOTE", "20")]
 
 
 def tol(want):
@@ -85,7 +85,7 @@ def test_every_switch_gives_the_oracles_answers(models, switch, value):
     try:
         for k, v in zip(names, values):
             os.environ[k] = v
-        vers = (6, 5, 7) if any(k in ("RWKV_KSW8", "RWKV_NO_LN_FUSE", "RWKV_NO_TILE", "RWKV_NO_DENSE", "RWKV_LN_256", "RWKV_LN_THREADS", "RWKV_SPB", "RWKV_KSB", "RWKV_TILE_KSPLIT", "RWKV_PROMOTE", "RWKV_ROWJOB") for k in names) else (6,)
+        vers = (6, 5, 7) if any(k in ("RWKV_KSW8", "RWKV_NO_LN_FUSE", "RWKV_NO_TILE", "RWKV_NO_DENSE", "RWKV_LN_256", "RWKV_LN_THREADS", "RWKV_SPB", "RWKV_KSB", "RWKV_TILE_KSPLIT", "RWKV_PROMOTE") for k in names) else (6,)
         for ver in vers:
             tens, st = models[ver]
             for quant in ((0, 1, 2) if "RWKV_NF4_KC128_MIN" in names else (0, 1)):      # the NF4 chunk rule needs an all-NF4 launch
