@@ -390,7 +390,8 @@ struct rwkv_engine {
 
     void load(const rwkv_load_desc &d);
     int gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs *lnp = nullptr, const ShiftCommit *commit = nullptr, int cls = CLS_NONE);
-    void log_gemm(const std::vector<ProbSpec> &ps, int T, int fam, const char *kind, int variant, int grid, int ksplit);
+    void log_gemm(const std::vector<ProbSpec> &ps, int T, int fam, const char *kind, int variant, int grid, int ksplit, int threads);
+    void log_row(const char *kernel, int T, long grid, double bytes);   // RWKV_LAUNCH_LOG: algorithmic bytes of a non-GEMM launch of layer 0 / 1
     bool ln_fusable(std::vector<ProbSpec> &ps, int T, int np, int cls = CLS_NONE);
     float *lnp_xx_att = nullptr, *lnp_xx_ffn = nullptr;   // normalised rows published by an LN-prologue launch (for the commit)
     void plan_step(const rwkv_slot_input *in, StepPlan &pl);
@@ -1039,21 +1040,29 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         }
         Lh.total_blocks = blocks;
         Lh.xcd_map = kn.tile_xcd;                                   // A/B switch
-        log_gemm(ps, T, fam, "tile", shape, blocks, ksplit);
+        {   // block size of the tile shape (rwkv_kernels.hip TG_SH; the pipelined kernel runs 256 threads): the profile joins on it
+            static const int waves[10] = {8, 8, 4, 4, 4, 8, 4, 4, 4, 8};
+            log_gemm(ps, T, fam, "tile", shape, blocks, ksplit, shape < 10 ? waves[shape] * 64 : 256);
+        }
         launch(fam, [&] { launch_gemm_tile(Lh, shape, hilo, s_main); });
         return ksplit;
     }
     const int np = plan_gemm(Lh, ps, T, hilo, pstride);
     if (lnp) Lh.lnp = *lnp;
     if (commit) Lh.commit = *commit;
-    log_gemm(ps, T, fam, "decode", Lh.single_shot, Lh.total_blocks + (Lh.commit.src ? 1 : 0), np);
+    log_gemm(ps, T, fam, "decode", Lh.single_shot, Lh.total_blocks + (Lh.commit.src ? 1 : 0), np, Lh.threads);
     launch(fam, [&] { launch_gemm(Lh, hilo, s_main); });
     return np;
 }
 
 // RWKV_LAUNCH_LOG (dev): what a launch of layer 0 (or the head) streams and computes, so that a profile can be priced without guessing which
 // grid size is which launch: {"kind","variant","T","grid","ksplit","rows","bytes","flops","mats"}
-void rwkv_engine::log_gemm(const std::vector<ProbSpec> &ps, int T, int fam, const char *kind, int variant, int grid, int ksplit) {
+void rwkv_engine::log_row(const char *kernel, int T, long grid, double bytes) {
+    if (!launch_log || cur_layer > 1) return;
+    std::fprintf(launch_log, "{\"kind\": \"row\", \"kernel\": \"%s\", \"T\": %d, \"grid\": %ld, \"bytes\": %.0f}\n", kernel, T, grid, bytes);
+    std::fflush(launch_log);
+}
+void rwkv_engine::log_gemm(const std::vector<ProbSpec> &ps, int T, int fam, const char *kind, int variant, int grid, int ksplit, int threads) {
     if (!launch_log || (cur_layer > 1 && fam != FAM_HEAD)) return;       // layers 0 and 1 (V7's layer 0 has no value-residual LoRA) + the head
     uint64_t bytes = 0;
     double flops = 0;
@@ -1066,8 +1075,8 @@ void rwkv_engine::log_gemm(const std::vector<ProbSpec> &ps, int T, int fam, cons
         for (auto &kv : mats)
             if (&kv.second == sp.W) { names += (names.empty() ? "" : "+") + kv.first; break; }
     }
-    std::fprintf(launch_log, "{\"kind\": \"%s\", \"variant\": %d, \"T\": %d, \"grid\": %d, \"ksplit\": %d, \"rows\": %ld, \"bytes\": %llu, \"flops\": %.0f, \"mats\": \"%s\"}\n",
-                 kind, variant, T, grid, ksplit, rows, (unsigned long long)bytes, flops, names.c_str());
+    std::fprintf(launch_log, "{\"kind\": \"%s\", \"variant\": %d, \"T\": %d, \"grid\": %d, \"threads\": %d, \"ksplit\": %d, \"rows\": %ld, \"bytes\": %llu, \"flops\": %.0f, \"mats\": \"%s\"}\n",
+                 kind, variant, T, grid, threads, ksplit, rows, (unsigned long long)bytes, flops, names.c_str());
     std::fflush(launch_log);
 }
 
@@ -1222,6 +1231,12 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
             cm.src = xx_pub; cm.sx = r.sx; cm.sx_slot_stride = r.sx_slot_stride; cm.rm = r.rm; cm.T = T; cm.C = C;
             return cm;
         };
+        // RWKV_LAUNCH_LOG: what a row-kernel launch moves (its rows and their partial slabs in, state row in and out, residual and operands out)
+        auto log_ln = [&](const LnShiftArgs &r) {
+            int nlo = 0;
+            for (int m = 0; m < r.nmix; ++m) nlo += r.olo[m] ? 1 : 0;
+            log_row("ln_shift_kernel", T, T, (double)T * C * (4.0 * (4 + r.np + (r.xx_out ? 1 : 0) + (r.dx_out ? 1 : 0)) + 2.0 * (r.nmix + nlo)) + 4.0 * C * (2 + r.nmix));
+        };
         bool att_fused = false;                                    // a commit of the time-mix shift state is pending
         if (info.version == 5) {
             a.mode = 0; a.nmix = 4;
@@ -1233,7 +1248,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
                 LnProArgs lp = ln_pro(a, lnp_xx_att);
                 gemm(ps, T, FAM_GEMM, &lp, nullptr, CLS_ATT);
             } else {
-                launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
+                { launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); }); log_ln(a); }
                 gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_ATT);
             }
         } else if (info.version == 6) {
@@ -1241,7 +1256,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
             a.xx_out = xx; a.dx_out = dx;
             const int no_fuse = kn.no_v6_fuse, no_ln_fuse = kn.no_ln_fuse;
             att_fused = !no_fuse && !no_ln_fuse && v6_mix_ln_supported(T, C, Dm, hilo, np);
-            if (!att_fused) launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
+            if (!att_fused) { launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); }); log_ln(a); }
             const int no_wide = kn.no_v6_wide;                      // A/B: two tile-GEMM launches instead of the wide fused form
             if ((v6_mix_supported(T, C, Dm) || (v6_mix_wide_supported(T, C, Dm) && !no_wide)) && !no_fuse) {
                 // fused: x_c = xx + dx * (mu_c + W2_c tanh(W1_c z)) in one launch
@@ -1253,6 +1268,9 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
                 m.mg_hi = aM.hi; m.mg_lo = aM.lo;               // scratch of the two-launch form (T x 5 Dm halves, like the unfused path's operand)
                 if (att_fused) { m.lnp = ln_pro(a, lnp_xx_att); m.mu_x = w.mu[0]; }
                 launch(FAM_GEMM, [&] { launch_v6_mix(m, hilo, s_main); });
+                // LoRA matrices once, z / xx / dx in, five operands out (+ the LayerNorm prologue's row traffic on single-token steps)
+                log_row("v6_mix_kernel", T, 0, 2.0 * (5.0 * Dm * C * 2) + (double)T * C * (2.0 + 8.0 + 10.0 * (m.olo[0] ? 2 : 1)) + 20.0 * C +
+                                                   (att_fused ? (double)T * C * 4.0 * (4 + np) : 0.0));
             } else {
                 {   // m = tanh(W1 z)  ->  operand [T][5*Dm]
                     ProbSpec s = prob(w.W1, aZ, ACT_TANH, nullptr, 0);
@@ -1289,7 +1307,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
                 LnProArgs lp = ln_pro(a, lnp_xx_att);
                 gemm(ps, T, FAM_GEMM, &lp, nullptr, CLS_ATT);
             } else {
-                launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); });
+                { launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); }); log_ln(a); }
                 gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_ATT);
             }
             ps.clear();
@@ -1313,6 +1331,10 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
             k.lnx_w = w.lnxw; k.lnx_b = w.lnxb;
             k.yhi = aY.hi; k.ylo = aY.lo; k.ldh = C;
             launch(FAM_WKV, [&] { launch_wkv(k, T > n_seq, s_main); });
+            // state tiles in and out (2 x 16 KiB per (slot, head)), the projections of every row in, the gated output operand out
+            log_row(T > n_seq ? "wkv_chunk_kernel" : "wkv_kernel", T, (long)n_seq * H,
+                    (double)n_seq * H * 32768.0 + (double)T * C * 4.0 * (info.version == 7 ? (l > 0 ? 8 : 6) : 4) +
+                        (info.version == 6 ? (double)T * Dd * 4.0 + (double)C * Dd * 2.0 : 0.0) + (double)T * C * 2.0 * (k.ylo ? 2 : 1));
         }
         {
             ProbSpec s = prob(w.Wo, aY, ACT_NONE, P, C);
@@ -1340,7 +1362,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
                 LnProArgs lp = ln_pro(f, lnp_xx_ffn);
                 gemm(ps, T, FAM_GEMM, &lp, nullptr, CLS_FFN1);
             } else {
-                launch(FAM_ROW, [&] { launch_ln_shift(f, T, s_main); });
+                { launch(FAM_ROW, [&] { launch_ln_shift(f, T, s_main); }); log_ln(f); }
                 gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_FFN1);
             }
             std::swap(cur, oth);
@@ -1629,15 +1651,43 @@ int32_t rwkv_engine_max_batch(const rwkv_engine *e) { return e ? e->max_batch : 
 int32_t rwkv_engine_token_chunk_size(const rwkv_engine *e) { return e ? e->chunk : 0; }
 uint64_t rwkv_engine_weight_bytes(const rwkv_engine *e) { return e ? e->weight_bytes : 0; }
 
+// Blocks handed out by rwkv_host_alloc, base -> bytes: the asynchronous read-back checks that the rows it is asked to write END inside the
+// block they start in (a pinned block that is too small, or a large offset into it, must come back as RWKV_ERR_INVALID, not as a DMA
+// over whatever follows the block in host memory).
+static std::mutex g_host_mu;
+static std::map<uintptr_t, size_t> g_host_blocks;
 rwkv_status rwkv_host_alloc(size_t bytes, void **out) {
     return guard([&] {
         if (!out || bytes == 0) throw RwkvError(RWKV_ERR_INVALID, "bad arguments");
         void *p = nullptr;
         HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        { std::lock_guard<std::mutex> g(g_host_mu); g_host_blocks[(uintptr_t)p] = bytes; }
         *out = p;
     });
 }
-void rwkv_host_free(void *p) { if (p) (void)hipHostFree(p); }
+void rwkv_host_free(void *p) {
+    if (!p) return;
+    { std::lock_guard<std::mutex> g(g_host_mu); g_host_blocks.erase((uintptr_t)p); }
+    (void)hipHostFree(p);
+}
+// bytes from `p` to the end of the pinned block that holds it: from the registry above, else (memory the caller pinned itself) from the
+// HIP runtime's address-range query; 0 = unknown
+static size_t pinned_bytes_left(const void *p) {
+    {
+        std::lock_guard<std::mutex> g(g_host_mu);
+        auto it = g_host_blocks.upper_bound((uintptr_t)p);
+        if (it != g_host_blocks.begin()) {
+            --it;
+            if ((uintptr_t)p < it->first + it->second) return it->first + it->second - (uintptr_t)p;
+        }
+    }
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && base && (uintptr_t)p >= (uintptr_t)base && (uintptr_t)p < (uintptr_t)base + size)
+        return (uintptr_t)base + size - (uintptr_t)p;
+    (void)hipGetLastError();
+    return 0;
+}
 
 rwkv_status rwkv_infer(rwkv_engine *e, const rwkv_slot_input *in, rwkv_slot_output *out) {
     return guard([&] {
@@ -1764,6 +1814,10 @@ rwkv_status rwkv_state_back_layer_async(rwkv_engine *e, int32_t slot, int32_t la
             throw RwkvError(RWKV_ERR_INVALID, "rwkv_state_back_layer_async: dst must be pinned host memory (rwkv_host_alloc)");
         }
         const size_t n = (size_t)64 * e->info.num_emb;
+        {
+            const size_t left = pinned_bytes_left(dst);
+            if (left && left < n * 4) throw RwkvError(RWKV_ERR_INVALID, "rwkv_state_back_layer_async: the rows would end " + std::to_string(n * 4 - left) + " bytes past the pinned block that holds dst");
+        }
         if (!e->s_copy) {
             HIP_CHECK(hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&e->ev_copy_a, hipEventDisableTiming));

@@ -2975,7 +2975,7 @@ void launch_f16_to_f32(const _Float16 *in, float *out, long n, int op, hipStream
 }
 
 // LoRA on a non-matrix tensor (`LoraBlend::full(alpha)` matches every tensor, lib.rs:466-482): a LoRA file that carries a tensor of
-// the SAME name blends it in whole, v += alpha * l, on the fp32 copy and BEFORE any load-time transform (op 1: exp(-exp(v))).
+// the SAME name blends it in whole, v = alpha * l + (1 - alpha) * v (a lerp, like the matrices' W += alpha B A^T only for alpha = 1), on the fp32 copy and BEFORE any load-time transform (op 1: exp(-exp(v))).
 __global__ void vec_blend_kernel(float *v, const _Float16 *l, long n, float alpha) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) v[i] = alpha * (float)l[i] + (1.0f - alpha) * v[i];
 }

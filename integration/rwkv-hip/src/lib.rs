@@ -104,6 +104,10 @@ impl Engine {
     /// `Full` slots of 100 tokens at chunk 128 emit 128 rows together, not 200); a `Full` slot emits one row per consumed token, a
     /// `Last` slot one row when the call exhausts its tokens, a `None` slot nothing.  The sum is <= token_chunk_size + max_batch.
     pub fn plan_rows(&self, input: &[SlotInput]) -> Result<Vec<usize>> {
+        // `rwkv_plan_chunk` reads `max_batch` entries: a shorter slice would be an out-of-bounds read behind a safe signature
+        if input.len() != self.max_batch {
+            return Err(Error { code: sys::RWKV_ERR_INVALID, message: format!("plan_rows: {} slot inputs for max_batch {}", input.len(), self.max_batch) });
+        }
         let pending: Vec<usize> = input.iter().map(|s| s.tokens.len()).collect();
         let mut take = vec![0i32; input.len()];
         check(unsafe { sys::rwkv_plan_chunk(self.max_batch as i32, self.token_chunk_size as i32, pending.as_ptr(), take.as_mut_ptr()) })?;
@@ -169,17 +173,19 @@ impl Engine {
         let mut v = vec![0f32; (self.info.head_size * self.info.num_emb) as usize];
         check(unsafe { sys::rwkv_state_back_layer(self.raw, slot as i32, layer as i32, v.as_mut_ptr()) })?; Ok(v)
     }
-    /// The same rows, not waited for: they land in `dst` (pinned: `PinnedLogits`) at float offset `at`, valid after `state_sync()`.
-    /// The slot may take its next request at once — a finished document's read-back overlaps the prefill of the following ones.
-    /// `&mut` keeps safe code from reading the block before the sync that follows.
-    pub fn state_back_layer_async(&self, slot: usize, layer: usize, dst: &mut PinnedLogits, at: usize) -> Result<()> {
-        let n = (self.info.head_size * self.info.num_emb) as usize;
-        if at.checked_add(n).map_or(true, |end| end > dst.floats) {
-            return Err(Error { code: sys::RWKV_ERR_INVALID, message: format!("pinned block holds {} floats, rows need {}..{}", dst.floats, at, at.saturating_add(n)) });
-        }
-        check(unsafe { sys::rwkv_state_back_layer_async(self.raw, slot as i32, layer as i32, dst.ptr.add(at)) })
+    /// The same rows, not waited for: they land in the pinned block at float offset `at` and are valid after the copy stream has been
+    /// waited for.  The slot may take its next request at once — a finished document's read-back overlaps the prefill of the following
+    /// ones.  Soundness: while a device-to-host copy is in flight the block must be neither read nor freed, and a `&mut` argument alone
+    /// does not say that (its borrow ends when the call returns).  So the call hands back a `PendingRows` guard that KEEPS the mutable
+    /// borrow of `dst` (and a borrow of the engine): safe code cannot touch, move or drop the block until the guard is consumed by
+    /// `PendingRows::sync()` — and dropping the guard without calling it waits too.  Several read-backs into ONE block go through
+    /// `PendingRows::also` (disjoint ranges are checked), so the borrow is still held exactly once.
+    pub fn state_back_layer_async<'a>(&'a self, slot: usize, layer: usize, dst: &'a mut PinnedLogits, at: usize) -> Result<PendingRows<'a>> {
+        let mut p = PendingRows { rt: self, dst, ranges: Vec::new(), waited: false };
+        p.issue(slot, layer, at)?;
+        Ok(p)
     }
-    /// waits for every pending `state_back_layer_async`
+    /// waits for every pending `state_back_layer_async` (what `PendingRows::sync` calls; harmless when nothing is pending)
     pub fn state_sync(&self) -> Result<()> { check(unsafe { sys::rwkv_state_sync(self.raw) }) }
     /// `vN::read_state` (lib.rs:378-389); `Error.code == RWKV_ERR_NO_STATE` <-> the warning at lib.rs:442
     pub fn read_init_state(&self, st: &[u8]) -> Result<Vec<f32>> {
@@ -192,6 +198,42 @@ impl Engine {
         let out: Vec<*mut f32> = rows.iter_mut().map(|r| r.as_mut_ptr()).collect();
         check(unsafe { sys::rwkv_softmax(self.raw, inp.as_ptr(), out.as_ptr(), rows.len()) })
     }
+}
+
+/// Read-backs in flight into one pinned block (`Runtime::state_back_layer_async`).  Holds the block's mutable borrow until the copy
+/// stream has been waited for: `sync()` gives the block back; `Drop` waits as well, so no path — early return, `?`, panic unwinding —
+/// lets the block be read or freed under the DMA.
+pub struct PendingRows<'a> {
+    rt: &'a Runtime,
+    dst: &'a mut PinnedLogits,
+    ranges: Vec<(usize, usize)>,
+    waited: bool,
+}
+impl<'a> PendingRows<'a> {
+    fn issue(&mut self, slot: usize, layer: usize, at: usize) -> Result<()> {
+        let n = (self.rt.info.head_size * self.rt.info.num_emb) as usize;
+        let end = match at.checked_add(n) { Some(e) if e <= self.dst.floats => e, _ => {
+            return Err(Error { code: sys::RWKV_ERR_INVALID, message: format!("pinned block holds {} floats, rows need {}..{}", self.dst.floats, at, at.saturating_add(n)) }) } };
+        if self.ranges.iter().any(|&(a, b)| at < b && a < end) {
+            return Err(Error { code: sys::RWKV_ERR_INVALID, message: format!("rows {}..{} overlap a read-back already in flight into this block", at, end) });
+        }
+        check(unsafe { sys::rwkv_state_back_layer_async(self.rt.raw, slot as i32, layer as i32, self.dst.ptr.add(at)) })?;
+        self.ranges.push((at, end));
+        Ok(())
+    }
+    /// one more slot's rows into the same block (a disjoint range), still under the one borrow
+    pub fn also(&mut self, slot: usize, layer: usize, at: usize) -> Result<()> { self.issue(slot, layer, at) }
+    /// wait for the copies; the block is the caller's again
+    pub fn sync(mut self) -> Result<&'a mut PinnedLogits> {
+        let r = self.rt.state_sync();
+        self.waited = true;
+        // SAFETY: `self` is consumed and its Drop (below) does nothing once `waited`; the reference is re-borrowed for the original lifetime
+        let dst: *mut PinnedLogits = self.dst;
+        r.map(|_| unsafe { &mut *dst })
+    }
+}
+impl Drop for PendingRows<'_> {
+    fn drop(&mut self) { if !self.waited { let _ = self.rt.state_sync(); } }
 }
 
 /// `Tokenizer` (lib.rs:375; run.rs:157-168, 856; sampler/bnf.rs:14-27)

@@ -1,7 +1,8 @@
 set -x
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_knobs.py -x -q -k "ROWJOB or NO_DENSE" 2>&1 | tail -5 > gpurun_out/r5_t1.log
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "decode or greedy or v7 or 256" 2>&1 | tail -5 >> gpurun_out/r5_t1.log
+rm -f gpurun_out/full_depth_errors.jsonl
+timeout 1500 python -m pytest tests/test_gpu_full_depth.py -x -q -s -k "promoted or (embeddings and v7)" 2>&1 | grep -v '^$' | tail -25 > gpurun_out/r5_t1.log
+timeout 600 python -m pytest tests/test_gpu_embeddings.py -x -q 2>&1 | tail -5 >> gpurun_out/r5_t1.log
 cat gpurun_out/r5_t1.log
-timeout 600 python scripts/ab_bench.py "v6 rowjob-wt::" "v6 norowjob:RWKV_ROWJOB=0:" 2>&1 | tee gpurun_out/r5_ab_rowjob.log
-AB_WORKLOAD=v7-2.9b AB_QUANT=nf4 timeout 600 python scripts/ab_bench.py "v7 rowjob-wt::" "v7 norowjob:RWKV_ROWJOB=0:" 2>&1 | tee -a gpurun_out/r5_ab_rowjob.log
+AB_WORKLOAD=v7-2.9b AB_QUANT=nf4 timeout 600 python scripts/ab_bench.py "v7 fp16::" "v7 promote7:RWKV_PROMOTE=7:" 2>&1 | tee gpurun_out/r5_ab_promote.log
+timeout 600 python scripts/ab_bench.py "v6 fp16::" "v6 promote5:RWKV_PROMOTE=5:" 2>&1 | tee -a gpurun_out/r5_ab_promote.log

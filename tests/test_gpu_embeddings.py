@@ -203,6 +203,18 @@ def test_state_job_with_slot_turnover_and_async_read_back(ver, quant):
     np.testing.assert_array_equal(arena.array, sync_copy)
     with pytest.raises(rt.RwkvError):                                      # pageable memory is refused, not silently staged
         eng.state.embed_async(layer, 0, np.empty((64, C), np.float32))
+    # the rows must END inside the pinned block they start in (advisor, round 4): an offset that leaves less than 64 x C floats is an
+    # RWKV_ERR_INVALID, not a DMA past the block; the last position that fits is fine
+    big = rt.PinnedArena((2, 64, C))
+    flat = big.array.reshape(-1)
+    with pytest.raises(rt.RwkvError):
+        eng.state.embed_async(layer, 0, flat[64 * C + 1:])
+    with pytest.raises(rt.RwkvError):
+        eng.state.embed_async(layer, 0, flat[2 * 64 * C - 8:])
+    eng.state.embed_async(layer, 0, flat[64 * C:])
+    eng.state.sync()
+    np.testing.assert_array_equal(big.array[1], eng.state.embed(layer, 0))
+    big.close()
     arena.close()
     job.close()
     eng.close()
