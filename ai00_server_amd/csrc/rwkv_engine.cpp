@@ -192,7 +192,6 @@ struct ProbSpec {
     int ldo = 0;
     bool partial = false;           // out = partial-sum buffer, K may be split across blocks
     Opd oh;                         // optional operand output
-    const float *lnp_mu = nullptr;  // LN-prologue launches: the token-shift mix vector of this problem (x unused)
 };
 
 enum Family { FAM_GEMM = 0, FAM_HEAD = 1, FAM_ROW = 2, FAM_WKV = 3, FAM_SAMPLE = 4, FAM_COPY = 5 };
@@ -389,11 +388,10 @@ struct rwkv_engine {
     }
 
     void load(const rwkv_load_desc &d);
-    int gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs *lnp = nullptr, const ShiftCommit *commit = nullptr, int cls = CLS_NONE);
+    int gemm(std::vector<ProbSpec> &ps, int T, int fam, const ShiftCommit *commit = nullptr, int cls = CLS_NONE);
     void log_gemm(const std::vector<ProbSpec> &ps, int T, int fam, const char *kind, int variant, int grid, int ksplit, int threads);
     void log_row(const char *kernel, int T, long grid, double bytes);   // RWKV_LAUNCH_LOG: algorithmic bytes of a non-GEMM launch of layer 0 / 1
-    bool ln_fusable(std::vector<ProbSpec> &ps, int T, int np, int cls = CLS_NONE);
-    float *lnp_xx_att = nullptr, *lnp_xx_ffn = nullptr;   // normalised rows published by an LN-prologue launch (for the commit)
+    float *lnp_xx_att = nullptr;                          // normalised rows published by the V6 mix's LN-prologue launch (for the commit)
     void plan_step(const rwkv_slot_input *in, StepPlan &pl);
     void upload_plan(const StepPlan &pl);
     void run_layers(int T, int n_seq, int n_out, const int *d_token, bool dense);
@@ -778,7 +776,7 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
     pstride = (long)TC;
     xA = dalloc<float>(TC); xB = dalloc<float>(TC); P = dalloc<float>(TC * 8);
     xx = dalloc<float>(TC); dx = dalloc<float>(TC);
-    lnp_xx_att = dalloc<float>((size_t)LNP_MAX_T * C); lnp_xx_ffn = dalloc<float>((size_t)LNP_MAX_T * C);
+    lnp_xx_att = dalloc<float>((size_t)LNP_MAX_T * C);
     fr = dalloc<float>(TC); fk = dalloc<float>(TC); fv = dalloc<float>(TC); fg = dalloc<float>(TC); frr = dalloc<float>(TC);
     ftd = dalloc<float>((size_t)chunk * 128);
     if (info.version == 7) {
@@ -826,7 +824,6 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
     int NT, KSW;
     gemm_variant(T, hilo, NT, KSW);
     const int KW = KSW * 32;
-    const int f_spb = knobs().spb, f_ksb = knobs().ksb;
     long total_strips = 0;
     for (auto &s : ps) total_strips += s.W->rows / 16;
     int blocks = 0, np = 1, max_nw = 1, lds_items = 1;
@@ -850,7 +847,6 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
             }
             if (!best) throw RwkvError(RWKV_ERR_UNSUPPORTED, "cannot split inner dimension");
             ksb = best;
-            if (f_ksb && f_ksb <= 8 && valid(f_ksb)) ksb = f_ksb;         // the partial-sum buffer holds 8 slabs (an override of 10 once wrote past it)
         }
         const int Kb = K / ksb;
         const int nslice = (Kb + KW - 1) / KW;                 // balanced: every wave owns the same number of slices
@@ -865,7 +861,7 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
         if ((total_strips * ksb + spb - 1) / spb > 1024) spb = 8;            // huge matrices (head): long pipelined blocks
         else if (spb * sub > maxr && strips * ksb <= 64) spb = std::max(1, maxr / sub);   // tiny member of a group
         spb = std::max(1, std::min(spb, 8));
-        if (force_spb) spb = force_spb; else if (f_spb) spb = f_spb;
+        if (force_spb) spb = force_spb;
         spb = std::min(spb, std::max(1, 150 / (nw * NT)));                     // LDS: spb*nw*NT KiB <= 150 KiB
         g.W = s.W->data; g.S = s.W->scales; g.fmt = s.W->fmt; g.rows = s.W->rows; g.K = K;
         g.xhi = s.x.hi + (s.xoff >> 5) * 512; g.xlo = s.x.lo ? s.x.lo + (s.xoff >> 5) * 512 : nullptr; g.ldx = s.x.ld;   // column offset = whole k-tiles
@@ -877,7 +873,6 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
         g.act = s.act; g.post = s.post; g.bias = s.bias; g.m0 = s.m0; g.m1 = s.m1; g.ldm = s.ldm;
         g.out_f32 = s.out; g.ldo = s.ldo; g.partial_stride = pstride;
         g.out_hi = s.oh.hi; g.out_lo = s.oh.lo; g.ldh = s.oh.ld;
-        g.lnp_mu = s.lnp_mu;
         max_nw = std::max(max_nw, nw);
         if (spb * sub > maxr) shot = false;
         if (Kb % 256) tail = true;
@@ -901,31 +896,40 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
     return np;
 }
 
-// Can this launch carry the LayerNorm + token-shift prologue (rwkv_kernels.h LnProArgs)?  Single-token steps in
-// Fp16 mode whose every problem walks K = C with one slice per wave and the same wave count (the prologue is a
-// block-wide cooperative pass), with room in LDS for the rows.
-bool rwkv_engine::ln_fusable(std::vector<ProbSpec> &ps, int T, int np, int cls) {
-    const int off = kn.no_ln_fuse;
-    if (off || wide(cls) || T > LNP_MAX_T || np > LNP_MAX_NP) return false;
-    int NT, KSW;
-    gemm_variant(T, hilo, NT, KSW);
-    if (NT != 1 || KSW != 16) return false;
-    const int C = info.num_emb;
-    for (auto &s : ps) if (s.W->K != C || s.partial) return false;
-    GemmLaunch Lh;
-    plan_gemm(Lh, ps, T, hilo, pstride);
-    for (int i = 0; i < Lh.nprob; ++i) {
-        const GemmProb &g = Lh.p[i];
-        if (g.ksb != 1 || g.nw * 64 != Lh.threads || (C + KSW * 32 - 1) / (KSW * 32) > g.nw) return false;
-    }
-    if (C > 8 * Lh.threads || C % 32) return false;
-    return (size_t)Lh.lds_items * NT * 1024 + lnp_lds_bytes(T, C, hilo) <= 150 * 1024;
-}
-
-int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs *lnp, const ShiftCommit *commit, int cls) {
+int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const ShiftCommit *commit, int cls) {
     GemmLaunch Lh;
     const bool hilo = wide(cls);                                 // shadows the engine-wide flag: this launch's operand width
-    if (hilo && !lnp) for (auto &sp : ps) if (!sp.x.lo) throw RwkvError(RWKV_ERR_INVALID, "gemm: a hi + lo launch needs the lo part of every operand");
+    if (hilo) for (auto &sp : ps) if (!sp.x.lo) throw RwkvError(RWKV_ERR_INVALID, "gemm: a hi + lo launch needs the lo part of every operand");
+    // launches whose every matrix is short in K (V7's second LoRA stage): the output-stationary small-K kernel, whatever the step's rows
+    // (a launch that has to carry a token-shift commit keeps the decode kernel: the commit rides on its extra block)
+    // Decode-shaped steps only: at 32 rows 6.4 -> ~5.5 us (V7-2.9B: -1.0 / -1.7 / -1.7 % per step at 32 / 8 / 1 slots); at 256 and 2048 rows
+    // the tile kernels, which share X through LDS, are as fast (profiles/r5_exp_smallk_ab.log).
+    if (T <= 64 && !(commit && commit->src) && !ps.empty() && ps.size() <= GEMM_MAXP) {
+        Lh = GemmLaunch{};
+        Lh.nprob = (int)ps.size();
+        Lh.T = T;
+        int items = 0;
+        bool ok = true;
+        for (size_t i = 0; i < ps.size() && ok; ++i) {
+            const ProbSpec &sp = ps[i];
+            GemmProb &g = Lh.p[i];
+            ok = !sp.partial && sp.xoff == 0;
+            g.W = sp.W->data; g.S = sp.W->scales; g.fmt = sp.W->fmt; g.rows = sp.W->rows; g.K = sp.W->K;
+            g.xhi = sp.x.hi; g.xlo = sp.x.lo; g.ldx = sp.x.ld;
+            g.spb = 1; g.nw = 1; g.ksb = 1; g.Kb = g.K; g.nslice = 1; g.nblk_strip = g.rows / 16;
+            g.block_begin = items;
+            items += g.rows / 16;
+            g.act = sp.act; g.post = sp.post; g.bias = sp.bias; g.m0 = sp.m0; g.m1 = sp.m1; g.ldm = sp.ldm;
+            g.out_f32 = sp.out; g.ldo = sp.ldo; g.partial_stride = pstride;
+            g.out_hi = sp.oh.hi; g.out_lo = sp.oh.lo; g.ldh = sp.oh.ld;
+        }
+        Lh.total_blocks = items;
+        if (ok && smallk_supported(Lh)) {
+            log_gemm(ps, T, fam, "smallk", 0, (items + 3) / 4, 1, 256);
+            launch(fam, [&] { launch_smallk(Lh, hilo, s_main); });
+            return 1;
+        }
+    }
     const int no_tile = kn.no_tile;
     if (T >= GEMM_TILE_MIN_T && !no_tile) {
         // prefill: LDS-tiled MFMA GEMM, no K split (partial problems write one slab)
@@ -950,7 +954,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         // profiles/r3_exp_tile_128x64.log
         bool all_nf4 = true;
         for (auto &s : ps) all_nf4 = all_nf4 && s.W->fmt == W_NF4;
-        if (all_nf4 && tot64 >= kn.nf4_kc128_min) shape = 3;
+        if (all_nf4 && tot64 >= 512) shape = 3;
         // the direct-to-LDS 128x64 shape (7: two strips per wave, X tiles by global_load_lds) pays only for very large
         // grids: 7B fp16 prefill at chunk 1024 25.9 -> 27.5 k tok/s, but 21.3 -> 17.8 k at chunk 512; the 256x128
         // GLDS shape (9) wins isolated large fp16 GEMMs (404 -> 536 TFLOP/s) and loses the model (small matrices starve)
@@ -970,9 +974,9 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         {
             long t3 = 0;
             for (auto &sp : ps) { t3 += gemm_tile_blocks(GEMM_TILE3, sp.W->rows, T); ok3 = ok3 && gemm_tile3_supported(hilo, sp.W->K); }
-            const long fill_min = kn.tile3_fill;
+            const long fill_min = 60;
             const long rounds = (t3 + 511) / 512;
-            if (ok3 && fill_min > 0 && t3 >= kn.tile3_min_tiles && t3 * 100 >= fill_min * rounds * 512) shape = GEMM_TILE3;
+            if (ok3 && t3 >= 300 && t3 * 100 >= fill_min * rounds * 512) shape = GEMM_TILE3;
         }
         // The pipelined kernel on 128 x 64 tiles (shape 11, round 4) for the NON-linear launches of steps the 128-token tile cannot fill:
         // at 256 rows a 10304-row launch is 160 tiles of 128 x 128 (fewer than CUs) but 324 of 128 x 64, each prefetching four stages
@@ -990,7 +994,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
                 big_not_nf4 = big_not_nf4 || sp.W->fmt != W_NF4;
             }
             const bool in_range = big_f16 ? (T > 320 && T <= 768) : (T <= 320 || (!big_not_nf4 && T > 768 && T <= 1280));
-            if (ok3 && kn.tile3_64 && !linear_launch && in_range) shape = GEMM_TILE3_64;
+            if (ok3 && !linear_launch && in_range) shape = GEMM_TILE3_64;
         }
         if (f_shape >= 0 && f_shape < GEMM_TILE_SHAPES && ((f_shape != GEMM_TILE3 && f_shape != GEMM_TILE3_64) || ok3)) shape = f_shape;
         // K split of a linear launch on the pipelined kernel (Wo, Fv: one `partial` problem whose output the next row kernel sums
@@ -998,7 +1002,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         // until the rounds are full — 3 x 320 tiles (V6-3B at 2048 rows) fill 94 % of two rounds a third as long (tg3_body).
         int ksplit = 1;
         if (ok3 && kn.tile_ksplit && ps.size() == 1 && ps[0].partial && ps[0].post != POST_MIX && ps[0].act == ACT_NONE && !ps[0].bias &&
-            !ps[0].oh.hi && (f_shape < 0 || f_shape == GEMM_TILE3 || f_shape == GEMM_TILE3_64) && kn.tile3_fill > 0) {
+            !ps[0].oh.hi && (f_shape < 0 || f_shape == GEMM_TILE3 || f_shape == GEMM_TILE3_64)) {
             const long t3 = gemm_tile_blocks(GEMM_TILE3, ps[0].W->rows, T);
             const int G = ps[0].W->K / 128;
             double best = shape == GEMM_TILE3 ? (double)t3 / (((t3 + 511) / 512) * 512) : 0.0;
@@ -1039,7 +1043,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
             g.out_hi = s.oh.hi; g.out_lo = s.oh.lo; g.ldh = s.oh.ld;
         }
         Lh.total_blocks = blocks;
-        Lh.xcd_map = kn.tile_xcd;                                   // A/B switch
+        Lh.xcd_map = 1;                                             // XCD-banded tile numbering (rwkv_kernels.hip tg_body)
         {   // block size of the tile shape (rwkv_kernels.hip TG_SH; the pipelined kernel runs 256 threads): the profile joins on it
             static const int waves[10] = {8, 8, 4, 4, 4, 8, 4, 4, 4, 8};
             log_gemm(ps, T, fam, "tile", shape, blocks, ksplit, shape < 10 ? waves[shape] * 64 : 256);
@@ -1048,7 +1052,6 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const LnProArgs
         return ksplit;
     }
     const int np = plan_gemm(Lh, ps, T, hilo, pstride);
-    if (lnp) Lh.lnp = *lnp;
     if (commit) Lh.commit = *commit;
     log_gemm(ps, T, fam, "decode", Lh.single_shot, Lh.total_blocks + (Lh.commit.src ? 1 : 0), np, Lh.threads);
     launch(fam, [&] { launch_gemm(Lh, hilo, s_main); });
@@ -1243,22 +1246,15 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
             for (int i = 0; i < 4; ++i) { a.mu[i] = w.mu[i]; a.ohi[i] = aA[i].hi; a.olo[i] = aA[i].lo; }
             ps = {prob(w.Wk, aA[0], ACT_NONE, fk, C), prob(w.Wv, aA[1], ACT_NONE, fv, C),
                   prob(w.Wr, aA[2], ACT_NONE, fr, C), prob(w.Wg, aA[3], ACT_SILU, fg, C)};
-            for (int i = 0; i < 4; ++i) ps[i].lnp_mu = w.mu[i];
-            if ((att_fused = ln_fusable(ps, T, np, CLS_ATT))) {
-                LnProArgs lp = ln_pro(a, lnp_xx_att);
-                gemm(ps, T, FAM_GEMM, &lp, nullptr, CLS_ATT);
-            } else {
-                { launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); }); log_ln(a); }
-                gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_ATT);
-            }
+            { launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); }); log_ln(a); }
+            gemm(ps, T, FAM_GEMM, nullptr, CLS_ATT);
         } else if (info.version == 6) {
             a.mode = 1; a.nmix = 1; a.mu[0] = w.mu[0]; a.ohi[0] = aZ.hi; a.olo[0] = aZ.lo;
             a.xx_out = xx; a.dx_out = dx;
             const int no_fuse = kn.no_v6_fuse, no_ln_fuse = kn.no_ln_fuse;
             att_fused = !no_fuse && !no_ln_fuse && v6_mix_ln_supported(T, C, Dm, hilo, np);
             if (!att_fused) { launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); }); log_ln(a); }
-            const int no_wide = kn.no_v6_wide;                      // A/B: two tile-GEMM launches instead of the wide fused form
-            if ((v6_mix_supported(T, C, Dm) || (v6_mix_wide_supported(T, C, Dm) && !no_wide)) && !no_fuse) {
+            if ((v6_mix_supported(T, C, Dm) || v6_mix_wide_supported(T, C, Dm)) && !no_fuse) {
                 // fused: x_c = xx + dx * (mu_c + W2_c tanh(W1_c z)) in one launch
                 V6MixArgs m{};
                 m.W1 = w.W1->data;
@@ -1291,32 +1287,25 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
             ps = {prob(w.Wk, aA[2], ACT_NONE, fk, C), prob(w.Wv, aA[3], ACT_NONE, fv, C),
                   prob(w.Wr, aA[4], ACT_NONE, fr, C), prob(w.Wg, aA[5], ACT_SILU, fg, C),
                   prob(w.D1, aA[1], ACT_TANH, ftd, Dd)};
-            if (att_fused) { ShiftCommit cm = commit_of(a, lnp_xx_att); gemm(ps, T, FAM_GEMM, nullptr, &cm, CLS_ATT); att_fused = false; }
-            else gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_ATT);
+            if (att_fused) { ShiftCommit cm = commit_of(a, lnp_xx_att); gemm(ps, T, FAM_GEMM, &cm, CLS_ATT); att_fused = false; }
+            else gemm(ps, T, FAM_GEMM, nullptr, CLS_ATT);
         } else {
             a.mode = 1; a.nmix = 6;
             for (int i = 0; i < 6; ++i) { a.mu[i] = w.mu[i]; a.ohi[i] = aA[i].hi; a.olo[i] = aA[i].lo; }
             // opA: 0=r 1=w 2=k 3=v 4=a 5=g
             ps = {prob(w.Wr, aA[0], ACT_NONE, fr, C), prob(w.Wk, aA[2], ACT_NONE, fk, C), prob(w.Wv, aA[3], ACT_NONE, fv, C)};
-            ps[0].lnp_mu = w.mu[0]; ps[1].lnp_mu = w.mu[2]; ps[2].lnp_mu = w.mu[3];
-            { ProbSpec s = prob(w.w1, aA[1], ACT_TANH, nullptr, 0); s.oh = aL[0]; s.lnp_mu = w.mu[1]; ps.push_back(s); }
-            { ProbSpec s = prob(w.a1, aA[4], ACT_NONE, nullptr, 0); s.oh = aL[1]; s.lnp_mu = w.mu[4]; ps.push_back(s); }
-            { ProbSpec s = prob(w.g1, aA[5], ACT_SIGMOID, nullptr, 0); s.oh = aL[2]; s.lnp_mu = w.mu[5]; ps.push_back(s); }
-            if (l > 0) { ProbSpec s = prob(w.v1, aA[3], ACT_NONE, nullptr, 0); s.oh = aL[3]; s.lnp_mu = w.mu[3]; ps.push_back(s); }
-            if ((att_fused = ln_fusable(ps, T, np, CLS_ATT))) {
-                LnProArgs lp = ln_pro(a, lnp_xx_att);
-                gemm(ps, T, FAM_GEMM, &lp, nullptr, CLS_ATT);
-            } else {
-                { launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); }); log_ln(a); }
-                gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_ATT);
-            }
+            { ProbSpec s = prob(w.w1, aA[1], ACT_TANH, nullptr, 0); s.oh = aL[0]; ps.push_back(s); }
+            { ProbSpec s = prob(w.a1, aA[4], ACT_NONE, nullptr, 0); s.oh = aL[1]; ps.push_back(s); }
+            { ProbSpec s = prob(w.g1, aA[5], ACT_SIGMOID, nullptr, 0); s.oh = aL[2]; ps.push_back(s); }
+            if (l > 0) { ProbSpec s = prob(w.v1, aA[3], ACT_NONE, nullptr, 0); s.oh = aL[3]; ps.push_back(s); }
+            { launch(FAM_ROW, [&] { launch_ln_shift(a, T, s_main); }); log_ln(a); }
+            gemm(ps, T, FAM_GEMM, nullptr, CLS_ATT);
             ps.clear();
             { ProbSpec s = prob(w.w2, aL[0], ACT_DECAY7, fw7, C); s.bias = w.w0; ps.push_back(s); }
             { ProbSpec s = prob(w.a2, aL[1], ACT_SIGMOID, fa7, C); s.bias = w.a0; ps.push_back(s); }
             { ProbSpec s = prob(w.g2, aL[2], ACT_NONE, fg, C); ps.push_back(s); }
             if (l > 0) { ProbSpec s = prob(w.v2, aL[3], ACT_SIGMOID, fvg7, C); s.bias = w.v0; ps.push_back(s); }
-            if (att_fused) { ShiftCommit cm = commit_of(a, lnp_xx_att); gemm(ps, T, FAM_GEMM, nullptr, &cm, CLS_LORA2); att_fused = false; }
-            else gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_LORA2);
+            gemm(ps, T, FAM_GEMM, nullptr, CLS_LORA2);
         }
         std::swap(cur, oth);
         {
@@ -1340,8 +1329,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
             ProbSpec s = prob(w.Wo, aY, ACT_NONE, P, C);
             s.partial = true;
             ps = {s};
-            if (att_fused) { ShiftCommit cm = commit_of(a, lnp_xx_att); np = gemm(ps, T, FAM_GEMM, nullptr, &cm, CLS_WO); }
-            else np = gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_WO);
+            np = gemm(ps, T, FAM_GEMM, nullptr, CLS_WO);
         }
         // ---- channel mix
         LnShiftArgs f{};
@@ -1352,19 +1340,13 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
         f.mode = info.version == 5 ? 0 : 1;
         f.nmix = info.version == 7 ? 1 : 2;
         for (int i = 0; i < f.nmix; ++i) { f.mu[i] = w.fmu[i]; f.ohi[i] = aF[i].hi; f.olo[i] = aF[i].lo; }
-        bool ffn_fused = false;
         {
             ProbSpec s = prob(w.Fk, aF[0], ACT_RELU2, nullptr, 0);
-            s.oh = aK; s.lnp_mu = w.fmu[0];
+            s.oh = aK;
             ps = {s};
-            if (info.version != 7) { ProbSpec r = prob(w.Fr, aF[1], ACT_SIGMOID, frr, C); r.lnp_mu = w.fmu[1]; ps.push_back(r); }
-            if ((ffn_fused = ln_fusable(ps, T, np, CLS_FFN1))) {
-                LnProArgs lp = ln_pro(f, lnp_xx_ffn);
-                gemm(ps, T, FAM_GEMM, &lp, nullptr, CLS_FFN1);
-            } else {
-                { launch(FAM_ROW, [&] { launch_ln_shift(f, T, s_main); }); log_ln(f); }
-                gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_FFN1);
-            }
+            if (info.version != 7) { ProbSpec r = prob(w.Fr, aF[1], ACT_SIGMOID, frr, C); ps.push_back(r); }
+            { launch(FAM_ROW, [&] { launch_ln_shift(f, T, s_main); }); log_ln(f); }
+            gemm(ps, T, FAM_GEMM, nullptr, CLS_FFN1);
             std::swap(cur, oth);
         }
         {
@@ -1372,8 +1354,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
             s.partial = true;
             if (info.version != 7) { s.post = POST_MUL; s.m0 = frr; s.ldm = C; }
             ps = {s};
-            if (ffn_fused) { ShiftCommit cm = commit_of(f, lnp_xx_ffn); np = gemm(ps, T, FAM_GEMM, nullptr, &cm, CLS_FV); }
-            else np = gemm(ps, T, FAM_GEMM, nullptr, nullptr, CLS_FV);
+            np = gemm(ps, T, FAM_GEMM, nullptr, CLS_FV);
         }
     }
     if (n_out > 0) {
@@ -1383,7 +1364,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
         launch(FAM_ROW, [&] { launch_ln_out(o, n_out, s_main); });
         std::vector<ProbSpec> ps(1);
         ps[0].W = head; ps[0].x = aO; ps[0].out = logits; ps[0].ldo = V;
-        gemm(ps, n_out, FAM_HEAD, nullptr, nullptr, CLS_HEAD);
+        gemm(ps, n_out, FAM_HEAD, nullptr, CLS_HEAD);
     } else if (np > 0) {
         // nothing consumes the pending partial sums: fine, the residual stream dies with the step
     }
@@ -2054,7 +2035,7 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
                     g.xhi = x.hi; g.xlo = x.lo; g.ldx = K; g.ksb = 1; g.block_begin = 0;
                     g.out_f32 = out; g.ldo = rows;
                     Lh.total_blocks = gemm_tile_blocks(shape, rows, T);
-                    Lh.xcd_map = knobs().tile_xcd;
+                    Lh.xcd_map = 1;
                     if (lds_kib) *lds_kib = (float)Lh.total_blocks;
                     launch_gemm_tile(Lh, shape, hilo != 0, run_st);
                     continue;

@@ -14,21 +14,13 @@ enum Post : int { POST_NONE = 0, POST_MUL = 1, POST_MIX = 2 };
 // is created, and installed for the thread that drives the engine (`use_knobs`): every step of an engine, and every graph it
 // captured, sees the same choices whatever the environment does later.  Defaults are the product.  DESIGN.md 4.1.
 struct Knobs {
-    int spb = 0, ksb = 0;            // RWKV_SPB / RWKV_KSB: strips per block, K split of the decode GEMM planner (0 = planner's choice)
-    int ksw8 = 1;                    // RWKV_KSW8: T <= 16 steps run 256-k waves (ten per block); 0 = 512-k waves (five)
-    int no_ln_fuse = 0;              // RWKV_NO_LN_FUSE: row kernels instead of the LayerNorm prologue on single-token steps
-    int no_v6_fuse = 0, no_v6_wide = 0, v6mix_split = 0;   // RWKV_NO_V6_FUSE / RWKV_NO_V6_WIDE / RWKV_V6MIX_SPLIT
-    int no_tile = 0, tile_shape = -1, tile3_fill = 60, tile_xcd = 1;   // RWKV_NO_TILE / RWKV_TILE_SHAPE / RWKV_TILE3_FILL / RWKV_TILE_XCD
-    int tile_ksplit = 1;             // RWKV_TILE_KSPLIT: K split of linear launches on the pipelined prefill kernel (0 = off)
+    int no_ln_fuse = 0;              // RWKV_NO_LN_FUSE: the ln_shift row kernel instead of the LayerNorm prologue of the V6 mix on single-token steps
+    int no_v6_fuse = 0;              // RWKV_NO_V6_FUSE: the V6 token-shift LoRA as two GEMM launches instead of v6_mix_kernel
+    int no_tile = 0, tile_shape = -1;   // RWKV_NO_TILE: the decode GEMM for every step; RWKV_TILE_SHAPE=0..11: force a prefill tile shape (parity of every shape)
     int no_dense = 0;                // RWKV_NO_DENSE: general row metadata on dense decode steps
-    int ln_256 = 0;                  // RWKV_LN_256: 256-thread ln_shift everywhere
-    int tile3_64 = 1;                // RWKV_TILE3_64: the pipelined kernel on 128 x 64 tiles for non-linear launches of 256- / 1024-row steps (0 = never)
-    int tile3_min_tiles = 300;       // RWKV_TILE3_MIN_TILES: fewest tiles for which the pipelined prefill kernel is considered
-    int nf4_kc128_min = 512;         // RWKV_NF4_KC128_MIN: 64x64 tiles of an all-NF4 launch walk K in 128-k chunks from this many tiles
-    int v6_split_min_t = 512;        // RWKV_V6_SPLIT_MIN_T: rows from which the wide V6 mix runs as two launches (v6_mix_apply_kernel)
+    int tile_ksplit = 1;             // RWKV_TILE_KSPLIT=0: no K copies of linear prefill launches (the race screen compares tile shapes BIT for bit, which needs one summation order)
     int promote = 0;                 // RWKV_PROMOTE: bit mask of GEMM launch classes that read hi + lo operands in Precision::Fp16 (1 att r/k/v(/g) + first-stage
                                      // LoRAs, 2 V7 second-stage LoRAs, 4 Wo, 8 Fk / Fr, 16 Fv, 32 head); rwkv_engine.cpp OpdClass
-    int ln_threads = 0;              // RWKV_LN_THREADS: threads per row of ln_shift on prefill-shaped steps (0 = 1024 up to 256 rows, 512 above; 256 / 512 / 1024 force)
     static Knobs from_env();
 };
 const Knobs &knobs();                // the calling thread's current set
@@ -37,7 +29,7 @@ void use_knobs(const Knobs &k);
 constexpr int TILE_ROWS = 16;        // output rows per strip (MFMA 16x16x32 M)
 constexpr int KSTEP = 32;            // K per MFMA
 constexpr int GEMM_MAX_WAVES = 10;    // 640-thread blocks: <= 168 VGPRs per lane (KSW = 8 variants)
-constexpr int GEMM_MAX_WAVES_K16 = 8; // KSW = 16 and four-tile (NT = 4) variants: 512-thread blocks, 2 waves per SIMD -> 256 VGPRs per lane
+constexpr int GEMM_MAX_WAVES_K16 = 8; // four-tile (NT = 4) and two-tile hi + lo variants: 512-thread blocks, 2 waves per SIMD -> 256 VGPRs per lane
 int gemm_variant_max_waves(int NT, int KSW, bool hilo = false);
 constexpr int GEMM_MAXP = 8;
 constexpr int INT8_BLOCK = 128;
@@ -117,7 +109,6 @@ struct GemmProb {
     long partial_stride;
     _Float16 *out_hi, *out_lo;      // operand output [T][ldh]
     int ldh;
-    const float *lnp_mu;            // LN-prologue launches: this problem's token-shift mix vector (xhi/xlo unused)
 };
 
 struct GemmLaunch {
@@ -130,13 +121,14 @@ struct GemmLaunch {
     int tail;                       // some fp16 problem has a K range that is not a multiple of 256: predicated variant
     int total_blocks;
     int xcd_map;                    // prefill tile GEMM: XCD-banded tile numbering (rwkv_kernels.hip tg_body)
-    LnProArgs lnp;
     ShiftCommit commit;             // grid = total_blocks + 1 when commit.src is set
 };
 
 void gemm_variant(int T, bool hilo, int &NT, int &KSW);   // tile variant used for T rows
 size_t lnp_lds_bytes(int T, int C, bool hilo);                       // extra dynamic LDS of an LN-prologue launch
 void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s);
+bool smallk_supported(const GemmLaunch &L);              // every problem: fp16, K <= 320, fp32 output, no post-op (V7's second LoRA stage)
+void launch_smallk(const GemmLaunch &L, bool hilo, hipStream_t s);   // output-stationary: one wave per (problem, strip), all rows of the step
 int gemm_max_rounds(int fmt, int NT, bool hilo);
 // prefill path (T >= GEMM_TILE_MIN_T): LDS-tiled MFMA GEMM, no K split; uses p[].block_begin and total_blocks only
 constexpr int GEMM_TILE_MIN_T = 193;                     // measured crossover (V6-3B Int8): up to 192 rows the decode kernel's 64-row passes win or tie

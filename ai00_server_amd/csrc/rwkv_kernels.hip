@@ -486,18 +486,10 @@ static int knob_env(const char *name, int dflt) {
 }
 Knobs Knobs::from_env() {
     Knobs k;
-    k.spb = knob_env("RWKV_SPB", 0); k.ksb = knob_env("RWKV_KSB", 0); k.ksw8 = knob_env("RWKV_KSW8", 1);
     k.no_ln_fuse = knob_env("RWKV_NO_LN_FUSE", 0); k.no_v6_fuse = knob_env("RWKV_NO_V6_FUSE", 0);
-    k.no_v6_wide = knob_env("RWKV_NO_V6_WIDE", 0); k.v6mix_split = knob_env("RWKV_V6MIX_SPLIT", 0);
     k.no_tile = knob_env("RWKV_NO_TILE", 0); k.tile_shape = knob_env("RWKV_TILE_SHAPE", -1);
-    k.tile3_fill = knob_env("RWKV_TILE3_FILL", 60); k.tile_xcd = knob_env("RWKV_TILE_XCD", 1);
+    k.no_dense = knob_env("RWKV_NO_DENSE", 0);
     k.tile_ksplit = knob_env("RWKV_TILE_KSPLIT", 1);
-    k.no_dense = knob_env("RWKV_NO_DENSE", 0); k.ln_256 = knob_env("RWKV_LN_256", 0);
-    k.ln_threads = knob_env("RWKV_LN_THREADS", 0);
-    k.v6_split_min_t = knob_env("RWKV_V6_SPLIT_MIN_T", 512);
-    k.tile3_min_tiles = knob_env("RWKV_TILE3_MIN_TILES", 300);
-    k.nf4_kc128_min = knob_env("RWKV_NF4_KC128_MIN", 512);
-    k.tile3_64 = knob_env("RWKV_TILE3_64", 1);
     k.promote = knob_env("RWKV_PROMOTE", 0);
     return k;
 }
@@ -527,7 +519,7 @@ __device__ __forceinline__ const void *pin_p(const void *p) {
     const unsigned lo = (unsigned)pin_s((int)(unsigned)v), hi = (unsigned)pin_s((int)(unsigned)(v >> 32));
     return (const void *)(((unsigned long long)hi << 32) | lo);
 }
-template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, int FMT, bool LNP>
+template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, int FMT>
 __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
     constexpr int KW = KSW * 32, SUB = KSW / RS, RK = RS * 32;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -576,7 +568,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
     // streamed (not single-shot) quantised weights: a ring of RD rounds in flight per wave.  With only cur/nxt
     // (one round ahead) a wave's K slice is a serial chain of memory latencies — 6 rounds x ~0.9 us at T = 1
     // (scripts/trace_gemm.py); fp16 rounds are twice the registers and stay at one round ahead.
-    constexpr int RD = (!SHOT && FMT != W_F16) ? ((NT >= 2 || HILO || LNP) ? 2 : 4) : 1;
+    constexpr int RD = (!SHOT && FMT != W_F16) ? ((NT >= 2 || HILO) ? 2 : 4) : 1;
     WRound<FMT> ring[RD];
     // weights of one K slice of this wave: everything (single shot), the first RD rounds (ring) or the first round
     auto issue_w = [&](int k0, int nsub, int nround, bool ringed) {
@@ -638,31 +630,9 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
                     }
                 }
             };
-            if constexpr (LNP) {
-                // LayerNorm prologue launch: row loads, then this wave's weights (holding both in flight at once does not
-                // fit the register file), then the reductions; the B fragments come from the prologue's LDS image.
-                // One slice per wave, one 16-token tile (host checks).
-                float *xx_l = (float *)(smem + (size_t)L.lds_items * NT * 64 * 16);
-                const int ldl = L.lnp.C + LNP_PAD;
-                float *pv_l = xx_l + L.T * ldl, *lred = pv_l + L.T * ldl;
-                _Float16 *op_l = (_Float16 *)(lred + 64);
-                LnCarry carry;
-                ln_prologue_load(L.lnp, L.T, xx_l, pv_l, lred, blockIdx.x == 0, carry);
-                issue_w(k0, nsub, nround, ringed);             // the weights fly while the rows are reduced and normalised
-                ln_prologue_finish<HILO>(L.lnp, L.T, P.lnp_mu, xx_l, pv_l, op_l, lred, blockIdx.x == 0, carry);
-                const int tl = min(lane & 15, L.T - 1);
-                const _Float16 *oph = op_l + lnp_op_off(L.T, k0 + (lane >> 4) * 8, tl);
-#pragma unroll
-                for (int ks = 0; ks < KSW; ++ks) {
-                    const bool in = !TAIL || (k0 + ks * 32 < kend);
-                    xb[0][ks] = in ? *(const f16x8 *)(oph + (size_t)ks * 4 * L.T * 8) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                    if constexpr (HILO) xl[0][ks] = in ? *(const f16x8 *)(oph + (size_t)L.T * L.lnp.C + (size_t)ks * 4 * L.T * 8) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                }
-            } else {
-                load_x();
-                TRACE_PT(7);
-                issue_w(k0, nsub, nround, ringed);
-            }
+            load_x();
+            TRACE_PT(7);
+            issue_w(k0, nsub, nround, ringed);
 #ifdef RWKV_TRACE
             TRACE_PT(1);
 #if RWKV_TRACE >= 2
@@ -793,8 +763,8 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch &L, const GemmProb &P
     TRACE_PT(4);
 }
 
-template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL, bool LNP>
-__global__ __launch_bounds__(((KSW == 16 || NT == 4 || (NT == 2 && HILO)) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES) * 64) void gemm_kernel(const GemmLaunch L) {
+template <int NT, int KSW, bool HILO, bool SHOT, bool TAIL>
+__global__ __launch_bounds__(((NT == 4 || (NT == 2 && HILO)) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES) * 64) void gemm_kernel(const GemmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x >= L.total_blocks) {                      // the extra block of a launch that carries a commit
         shift_commit(L.commit);
@@ -804,48 +774,46 @@ __global__ __launch_bounds__(((KSW == 16 || NT == 4 || (NT == 2 && HILO)) ? GEMM
     for (int i = 1; i < L.nprob; ++i)
         if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
     const GemmProb &P = L.p[pi];
-    if (P.fmt == W_F16) gemm_body<NT, KSW, HILO, SHOT, TAIL, W_F16, LNP>(L, P, smem);
-    else if (P.fmt == W_INT8) gemm_body<NT, KSW, HILO, SHOT, false, W_INT8, LNP>(L, P, smem);   // quantised K is a multiple of 256
-    else gemm_body<NT, KSW, HILO, SHOT, false, W_NF4, LNP>(L, P, smem);
+    if (P.fmt == W_F16) gemm_body<NT, KSW, HILO, SHOT, TAIL, W_F16>(L, P, smem);
+    else if (P.fmt == W_INT8) gemm_body<NT, KSW, HILO, SHOT, false, W_INT8>(L, P, smem);   // quantised K is a multiple of 256
+    else gemm_body<NT, KSW, HILO, SHOT, false, W_NF4>(L, P, smem);
 }
 
-int gemm_variant_max_waves(int NT, int KSW, bool hilo) { return (KSW == 16 || NT == 4 || (NT == 2 && hilo)) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES; }
+int gemm_variant_max_waves(int NT, int, bool hilo) { return (NT == 4 || (NT == 2 && hilo)) ? GEMM_MAX_WAVES_K16 : GEMM_MAX_WAVES; }
 
 void gemm_variant(int T, bool hilo, int &NT, int &KSW) {
-    // T <= 16: ten waves of 256 k per block rather than five of 512 k — a wave's loads return in order and what a CU can pull from
-    // HBM grows with its waves, not with the loads each keeps in flight (profiles/r3_exp_stream_waves_x_loads.log: 27 MB over 256
-    // workgroups: 5 waves 8.6-10.8 us, 10 waves 6.9-8.0, 16 waves 6.8-7.1 whatever the depth); on the real launches 9.09 -> 8.85 us
-    // (r/k/v/g Int8, T = 1), one-slot step 1.707 -> 1.696 ms, eight slots 1.851 -> 1.827.  Knobs::ksw8 = 0 restores 512-k waves.
-    const int ksw8 = knobs().ksw8;
+    // Every variant runs 256-k waves (ten per block at K = 2560): a wave's loads return in order and what a CU can pull from HBM grows with
+    // its waves, not with the loads each keeps in flight (profiles/r3_exp_stream_waves_x_loads.log: 27 MB over 256 workgroups: 5 waves
+    // 8.6-10.8 us, 10 waves 6.9-8.0, 16 waves 6.8-7.1 whatever the depth).  (The 512-k form and its LayerNorm-prologue launch lost that
+    // A/B in round 3 and were removed in round 5.)
+    KSW = 8;
     // hi + lo operands (Precision::Fp32, or a promoted launch): 17+ rows run two token tiles per pass in 512-thread blocks (128 X registers, the
     // register shape of the four-tile variant) — one pass over the weights for up to 32 rows instead of one per 16
-    if (hilo) { NT = T <= 16 ? 1 : 2; KSW = 8; }
-    else if (T <= 16) { NT = 1; KSW = ksw8 ? 8 : 16; }
-    else if (T <= 32) { NT = 2; KSW = 8; }
-    else { NT = 4; KSW = 8; }                                    // 33..64 rows in ONE pass over the weights (128 X registers)
+    if (hilo) NT = T <= 16 ? 1 : 2;
+    else if (T <= 16) NT = 1;
+    else if (T <= 32) NT = 2;
+    else NT = 4;                                                  // 33..64 rows in ONE pass over the weights (128 X registers)
 }
 
 void launch_gemm(const GemmLaunch &L, bool hilo, hipStream_t s) {
     int NT, KSW;
     gemm_variant(L.T, hilo, NT, KSW);
-    const bool lnp = L.lnp.x_in != nullptr;                   // host: only for the (NT 1, KSW 16, !hilo) variant, see plan_gemm
-    const size_t lds = (size_t)L.lds_items * NT * 64 * 16 + (lnp ? lnp_lds_bytes(L.T, L.lnp.C, hilo) : 0);
+    const size_t lds = (size_t)L.lds_items * NT * 64 * 16;
     dim3 grid(L.total_blocks + (L.commit.src ? 1 : 0)), block(L.threads);
     static bool attr_done[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
-#define GEMM_V3(X, sh, tl) X(1, 8, true, sh, tl, false) X(2, 8, true, sh, tl, false) X(1, 16, false, sh, tl, false) X(2, 8, false, sh, tl, false) X(1, 8, false, sh, tl, false) X(1, 16, false, sh, tl, true) \
-                           X(4, 8, false, sh, tl, false)
+#define GEMM_V3(X, sh, tl) X(1, 8, true, sh, tl) X(2, 8, true, sh, tl) X(2, 8, false, sh, tl) X(1, 8, false, sh, tl) X(4, 8, false, sh, tl)
 #define GEMM_VARIANTS(X) GEMM_V3(X, true, true) GEMM_V3(X, true, false) GEMM_V3(X, false, true) GEMM_V3(X, false, false)
     if (!attr_done[dev & 15]) {                               // allow > 64 KiB dynamic LDS (gfx950: 160 KiB / CU)
         const int cap = 160 * 1024;
-#define SET_ATTR(a, b, c, d, e, f) (void)hipFuncSetAttribute((const void *)gemm_kernel<a, b, c, d, e, f>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+#define SET_ATTR(a, b, c, d, e) (void)hipFuncSetAttribute((const void *)gemm_kernel<a, b, c, d, e>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         GEMM_VARIANTS(SET_ATTR)
 #undef SET_ATTR
         attr_done[dev & 15] = true;
     }
     const bool shot = L.single_shot != 0, tail = L.tail != 0;
-#define LAUNCH(a, b, c, d, e, f) if (NT == a && KSW == b && hilo == c && shot == d && tail == e && lnp == f) hipLaunchKernelGGL((gemm_kernel<a, b, c, d, e, f>), grid, block, lds, s, L);
+#define LAUNCH(a, b, c, d, e) if (NT == a && KSW == b && hilo == c && shot == d && tail == e) hipLaunchKernelGGL((gemm_kernel<a, b, c, d, e>), grid, block, lds, s, L);
     GEMM_VARIANTS(LAUNCH)
 #undef LAUNCH
 #undef GEMM_VARIANTS
@@ -1164,17 +1132,16 @@ void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
     const bool wide = a.T > 32;                                // v6_mix_wide_supported: one block per (mix, 32-token tile)
     // (17..32 rows as two NT = 1 token tiles — 200 workgroups that each pull W1_c + half of z — was measured and dropped: every
     // workgroup still pulls all of W1_c, so the launch's L2 traffic grows by half: 2.250 -> 2.267 ms per 32-slot step,
-    // profiles/r3_exp_ab_v6mix_ksw8.log.  Knobs::v6mix_split selects it.)
-    const int split = knobs().v6mix_split;
-    const bool split_tiles = !wide && a.T > 16 && split && a.lnp.x_in == nullptr;
-    const int NT = ((a.T <= 16 && !wide) || split_tiles) ? 1 : 2;
+    // profiles/r3_exp_ab_v6mix_ksw8.log.)
+    constexpr int V6_SPLIT_MIN_T = 512;                        // rows from which the wide form runs as two launches (v6_mix_apply_kernel)
+    const int NT = (a.T <= 16 && !wide) ? 1 : 2;
     const bool lnp = a.lnp.x_in != nullptr;                    // host: T <= LNP_MAX_T, !hilo, C <= 4096 (v6_mix_ln_supported)
     const size_t lds = (size_t)8 * 4 * NT * 64 * 16 + (size_t)2 * NT * 16 * (a.Dm + 8) * 2 + (lnp ? lnp_lds_bytes(LNP_MAX_T, a.C, hilo) : 0);
-    dim3 grid((a.C / 16 + 7) / 8, 5, split_tiles ? 2 : 1), block(512);
+    dim3 grid((a.C / 16 + 7) / 8, 5, 1), block(512);
     if (wide) {
         const int ntile = (a.T + 31) / 32;
         grid = dim3(std::max(1, std::min(8, 256 / (5 * ntile))), 5, ntile);   // fill the chip when the step has few token tiles
-        if (a.T >= knobs().v6_split_min_t && a.T % 32 == 0 && a.mg_hi && (!hilo || a.mg_lo)) {
+        if (a.T >= V6_SPLIT_MIN_T && a.T % 32 == 0 && a.mg_hi && (!hilo || a.mg_lo)) {
             grid = dim3(1, 5, ntile);
             const dim3 g2((a.C / 16 + 7) / 8, ntile);
             if (a.Dm == 32) {
@@ -1209,6 +1176,91 @@ bool v6_mix_ln_supported(int T, int C, int Dm, bool hilo, int np) {
     return v6_mix_supported(T, C, Dm) && T <= LNP_MAX_T && !hilo && np <= LNP_MAX_NP && C <= 8 * 512;
 }
 
+// =====================================================================================
+// Small-K GEMM, output-stationary (V7's second LoRA stage: four [C x D] matrices, D = 64 .. 320, against the first stage's [T x D]
+// outputs; K14).  One wave owns one strip (16 output rows) of one problem for ALL rows of the step: its <= KMAX / 32 weight tiles are
+// loaded once and stay in registers, then it walks the token tiles — the next tile's X fragments (one contiguous 1 KiB per k-step) are
+// requested before the current tile is multiplied — and stores bias + activation straight from the accumulators.  No K split across
+// waves, so no LDS, no barrier, no reduce; the launch is a load -> MFMA -> store chain of ~10 instructions per token tile.  Replaces
+// the generic kernels on these launches (which split a K of 96 over waves sized for K = 2560: 6.4 us at 32 rows, 10.8 us at 256).
+// =====================================================================================
+constexpr int SK_KMAX = 320, SK_TG = 4;
+template <bool HILO>
+__global__ __launch_bounds__(256) void smallk_kernel(const GemmLaunch L) {
+    const int lane = threadIdx.x & 63;
+    const int item = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);            // (problem, strip), problems back to back
+    if (item >= L.total_blocks) return;
+    int pi = 0;
+    for (int i = 1; i < L.nprob; ++i) if (item >= L.p[i].block_begin) pi = i;
+    const GemmProb &P = L.p[pi];
+    const int strip = item - P.block_begin, KT = P.K >> 5;
+    constexpr int MK = SK_KMAX / 32;
+    u32x4 w[MK];
+    const u32x4 *wb = (const u32x4 *)P.W + (long)strip * KT * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < MK; ++j) if (j < KT) w[j] = wb[j * 64];
+    const act_t bxh = act_buf(P.xhi), bxl = act_buf(P.xlo), bo = act_buf(P.out_f32);
+    const int row0 = strip * 16 + (lane >> 4) * 4;
+    const float4 bias = P.bias ? *(const float4 *)(P.bias + row0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ntile = (L.T + 15) >> 4, act = P.act, ldo = P.ldo;
+    const long tstride = (long)(P.ldx >> 5) * 512;                              // halves between token tiles of the operand
+    struct XT { f16x8 h[MK], l[HILO ? MK : 1]; };
+    auto load_x = [&](int tile, XT &x) {
+        const int tl = min(lane & 15, L.T - 1 - tile * 16);                      // lanes beyond the last row re-read it (never stored)
+        const long xo = tile * tstride + ((lane >> 4) * 16 + tl) * 8;
+#pragma unroll
+        for (int j = 0; j < MK; ++j) {
+            if (j < KT) {
+                x.h[j] = act_ldh8(bxh, xo + j * 512);
+                if constexpr (HILO) x.l[j] = act_ldh8(bxl, xo + j * 512);
+            }
+        }
+    };
+    auto mul_store = [&](int tile, const XT &x) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+#pragma unroll
+        for (int j = 0; j < MK; ++j) {
+            if (j < KT) {
+                const f16x8 af = __builtin_bit_cast(f16x8, w[j]);
+                f32x4 &d = (j & 1) ? acc2 : acc;
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, x.h[j], d, 0, 0, 0);
+                if constexpr (HILO) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, x.l[j], d, 0, 0, 0);
+            }
+        }
+        const int t = tile * 16 + (lane & 15);
+        if (t < L.T) {
+            float v[4] = {acc[0] + acc2[0] + bias.x, acc[1] + acc2[1] + bias.y, acc[2] + acc2[2] + bias.z, acc[3] + acc2[3] + bias.w};
+            apply_act4(act, v);
+            act_st4(bo, (long)t * ldo + row0, make_float4(v[0], v[1], v[2], v[3]));
+        }
+    };
+    // two named buffers, the tile loop unrolled by two: a buffer picked by a run-time index would live in scratch memory
+    // (prefill-shaped steps: blockIdx.y walks groups of SK_TG token tiles, so a wave's chain stays four tiles long whatever the step)
+    const int tbeg = (int)blockIdx.y * SK_TG, tend = min(ntile, tbeg + SK_TG);
+    XT xa, xb;
+    load_x(tbeg, xa);
+    for (int tile = tbeg; tile < tend; tile += 2) {
+        if (tile + 1 < tend) load_x(tile + 1, xb);
+        mul_store(tile, xa);
+        if (tile + 2 < tend) load_x(tile + 2, xa);
+        if (tile + 1 < tend) mul_store(tile + 1, xb);
+    }
+}
+// every problem: fp16 weights, K <= SK_KMAX, fp32 output only, no post-op, no K split
+bool smallk_supported(const GemmLaunch &L) {
+    if (L.nprob < 1) return false;
+    for (int i = 0; i < L.nprob; ++i) {
+        const GemmProb &g = L.p[i];
+        if (g.fmt != W_F16 || g.K > SK_KMAX || g.K % 32 || g.rows % 16 || !g.out_f32 || g.out_hi || g.post != POST_NONE || g.ksb != 1) return false;
+    }
+    return true;
+}
+// L.p[i].block_begin = first (problem, strip) item of problem i, L.total_blocks = items in all
+void launch_smallk(const GemmLaunch &L, bool hilo, hipStream_t s) {
+    const dim3 grid((L.total_blocks + 3) / 4, ((L.T + 15) / 16 + SK_TG - 1) / SK_TG), block(256);
+    if (hilo) hipLaunchKernelGGL(smallk_kernel<true>, grid, block, 0, s, L);
+    else hipLaunchKernelGGL(smallk_kernel<false>, grid, block, 0, s, L);
+}
 #endif  // part 1: fused V6 mix
 
 #if RWKV_PART_ON(2)
@@ -1990,34 +2042,23 @@ __global__ __launch_bounds__(NTHR) void ln_shift_kernel(const LnShiftArgs a) {
 void launch_ln_shift(const LnShiftArgs &a, int T, hipStream_t s) {
     // (Spare workgroups of this launch touching the next GEMM's weights into the Infinity Cache were built and measured in round 3:
     // a 32-slot step went from 2.25 to 3.00 ms — profiles/r3_exp_prefetch_by_row_kernel_workgroups.log — and the code was removed.)
-    const int wide_off = knobs().ln_256;                         // A/B switch
-    if (T <= 64 && !wide_off) {                                   // few rows: 1024 threads per row
-        if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<1, 1024>), dim3(T), dim3(1024), 0, s, a);
-        else hipLaunchKernelGGL((ln_shift_kernel<2, 1024>), dim3(T), dim3(1024), 0, s, a);
-        return;
-    }
-    // prefill-shaped steps (measured, profiles/r3_exp_ln_threads.log): up to 256 rows the 1024-thread form is still ahead (+3 % on a
-    // 256-token chunk), above that 512 threads per row (+0.6 % at 2048 rows; 1024 there is -1.8 %: 2 blocks per CU).  The 256-thread
-    // form keeps ~250 VGPRs, i.e. 8 waves per CU.
-    int thr = knobs().ln_threads;
-    if (thr == 0) thr = T <= 256 ? 1024 : 512;
+    // Threads per row (measured, profiles/r3_exp_ln_threads.log): 1024 up to 256 rows (the kernel is one latency chain over ~90 KB per row,
+    // and 16 waves with ~6 loads each get it issued four times as fast as 4 waves with ~21; still +3 % on a 256-token chunk), 512 above
+    // (+0.6 % at 2048 rows; 1024 there is -1.8 %: 2 blocks per CU).  Rows of prefill-shaped steps are numbered XCD-banded (xcd_rows).
     LnShiftArgs a2 = a;
-    a2.xcd_rows = knobs().tile_xcd ? 1 : 0;
-    if (thr == 1024 && a.C <= 8192) {
+    a2.xcd_rows = T > 64 ? 1 : 0;
+    if (T <= 256 && a.C <= 8192) {
         if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<1, 1024>), dim3(T), dim3(1024), 0, s, a2);
         else hipLaunchKernelGGL((ln_shift_kernel<2, 1024>), dim3(T), dim3(1024), 0, s, a2);
         return;
     }
-    if (thr == 512 && a.C <= 8192) {
+    if (a.C <= 8192) {
         if (a.C <= 2048) hipLaunchKernelGGL((ln_shift_kernel<1, 512>), dim3(T), dim3(512), 0, s, a2);
         else if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<2, 512>), dim3(T), dim3(512), 0, s, a2);
         else hipLaunchKernelGGL((ln_shift_kernel<4, 512>), dim3(T), dim3(512), 0, s, a2);
         return;
     }
-    if (a.C <= 1024) hipLaunchKernelGGL((ln_shift_kernel<1, 256>), dim3(T), dim3(256), 0, s, a2);
-    else if (a.C <= 2048) hipLaunchKernelGGL((ln_shift_kernel<2, 256>), dim3(T), dim3(256), 0, s, a2);
-    else if (a.C <= 4096) hipLaunchKernelGGL((ln_shift_kernel<4, 256>), dim3(T), dim3(256), 0, s, a2);
-    else hipLaunchKernelGGL((ln_shift_kernel<8, 256>), dim3(T), dim3(256), 0, s, a2);
+    hipLaunchKernelGGL((ln_shift_kernel<8, 256>), dim3(T), dim3(256), 0, s, a2);      // wider than 8192 channels: 256 threads x 8 float4
 }
 
 template <int PT>
@@ -2282,15 +2323,38 @@ __global__ __launch_bounds__(256, VER == 7 ? 2 : 3) void wkv_chunk_kernel(const 
                     if (a.layer != 0) { q5[i] = a.v_first[rb]; q6[i] = a.vg7[rb]; }
                 }
             }
+            if (VER == 7) {
+                // V7's per-token transforms on the eight tokens of this wave AT ONCE, in the registers the loads landed in (kappa =
+                // normalised k * k_k, k <- k (1 + (a - 1) k_a), v <- v + (v_first - v) gate): eight independent L2-norm reductions
+                // interleave instead of one dependent LDS round trip + reduction per token (the rolled form was phase A2 of round 3).
+                // The same operations on the same values in the same order per token: bit-identical.
+                float kk[WKV_CH / 4], ss[WKV_CH / 4];
 #pragma unroll
-            for (int i = 0; i < WKV_CH / 4; ++i) {
-                const int tt = wave + 4 * i;
-                if (tt < n) {
-                    s_r[tt][lane] = q0[i]; s_k[tt][lane] = q1[i]; s_v[tt][lane] = q2[i];
-                    if (VER == 7) {
-                        s_ka[tt][lane] = q3[i]; s_w[tt][lane] = q4[i];
-                        if (a.layer != 0) { s_o[tt][lane] = q5[i]; s_kk[tt][lane] = q6[i]; }
+                for (int i = 0; i < WKV_CH / 4; ++i) { kk[i] = q1[i] * kk_p; ss[i] = kk[i] * kk[i]; }
+#pragma unroll
+                for (int i = 0; i < WKV_CH / 4; ++i) ss[i] = wave_sum(ss[i]);
+#pragma unroll
+                for (int i = 0; i < WKV_CH / 4; ++i) {
+                    const int tt = wave + 4 * i;
+                    if (tt < n) {
+                        const float av = q3[i];
+                        const float kn = kk[i] / fmaxf(sqrtf(ss[i]), 1e-12f);
+                        float v = q2[i];
+                        if (a.layer == 0) a.v_first[(long)(row0 + c0 + tt) * C + cb + lane] = v;
+                        else v = v + (q5[i] - v) * q6[i];
+                        s_r[tt][lane] = q0[i];
+                        s_k[tt][lane] = q1[i] * (1.0f + (av - 1.0f) * ka_p);
+                        s_v[tt][lane] = v;
+                        s_w[tt][lane] = q4[i];
+                        s_kk[tt][lane] = -kn;
+                        s_ka[tt][lane] = kn * av;
                     }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < WKV_CH / 4; ++i) {
+                    const int tt = wave + 4 * i;
+                    if (tt < n) { s_r[tt][lane] = q0[i]; s_k[tt][lane] = q1[i]; s_v[tt][lane] = q2[i]; }
                 }
             }
         }
@@ -2332,22 +2396,8 @@ __global__ __launch_bounds__(256, VER == 7 ? 2 : 3) void wkv_chunk_kernel(const 
                 }
             }
         }
-        for (int tt = wave; tt < n; tt += 4) {
-            if (VER == 5) {
-                s_w[tt][lane] = wconst;
-            } else if (VER == 7) {
-                const float av = s_ka[tt][lane];
-                float k = s_k[tt][lane], v = s_v[tt][lane];
-                float kk = k * kk_p;
-                const float ss = wave_sum(kk * kk);
-                kk = kk / fmaxf(sqrtf(ss), 1e-12f);
-                k = k * (1.0f + (av - 1.0f) * ka_p);
-                if (a.layer == 0) a.v_first[(long)(row0 + c0 + tt) * C + cb + lane] = v;
-                else v = v + (s_o[tt][lane] - v) * s_kk[tt][lane];
-                s_kk[tt][lane] = -kk;
-                s_ka[tt][lane] = kk * av;
-                s_k[tt][lane] = k; s_v[tt][lane] = v;
-            }
+        if (VER == 5) {
+            for (int tt = wave; tt < n; tt += 4) s_w[tt][lane] = wconst;
         }
         if (c0 == 0) TRACE_K(3, 2);
         __syncthreads();

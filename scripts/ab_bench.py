@@ -1,5 +1,5 @@
 """Dev tool (GPU box): A/B of whole decode steps.  Each variant = (label, extra env, library path); prints ms/step at B=32, 8, 1.
-    python scripts/ab_bench.py "base::" "ksb1:RWKV_KSB=1:" "lean::ai00_server_amd/librwkv_hip_lean.so"
+    python scripts/ab_bench.py "base::" "lean::ai00_server_amd/librwkv_hip_lean.so"
 """
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

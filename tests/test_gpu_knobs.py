@@ -2,7 +2,8 @@
 that has to give the oracle's answers too.  The switches are read once per engine, at creation (`rwkv::Knobs`), which is what
 lets one process walk them: set the variable, build an engine, drop the variable.
 
-Per switch: a two-layer V6 model at a width where the switched path is really taken (C = 512: v6_mix needs C % 256 == 0), fp16
+(Round 5 removed the switches whose A/B was lost in rounds 2-4 together with their code paths: what is left selects paths that
+parity needs — every tile shape, the unfused forms — or a documented mode.)  Per switch: a two-layer V6 model at a width where the switched path is really taken (C = 512: v6_mix needs C % 256 == 0), fp16
 and Int8, prefill of ragged prompts (a 300-row step: tile GEMM / wide mix) then decode at 1, 3 and 20 slots (LayerNorm prologue,
 NT = 1 and NT = 2 GEMMs), logits + state against the oracle; V5 / V7 for the switches that touch their paths."""
 import os
@@ -16,12 +17,8 @@ from oracle import rwkv_ref as R
 pytestmark = pytest.mark.gpu
 FP16_TOL = 1e-3
 
-SWITCHES = [("RWKV_KSW8", "0"), ("RWKV_NO_LN_FUSE", "1"), ("RWKV_NO_V6_FUSE", "1"), ("RWKV_NO_V6_WIDE", "1"), ("RWKV_V6MIX_SPLIT", "1"),
-            ("RWKV_NO_TILE", "1"), ("RWKV_TILE_XCD", "0"), ("RWKV_TILE3_FILL", "0"), ("RWKV_NO_DENSE", "1"), ("RWKV_LN_256", "1"),
-            ("RWKV_SPB", "2"), ("RWKV_KSB", "2"), ("RWKV_KSW8+RWKV_NO_LN_FUSE", "0+1"), ("RWKV_TILE_SHAPE", "10"), ("RWKV_TILE_KSPLIT", "0"),
-            ("RWKV_LN_THREADS", "256"), ("RWKV_LN_THREADS", "1024"), ("RWKV_TILE3_MIN_TILES", "1"), ("RWKV_NF4_KC128_MIN", "1"),
-            ("RWKV_TILE3_64", "0"), ("RWKV_TILE_SHAPE", "11"), ("RWKV_V6_SPLIT_MIN_T", "64"),
-            ("RWKV_PROMOTE", "63"), ("RWKV_PROMOTE", "3"), ("RWKV_PROMOTE", "20")]
+SWITCHES = [("RWKV_NO_LN_FUSE", "1"), ("RWKV_NO_V6_FUSE", "1"), ("RWKV_NO_TILE", "1"), ("RWKV_NO_DENSE", "1"), ("RWKV_TILE_SHAPE", "10"),
+            ("RWKV_TILE_SHAPE", "11"), ("RWKV_TILE_KSPLIT", "0"), ("RWKV_PROMOTE", "63"), ("RWKV_PROMOTE", "3"), ("RWKV_PROMOTE", "20")]
 
 
 def tol(want):
@@ -85,10 +82,10 @@ def test_every_switch_gives_the_oracles_answers(models, switch, value):
     try:
         for k, v in zip(names, values):
             os.environ[k] = v
-        vers = (6, 5, 7) if any(k in ("RWKV_KSW8", "RWKV_NO_LN_FUSE", "RWKV_NO_TILE", "RWKV_NO_DENSE", "RWKV_LN_256", "RWKV_LN_THREADS", "RWKV_SPB", "RWKV_KSB", "RWKV_TILE_KSPLIT", "RWKV_PROMOTE") for k in names) else (6,)
+        vers = (6, 5, 7) if any(k in ("RWKV_NO_LN_FUSE", "RWKV_NO_TILE", "RWKV_NO_DENSE", "RWKV_TILE_KSPLIT", "RWKV_PROMOTE") for k in names) else (6,)
         for ver in vers:
             tens, st = models[ver]
-            for quant in ((0, 1, 2) if "RWKV_NF4_KC128_MIN" in names else (0, 1)):      # the NF4 chunk rule needs an all-NF4 launch
+            for quant in (0, 1):
                 assert run_case(st, tens, quant) <= 1.0, f"V{ver} quant {quant}"
     finally:
         for k, v in old.items():
@@ -98,11 +95,9 @@ def test_every_switch_gives_the_oracles_answers(models, switch, value):
                 os.environ[k] = v
 
 
-def test_wide_mix_forms_agree_on_a_1024_row_step(models):
-    """Steps of >= 512 rows (a multiple of 32) run the wide V6 mix as two launches (v6_mix_kernel<..., P1ONLY> + v6_mix_apply_kernel);
-    RWKV_V6_SPLIT_MIN_T above the step keeps the single launch.  Both must give the oracle's logits and the same bits as each other
-    (same products, same order — only the work distribution differs); fp16 and the hi/lo operand form.  RWKV_TILE_XCD=0 on top: the
-    row kernels' plain row numbering."""
+def test_wide_mix_split_form_on_a_1024_row_step(models):
+    """Steps of >= 512 rows (a multiple of 32) run the wide V6 mix as two launches (v6_mix_kernel<..., P1ONLY> + v6_mix_apply_kernel): the
+    oracle's logits in fp16 and in the hi/lo operand form, and the same bits on a second engine (the work distribution is deterministic)."""
     tens, st = models[6]
     B, L = 32, 32
     ps = [[t % 1024 for t in R.synth_prompt(90 + b, L)] for b in range(B)]
@@ -110,13 +105,8 @@ def test_wide_mix_forms_agree_on_a_1024_row_step(models):
     want = rb.prefill(ps, rb.init_states(B))
     for prec in (rt.Precision.Fp16, rt.Precision.Fp32):
         res = []
-        for env in ({}, {"RWKV_V6_SPLIT_MIN_T": "4096"}, {"RWKV_TILE_XCD": "0"}):
-            os.environ.update(env)
-            try:
-                eng = rt.ModelBuilder(st).build(max_batch=B, token_chunk_size=1024, precision=prec)
-            finally:
-                for k in env:
-                    os.environ.pop(k, None)
+        for rep in range(2):
+            eng = rt.ModelBuilder(st).build(max_batch=B, token_chunk_size=1024, precision=prec)
             inp = rt.RnnInput([rt.RnnInputBatch(list(p), rt.RnnOption.Last) for p in ps])
             inp, outs = eng.infer(inp)
             assert inp.num_token() == 0                                  # one 1024-row step
@@ -125,7 +115,7 @@ def test_wide_mix_forms_agree_on_a_1024_row_step(models):
                 assert float(np.abs(got[b] - want[b]).max()) <= tol(want[b])
             res.append(got)
             eng.close()
-        assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+        assert np.array_equal(res[0], res[1])
 
 
 def test_switches_are_frozen_per_engine(models):
