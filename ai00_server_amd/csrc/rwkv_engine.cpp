@@ -274,7 +274,10 @@ struct rwkv_engine {
     Opd opA[6], opM, opY, opK, opO, opL[4];
     long pstride = 0;
     // row meta (device + pinned host)
-    int *d_meta = nullptr, *h_meta = nullptr;
+    int *d_meta = nullptr, *h_meta = nullptr;                  // h_meta: a ring of META_RING pinned staging buffers (state-only steps are not waited for)
+    static constexpr int META_RING = 4;
+    hipEvent_t meta_ev[META_RING] = {nullptr, nullptr, nullptr, nullptr};
+    int meta_next = 0;
     int *h_tok = nullptr, *dv_tok = nullptr;               // pinned token ids of a dense step and their device-visible alias
     StepPlan last_plan;                                    // plan cache: a serving loop repeats the same dense decode pattern
     std::vector<size_t> last_ntok;
@@ -338,6 +341,7 @@ struct rwkv_engine {
         if (logits_host) (void)hipHostFree(logits_host);
         if (soft_host) (void)hipHostFree(soft_host);
         if (h_meta) (void)hipHostFree(h_meta);
+        for (auto ev : meta_ev) if (ev) (void)hipEventDestroy(ev);
         if (h_tok) (void)hipHostFree(h_tok);
         if (h_samp) (void)hipHostFree(h_samp);
         if (h_allow) (void)hipHostFree(h_allow);
@@ -792,7 +796,8 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
     HIP_CHECK(hipHostMalloc((void **)&logits_host, (size_t)chunk * V * 4, hipHostMallocDefault));
     meta_cap = (size_t)chunk * 5 + (size_t)max_batch * 3 + 16;
     d_meta = dalloc<int>(meta_cap);
-    HIP_CHECK(hipHostMalloc((void **)&h_meta, meta_cap * 4, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&h_meta, meta_cap * 4 * META_RING, hipHostMallocDefault));
+    for (auto &ev : meta_ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIP_CHECK(hipHostMalloc((void **)&h_tok, (size_t)max_batch * 4, hipHostMallocMapped | hipHostMallocCoherent));   // uncached on the device: always the host's latest store
     HIP_CHECK(hipHostGetDevicePointer((void **)&dv_tok, h_tok, 0));
     d_tok_feedback = dalloc<int>(chunk);
@@ -1171,7 +1176,12 @@ RowMeta rwkv_engine::meta_ptrs(int) const {
 }
 
 void rwkv_engine::upload_plan(const StepPlan &pl) {
-    int *h = h_meta;
+    // a staging buffer is free again when the copy that read it has run (a step that emits nothing returns without waiting for the device,
+    // so the previous copies may still be queued: four buffers, each guarded by the event recorded behind its copy)
+    const int slot = meta_next;
+    meta_next = (meta_next + 1) % META_RING;
+    HIP_CHECK(hipEventSynchronize(meta_ev[slot]));
+    int *h = h_meta + (size_t)slot * meta_cap;
     std::memcpy(h, pl.token.data(), pl.T * 4);
     std::memcpy(h + chunk, pl.slot.data(), pl.T * 4);
     std::memcpy(h + 2 * chunk, pl.prev.data(), pl.T * 4);
@@ -1181,6 +1191,7 @@ void rwkv_engine::upload_plan(const StepPlan &pl) {
     std::memcpy(h + 5 * chunk + max_batch, pl.seq_begin.data(), pl.n_seq * 4);
     std::memcpy(h + 5 * chunk + 2 * max_batch, pl.seq_len.data(), pl.n_seq * 4);
     HIP_CHECK(hipMemcpyAsync(d_meta, h, meta_cap * 4, hipMemcpyHostToDevice, s_main));
+    HIP_CHECK(hipEventRecord(meta_ev[slot], s_main));
     uploaded_id = pl.id;
 }
 
@@ -1542,8 +1553,12 @@ void rwkv_engine::infer(const rwkv_slot_input *in, rwkv_slot_output *out) {
         HIP_CHECK(hipStreamSynchronize(s_main));
         return;
     }
-    if (pl.n_out > 0)
-        HIP_CHECK(hipMemcpyAsync(logits_host, logits, (size_t)pl.n_out * V * 4, hipMemcpyDeviceToHost, s_main));
+    // A step that emits no row (state-only requests: RWKV_OPTION_NONE, or `Last` slots that still have tokens pending) hands nothing back
+    // but `n_consumed`, which the plan already knows: it is NOT waited for.  The next call's host work (plan, metadata staging, launch)
+    // overlaps this step on the device; every call that reads device data (`state.back / read / write`, a step with rows) is ordered
+    // behind it on the stream and waits as before.  A device fault surfaces at that next wait.
+    if (pl.n_out == 0) return;
+    HIP_CHECK(hipMemcpyAsync(logits_host, logits, (size_t)pl.n_out * V * 4, hipMemcpyDeviceToHost, s_main));
     HIP_CHECK(hipStreamSynchronize(s_main));
     for (const Seg &g : segs) std::memcpy(g.dst, logits_host + g.row0 * V, g.rows * V * 4);
 }

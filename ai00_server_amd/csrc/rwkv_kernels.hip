@@ -1976,6 +1976,13 @@ __global__ __launch_bounds__(NTHR) void ln_shift_kernel(const LnShiftArgs a) {
     ROW_FOR(i, c) { wv[i] = ld4(a.lnw + c); bv[i] = ld4(a.lnb + c); }
     if (a.nmix > 0) { ROW_FOR(i, c) mu0[i] = ld4(a.mu[0] + c); }
     if (a.nmix > 1) { ROW_FOR(i, c) mu1[i] = ld4(a.mu[1] + c); }
+    // one float4 per thread (C <= 4 * NTHR): the mixes beyond the second (V5: four, V7: six) are requested here as well — left in the emit
+    // loop each was an L2 round trip behind the two reductions of a kernel that is nothing but a latency chain
+    float4 mux[PT == 1 ? 4 : 1];
+    if constexpr (PT == 1) {
+#pragma unroll
+        for (int m = 2; m < 6; ++m) if (m < a.nmix && threadIdx.x * 4 < C) mux[m - 2] = ld4(a.mu[m] + threadIdx.x * 4);
+    }
     // dense decode step (row t = slot t, one row per slot): no metadata round trip in front of the state load
     const int slot = a.rm.dense ? t : a.rm.slot[t], prev = a.rm.dense ? -1 : a.rm.prev[t], last = a.rm.dense ? t : a.rm.last[t];
     float *__restrict__ sx = a.sx + (long)slot * a.sx_slot_stride;
@@ -2011,6 +2018,7 @@ __global__ __launch_bounds__(NTHR) void ln_shift_kernel(const LnShiftArgs a) {
             float4 muv[PT];
             if (m == 0) { ROW_FOR(i, c) muv[i] = mu0[i]; }
             else if (m == 1) { ROW_FOR(i, c) muv[i] = mu1[i]; }
+            else if constexpr (PT == 1) { muv[0] = mux[m - 2]; }
             else { const float *__restrict__ mu = a.mu[m]; ROW_FOR(i, c) muv[i] = ld4(mu + c); }
             ROW_FOR(i, c) {
                 float4 o;

@@ -194,17 +194,20 @@ class StateJob:
                 self.out.close()
             self.out = self._Arena((len(docs), N, Cn))
         out = self.out.array
+        # documents as uint32 arrays, once: a step then hands the engine views (no per-token Python work per call); empty prompt => [0] (run.rs:489-492)
+        arr = [np.asarray(d if len(d) else [0], dtype=np.uint32) for d in docs]
         waiting = deque(range(len(docs)))
         owner = [-1] * B                        # document id a slot works on
-        rest = [[] for _ in range(B)]           # its tokens not yet consumed
+        none = np.zeros(0, np.uint32)
+        rest = [none for _ in range(B)]         # its tokens not yet consumed
         calls = 0
         while waiting or any(o >= 0 for o in owner):
             for b in range(B):                  # `queue`: the next document takes an idle slot
                 if owner[b] < 0 and waiting:
                     d = waiting.popleft()
                     rt.state.write(self.zero, b)
-                    owner[b], rest[b] = d, list(docs[d]) if len(docs[d]) else [0]          # empty prompt => [0] (run.rs:489-492)
-            inp = RnnInput([RnnInputBatch(rest[b] if owner[b] >= 0 else [], RnnOption.NoOutput) for b in range(B)])
+                    owner[b], rest[b] = d, arr[d]
+            inp = RnnInput([RnnInputBatch(rest[b] if owner[b] >= 0 else none, RnnOption.NoOutput) for b in range(B)])
             inp, _ = rt.infer(inp)              # one step over <= token_chunk_size tokens of all busy slots
             calls += 1
             for b in range(B):

@@ -444,7 +444,9 @@ class Runtime:
         for b, ib in enumerate(inp.batches):
             o = self._outs[b]
             outs.append(self._views[b][:o.n_rows].copy())         # RnnOutputBatch: [n_rows, V]; empty if n_rows == 0
-            ib.tokens = list(ib.tokens[o.n_consumed:])
+            # tokens handed over as a numpy array stay one (a view of the rest: the batch jobs keep their documents as arrays, so a step costs
+            # no per-token Python work); lists stay lists
+            ib.tokens = ib.tokens[o.n_consumed:] if isinstance(ib.tokens, np.ndarray) else list(ib.tokens[o.n_consumed:])
         return inp, outs
 
     def infer(self, inp: RnnInput):

@@ -125,7 +125,11 @@ typedef struct rwkv_slot_output {  /* RnnOutputBatch, run.rs:1146-1155 */
  * (arrays have max_batch entries).  The caller advances `tokens` by `n_consumed` and calls
  * again while any tokens remain (the `while input.num_token() > 0` loop, run.rs:1134).
  * Last: one row when the slot's tokens are exhausted by this call.  Full: one row per token
- * consumed.  State of each touched slot is updated in place on the device. */
+ * consumed.  State of each touched slot is updated in place on the device.  A call that emits rows returns when they are in the
+ * caller's buffers.  A call that emits NO row (state-only slots, or `Last` slots whose tokens are not exhausted yet) returns as soon as
+ * the step is queued: `n_consumed` is final, the device runs behind, and everything that reads device data afterwards (a later
+ * rwkv_infer with rows, rwkv_state_back / _read / _write / _back_layer[_async]) is ordered behind it — host work between two steps of a
+ * long prefill overlaps the device.  The `tokens` arrays may be reused as soon as the call returns (they are staged on return). */
 rwkv_status rwkv_infer(rwkv_engine *e, const rwkv_slot_input *in, rwkv_slot_output *out);
 
 /* Pinned host memory for the `logits` buffers of rwkv_infer (the `TensorCpu<f32>` outputs of run.rs:1146-1155 are read back
