@@ -105,10 +105,10 @@ def test_real_bench_as_two_ranks_on_one_device():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The line the driver parses (profiles/r4_bench_default.json is the last one measured on the GPU box): every key of the bench
+    """The line the driver parses (profiles/r5_bench_default.json is the last one measured on the GPU box): every key of the bench
     contract, the roofline and cpu_baseline objects with their fields, value = tokens of all ranks / the slowest rank's time."""
     import json
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r4_bench_default.json")).readline())
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r5_bench_default.json")).readline())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in line, k
     assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None and line["data"] == "synthetic"
@@ -128,12 +128,25 @@ def test_committed_bench_line_keeps_the_contract():
     e = line["embeddings"]                                  # 512 documents x 256 tokens per rank at token_chunk_size 256
     assert e["unit"] == "embeddings/s" and e["docs_per_rank"] == 512 and e["doc_tokens"] == 256 and e["token_chunk_size"] == 256
     assert len(e["per_rank_embeddings_per_s"]) == line["n_gpus"] and len(line["pcie_inclusive"]["per_rank"]) == line["n_gpus"]
+    # round 5: the modes that hold north_star's 1e-3 are on the line too, each verified like the headline
+    f = line["precision_fp32"]
+    assert f["tokens_verified"] is True and f["embeddings"]["embeddings_verified"] is True and set(f["decode"]) == {"32", "8", "1"}
+    assert f["fp16_promoted"]["tokens_verified"] is True and f["fp16_promoted"]["RWKV_PROMOTE"] == 1
+    assert line["configs"]["config4_v7-2.9b_nf4"]["fp16_promoted"]["RWKV_PROMOTE"] == 7
+    assert len(line["per_rank_numa"]) == line["n_gpus"]
 
 
 def test_committed_roofline_table_is_what_the_script_generates():
-    """profiles/r4_roofline_table.md is GENERATED from the committed rocprofv3 summaries and launch logs (scripts/roofline_table.py): the
-    per-launch fractions DESIGN.md quotes cannot drift from the evidence without this test noticing."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "roofline_table.py"), "r4"], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert r.stdout == open(os.path.join(ROOT, "profiles", "r4_roofline_table.md")).read()
-    assert "0.6" in r.stdout and "(HBM)" in r.stdout and "(MFMA)" in r.stdout
+    """profiles/r5_roofline_table.md (and round 4's) is GENERATED from the committed rocprofv3 summaries and launch logs
+    (scripts/roofline_table.py): the per-launch fractions DESIGN.md quotes cannot drift from the evidence without this test noticing.  The
+    script asserts every fraction <= 1 and never prices two launches that differ in kernel, grid or block size as one row (round 4's table
+    had a 1.074: two 256-workgroup launches of different block sizes joined on the grid alone)."""
+    import re
+    for rnd in ("r5", "r4"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "roofline_table.py"), rnd], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout == open(os.path.join(ROOT, "profiles", f"{rnd}_roofline_table.md")).read()
+        assert "(HBM)" in r.stdout and "(MFMA)" in r.stdout
+        fracs = [float(x) for x in re.findall(r"\| (\d\.\d+) \((?:HBM|MFMA)\) \|", r.stdout)]
+        assert fracs and max(fracs) <= 1.0
+    assert "ambiguous" not in open(os.path.join(ROOT, "profiles", "r5_roofline_table.md")).read()       # round 5's logs carry the block size
