@@ -154,3 +154,18 @@ def test_pointer_mutability_and_integer_widths_of_the_functions_match():
         assert len(ca) == len(ra), name
         for i, (c, r) in enumerate(zip(ca, ra)):
             assert c_kind(c) == r_kind(r), f"{name} argument {i}: C `{c.strip()}` vs Rust `{r.strip()}`"
+
+
+def test_web_rwkv_comparison_script_is_well_formed():
+    """integration/compare_with_web_rwkv.sh (the one missing pin as one command: needs Rust + Vulkan + weights, none of which exist here):
+    at least it parses, refuses to run without its inputs, and names the routes and request fields the reference's API has
+    (api/oai/state.rs:24-27 `input`, completion.rs:49-67 `prompt` / `max_tokens` / `sampler`)."""
+    import subprocess
+    path = os.path.join(ROOT, "integration", "compare_with_web_rwkv.sh")
+    assert os.access(path, os.X_OK)
+    assert subprocess.run(["bash", "-n", path]).returncode == 0
+    r = subprocess.run(["bash", path], env={k: v for k, v in os.environ.items() if k not in ("AI00", "MODEL")}, capture_output=True, text=True)
+    assert r.returncode != 0 and "AI00" in r.stderr
+    text = open(path).read()
+    for needle in ("/api/oai/", '"completions"', '"states"', '"sampler"', '"top_k": 1', "ai00-core.patch", "cargo build"):
+        assert needle in text, needle

@@ -268,6 +268,41 @@ def test_compiled_restatement_agrees_with_the_numpy_one(name, quant):
     assert cb.step([1] * B, s2, want_logits=False) is None
 
 
+@pytest.mark.parametrize("name", ["v6-small", "v7-small"])
+def test_operand_rounding_switch_of_the_compiled_restatement(name):
+    """`CpuBackend.set_operand_rounding` (the instrument behind profiles/r5_fp16_error_attribution_sim_*.jsonl and RWKV_PROMOTE): mask 0 IS
+    the oracle (bit for bit what every parity test uses); a set bit rounds that class's GEMM operands to fp16 and nothing else — the result
+    moves by f16 operand noise (well above fp32 round-off, well below 1e-2), a class the model version does not have moves nothing, and
+    switching the mask off again restores the exact bits."""
+    from oracle.cpu_backend import CpuBackend
+    t = R.synth_named(name)
+    cb = CpuBackend(t, 0, 0)
+    B, V = 4, cb.info.num_vocab
+    toks = [[int(x) for x in np.random.default_rng(5 + s).integers(1, V, B)] for s in range(6)]
+
+    def run(mask):
+        cb.set_operand_rounding(mask)
+        st = cb.init_states(B)
+        lg = None
+        for tk in toks:
+            lg = cb.step(tk, st)
+        cb.set_operand_rounding(0)
+        return lg, st
+
+    cls = list(CpuBackend.OPERAND_CLASSES)
+    base_l, base_s = run(0)
+    again_l, again_s = run(0)
+    assert np.array_equal(base_l, again_l) and np.array_equal(base_s, again_s)
+    all_l, _ = run((1 << len(cls)) - 1)
+    err = float(np.abs(all_l - base_l).max())
+    assert 1e-6 < err < 1e-2, err
+    att_l, _ = run(1 << cls.index("att"))
+    assert 1e-7 < float(np.abs(att_l - base_l).max()) <= 3 * err
+    absent = "lora2" if cb.info.version != 7 else "mix1"                  # V6 has no second-stage LoRAs, V7 no token-shift LoRA
+    off_l, off_s = run(1 << cls.index(absent))
+    assert np.array_equal(off_l, base_l) and np.array_equal(off_s, base_s)
+
+
 def test_compiled_fake_quantisation_is_bit_identical_to_the_numpy_one():
     """`rwkv_cpu_fake_quant_int8` (per 128-block a, b in fp16, one rounding of a*q + b from float64) and `rwkv_cpu_fake_quant_nf4`
     (per 64-block absmax, 15 fp32 midpoints, one rounding of absmax * table[idx]) against rwkv_ref.fake_quant over seven orders of
