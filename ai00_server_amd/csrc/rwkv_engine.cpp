@@ -856,7 +856,11 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
         const int Kb = K / ksb;
         const int nslice = (Kb + KW - 1) / KW;                 // balanced: every wave owns the same number of slices
         const int maxw = gemm_variant_max_waves(NT, KSW, hilo), per_wave = (nslice + maxw - 1) / maxw;
-        const int nw = (nslice + per_wave - 1) / per_wave;
+        int nw = (nslice + per_wave - 1) / per_wave;
+        // two-tile hi + lo launches run 512-thread blocks (8 waves): ten 256-k slices balance as five waves with two slices each, but what a CU
+        // pulls from HBM grows with its waves — eight waves, two of them with a second slice, stream the first 80 % of the block's bytes at once
+        // (Precision::Fp32 at 32 slots 2.587 -> 2.490 ms per step, Fp16 + RWKV_PROMOTE=1 2.307 -> 2.256)
+        if (hilo && NT == 2 && per_wave > 1) nw = std::min(maxw, nslice);
         // strips per block: the whole grid should be resident at once (~164 VGPRs -> 12 waves per CU), and a wave's
         // rounds should fit in registers so that every load is issued up-front (single shot); the head matrix is too
         // big for that and runs 8 strips per block, software-pipelined.

@@ -23,6 +23,12 @@ run_stats () {   # name, then the command
   echo "stats $name rc=$?"
 }
 BENCH="python $R/bench.py --decode-only --no-cpu-baseline --sweep= --verify-steps 0 --steps 50 --warmup 5"
+# the modes that hold north_star's 1e-3: Precision::Fp32, and Precision::Fp16 with the sensitive launches promoted
+# (ONLY_MODES=1: just these three runs)
+run_stats v6-3b_int8_b32_fp32 $BENCH --workload v6-3b --quant int8 --batch 32 --precision fp32
+RWKV_PROMOTE=1 run_stats v6-3b_int8_b32_promote1 $BENCH --workload v6-3b --quant int8 --batch 32
+RWKV_PROMOTE=7 run_stats v7-2.9b_nf4_b32_promote7 $BENCH --workload v7-2.9b --quant nf4 --batch 32
+if [ -n "${ONLY_MODES:-}" ]; then ls $P; exit 0; fi
 run_stats v6-3b_int8_b32 $BENCH --workload v6-3b --quant int8 --batch 32
 run_stats v6-3b_int8_b1 $BENCH --workload v6-3b --quant int8 --batch 1
 run_stats v6-7b_fp16_b8 $BENCH --workload v6-7b --quant none --batch 8
