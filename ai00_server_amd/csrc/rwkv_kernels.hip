@@ -774,6 +774,8 @@ __global__ __launch_bounds__(((NT == 4 || (NT == 2 && HILO)) ? GEMM_MAX_WAVES_K1
     for (int i = 1; i < L.nprob; ++i)
         if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
     const GemmProb &P = L.p[pi];
+    // (One kernel carries the three weight formats: building it with a single format compiled in changes no launch by more than noise —
+    // profiles/r5_exp_single_format_kernel.log — so code size is not where a launch's fixed cost goes.)
     if (P.fmt == W_F16) gemm_body<NT, KSW, HILO, SHOT, TAIL, W_F16>(L, P, smem);
     else if (P.fmt == W_INT8) gemm_body<NT, KSW, HILO, SHOT, false, W_INT8>(L, P, smem);   // quantised K is a multiple of 256
     else gemm_body<NT, KSW, HILO, SHOT, false, W_NF4>(L, P, smem);
