@@ -167,13 +167,24 @@ def shared_synth_st(R, name: str, job):
     if job.world == 1:
         return R.synth_st(name, fast=True)
     path = f"/dev/shm/rwkv_bench_{name}_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}.st"
+    ok, mine = True, None
     if job.local_rank_env == 0:
-        buf, _ = R.synth_st(name, fast=True)
-        with open(path + ".tmp", "wb") as f:
-            f.write(memoryview(buf))
-        os.replace(path + ".tmp", path)
-        del buf
-    job.host_barrier()
+        mine = R.synth_st(name, fast=True)
+        try:
+            with open(path + ".tmp", "wb") as f:
+                f.write(memoryview(mine[0]))
+            os.replace(path + ".tmp", path)
+        except OSError:                                              # /dev/shm too small (a container's default is 64 MB) or absent
+            ok = False
+            for q in (path + ".tmp", path):
+                try:
+                    os.unlink(q)
+                except OSError:
+                    pass
+    ok = all(job.gather_objects(ok))                                 # (doubles as the barrier behind the write)
+    if not ok:                                                       # every rank synthesises its own copy, as before round 5
+        return mine if mine is not None else R.synth_st(name, fast=True)
+    del mine
     img = np.memmap(path, dtype=np.uint8, mode="r")
     tensors = R.st_deserialize(img)
     job.host_barrier()

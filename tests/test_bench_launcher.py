@@ -63,6 +63,47 @@ def test_each_rank_binds_to_the_numa_node_of_its_gpu():
     assert numa[1]["numa_node"] is None and numa[1]["affinity"] == cpus
 
 
+def test_the_checkpoint_is_synthesised_once_per_node_and_mapped_by_the_other_ranks(tmp_path):
+    """N > 1: local rank 0 generates the `.st` image into /dev/shm, the others map it (bench.shared_synth_st); every rank ends up with the
+    same bytes and the same tensors, nothing is left in /dev/shm; when the image cannot be written there every rank falls back to its own copy."""
+    script = tmp_path / "ranks.py"
+    script.write_text(f"""
+import hashlib, json, os, sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np
+import bench
+from oracle import rwkv_ref as R
+args = bench.parse_args(["--gpus", "2"])
+job = bench.Job(args)
+if os.environ.get("BREAK_SHM") and job.local_rank_env == 0:
+    real_open = open
+    def broken(path, *a, **k):
+        if str(path).startswith("/dev/shm/"):
+            raise OSError(28, "No space left on device")
+        return real_open(path, *a, **k)
+    bench.open = broken
+img, tens = bench.shared_synth_st(R, "v6-tiny", job)
+own, _ = R.synth_st("v6-tiny", fast=True)
+info = R.model_info(tens)
+print(json.dumps({{"rank": job.rank, "sha": hashlib.sha256(bytes(memoryview(np.ascontiguousarray(img)))).hexdigest(), "same_as_own": bool(np.array_equal(np.asarray(img), own)),
+                  "layers": int(info.num_layer), "mapped": isinstance(img, np.memmap)}}), flush=True)
+job.close()
+""")
+    for broken in (False, True):
+        procs = []
+        for r in range(2):
+            env = clean_env(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29641 + int(broken)))
+            if broken:
+                env["BREAK_SHM"] = "1"
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = [p.communicate(timeout=180) for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
+        recs = sorted((last_json(o[0]) for o in outs), key=lambda d: d["rank"])
+        assert recs[0]["sha"] == recs[1]["sha"] and all(r["same_as_own"] and r["layers"] > 0 for r in recs)
+        assert [r["mapped"] for r in recs] == ([False, False] if broken else [True, True])
+        assert not [f for f in os.listdir("/dev/shm") if f.startswith("rwkv_bench_v6-tiny")]
+
+
 def test_under_torch_distributed_run_as_the_driver_launches_it():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29631", BENCH, "--gpus", "2", "--steps", "10", "--selftest-dist"], env=clean_env(),
