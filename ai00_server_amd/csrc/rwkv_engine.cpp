@@ -395,6 +395,7 @@ struct rwkv_engine {
     int gemm(std::vector<ProbSpec> &ps, int T, int fam, const ShiftCommit *commit = nullptr, int cls = CLS_NONE);
     void log_gemm(const std::vector<ProbSpec> &ps, int T, int fam, const char *kind, int variant, int grid, int ksplit, int threads);
     void log_row(const char *kernel, int T, long grid, double bytes);   // RWKV_LAUNCH_LOG: algorithmic bytes of a non-GEMM launch of layer 0 / 1
+    int step_max_rows = 0;                                // most rows any sequence has in the step being enqueued (run_plan)
     float *lnp_xx_att = nullptr;                          // normalised rows published by the V6 mix's LN-prologue launch (for the commit)
     void plan_step(const rwkv_slot_input *in, StepPlan &pl);
     void upload_plan(const StepPlan &pl);
@@ -1334,6 +1335,7 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
             k.v_first = vfirst; k.layer = l;
             k.lnx_w = w.lnxw; k.lnx_b = w.lnxb;
             k.yhi = aY.hi; k.ylo = aY.lo; k.ldh = C;
+            k.max_rows = step_max_rows;
             launch(FAM_WKV, [&] { launch_wkv(k, T > n_seq, s_main); });
             // state tiles in and out (2 x 16 KiB per (slot, head)), the projections of every row in, the gated output operand out
             log_row(T > n_seq ? "wkv_chunk_kernel" : "wkv_kernel", T, (long)n_seq * H,
@@ -1398,7 +1400,10 @@ void rwkv_engine::run_plan(const StepPlan &pl) {
     } else {
         upload_plan(pl);
     }
-    const uint64_t key = ((uint64_t)pl.dense << 63) | ((uint64_t)pl.T << 40) | ((uint64_t)pl.n_seq << 20) | (uint64_t)pl.n_out;
+    step_max_rows = 0;
+    for (int n : pl.seq_len) step_max_rows = std::max(step_max_rows, n);
+    const bool short_rows = step_max_rows <= 8;                  // picks the WKV form: part of the graph's identity
+    const uint64_t key = ((uint64_t)pl.dense << 63) | ((uint64_t)short_rows << 62) | ((uint64_t)pl.T << 40) | ((uint64_t)pl.n_seq << 20) | (uint64_t)pl.n_out;
     if (use_graphs && !profiling) {
         auto it = graphs.find(key);
         // a shape is captured the SECOND time it shows up: decode-shaped steps repeat at once, while the one-off shapes of

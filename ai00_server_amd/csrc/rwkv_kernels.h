@@ -228,6 +228,7 @@ struct WkvArgs {
     const float *lnx_w, *lnx_b;
     _Float16 *yhi, *ylo;
     int ldh;
+    int max_rows;                   // most rows any sequence has in this step (0: unknown): <= 8 selects the short-chunk form of wkv_chunk_kernel
 };
 void launch_wkv(const WkvArgs &a, bool multi_row, hipStream_t s);   // multi_row: some sequence has > 1 row in this step
 

@@ -2292,8 +2292,12 @@ __global__ __launch_bounds__(256, 5) void wkv_kernel(const WkvArgs a) {
 // to ~20 LDS reads + 48 FMAs + 16 DPP adds.
 // =====================================================================================
 constexpr int WKV_CH = 32;                               // tokens per chunk: 8 per wave in the parallel phases
-template <int VER, int DD>
-__global__ __launch_bounds__(256, VER == 7 ? 2 : 3) void wkv_chunk_kernel(const WkvArgs a) {
+// CH = 8 (round 5): the form for steps whose sequences have at most 8 rows each — the embeddings job at `token_chunk_size` 256 hands each of
+// 32 slots 8 tokens per call.  A quarter of the LDS rows and of the phase-A registers: five blocks per CU instead of two or three, so the
+// 1280 (slot, head) blocks of such a step are resident in ONE round instead of 1.7-2.5.
+template <int VER, int DD, int CH = WKV_CH>
+__global__ __launch_bounds__(256, CH == 8 ? 5 : (VER == 7 ? 2 : 3)) void wkv_chunk_kernel(const WkvArgs a) {
+    constexpr int WKV_CH = CH;                               // (shadows the namespace constant inside this kernel)
     __shared__ __attribute__((aligned(16))) float s_r[WKV_CH][64], s_k[WKV_CH][64], s_v[WKV_CH][64], s_w[WKV_CH][64];
     // kappa rows ([0]) and kappa*a rows ([1]) exist for V7 only: V5 / V6 keep 40 KiB of LDS and run three blocks per CU (a launch of
     // 1280 blocks is 1.7 rounds of 768 instead of 2.5 of 512)
@@ -2382,7 +2386,7 @@ __global__ __launch_bounds__(256, VER == 7 ? 2 : 3) void wkv_chunk_kernel(const 
             for (int ks = 0; ks < KS; ++ks) af[ks] = *(const f16x8 *)(d2 + ks * 32);
             const float4 dec4 = *(const float4 *)(a.wdec_or_decay + cb + wave * 16 + (lane >> 4) * 4);
 #pragma unroll
-            for (int tile = 0; tile < WKV_CH / 16; ++tile) {
+            for (int tile = 0; tile < (WKV_CH >= 16 ? WKV_CH / 16 : 1); ++tile) {
                 const int tt = tile * 16 + (lane & 15);
                 const float *tdp = a.td + (long)(row0 + c0 + min(tt, n - 1)) * Dd + (lane >> 4) * 8;
                 float4 t0[KS], t1[KS];
@@ -2455,11 +2459,13 @@ __global__ __launch_bounds__(256, VER == 7 ? 2 : 3) void wkv_chunk_kernel(const 
             const float q = row_sum16x4(outp[0], outp[1], outp[2], outp[3], jg);    // lane jg < 4 holds output aa = jg
             if (jg < 4) s_o[tt][jg * 16 + ig] = q;
         };
-        for (int t4 = 0; t4 < n; t4 += 4) {
-            float4 rq[4], kq[4], wq[4], nk[4], ka[4];
-            float vp[4][4];
+        // (the short-chunk form runs five waves per SIMD: occupancy hides the LDS latency and two tokens per trip keep it under 102 registers)
+        constexpr int UB = CH == 8 ? 2 : 4;
+        for (int t4 = 0; t4 < n; t4 += UB) {
+            float4 rq[UB], kq[UB], wq[UB], nk[UB], ka[UB];
+            float vp[UB][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {                        // rows beyond n are read (LDS, harmless) and never used
+            for (int u = 0; u < UB; ++u) {                       // rows beyond n are read (LDS, harmless) and never used
                 const int tt = min(t4 + u, WKV_CH - 1);
                 rq[u] = *(const float4 *)(&s_r[tt][jg * 4]);
                 kq[u] = *(const float4 *)(&s_k[tt][jg * 4]);
@@ -2469,7 +2475,7 @@ __global__ __launch_bounds__(256, VER == 7 ? 2 : 3) void wkv_chunk_kernel(const 
                 for (int aa = 0; aa < 4; ++aa) vp[u][aa] = s_v[tt][aa * 16 + ig];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < UB; ++u)
                 if (t4 + u < n) step(t4 + u, rq[u], kq[u], wq[u], nk[u], ka[u], vp[u]);
         }
         if (c0 == 0) TRACE_K(3, 4);
@@ -2527,6 +2533,13 @@ __global__ __launch_bounds__(256, VER == 7 ? 2 : 3) void wkv_chunk_kernel(const 
     TRACE_K(3, 7);
 }
 void launch_wkv(const WkvArgs &a, bool multi_row, hipStream_t s) {
+    if (multi_row && a.max_rows > 0 && a.max_rows <= 8) {                  // every sequence of the step has <= 8 rows: the five-blocks-per-CU form
+        if (a.version == 5) hipLaunchKernelGGL((wkv_chunk_kernel<5, 64, 8>), dim3(a.n_seq, a.H), dim3(256), 0, s, a);
+        else if (a.version == 6 && a.Dd == 64) hipLaunchKernelGGL((wkv_chunk_kernel<6, 64, 8>), dim3(a.n_seq, a.H), dim3(256), 0, s, a);
+        else if (a.version == 6) hipLaunchKernelGGL((wkv_chunk_kernel<6, 128, 8>), dim3(a.n_seq, a.H), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wkv_chunk_kernel<7, 64, 8>), dim3(a.n_seq, a.H), dim3(256), 0, s, a);
+        return;
+    }
     if (multi_row && a.version == 5) hipLaunchKernelGGL((wkv_chunk_kernel<5, 64>), dim3(a.n_seq, a.H), dim3(256), 0, s, a);
     else if (multi_row && a.version == 6 && a.Dd == 64) hipLaunchKernelGGL((wkv_chunk_kernel<6, 64>), dim3(a.n_seq, a.H), dim3(256), 0, s, a);
     else if (multi_row && a.version == 6 && a.Dd == 128) hipLaunchKernelGGL((wkv_chunk_kernel<6, 128>), dim3(a.n_seq, a.H), dim3(256), 0, s, a);
