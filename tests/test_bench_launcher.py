@@ -137,6 +137,7 @@ def test_real_bench_as_two_ranks_on_one_device():
     assert r.returncode == 0, r.stderr[-3000:]
     d = last_json(r.stdout)
     assert d["n_gpus"] == 2 and len(d["per_rank_tokens_per_s"]) == 2 and d["tokens_verified"] is True
+    assert [n["rank"] for n in d["per_rank_numa"]] == [0, 1] and all("numa_node" in n and "cpus_bound" in n for n in d["per_rank_numa"])
     assert d["value"] > 0 and d["config"]["parallelism"].startswith("replicas x2")
     for key in ("pcie_inclusive", "on_device_sampling"):
         assert len(d[key]["per_rank"]) == 2 and 0 < d[key]["value"] <= 2 * min(d[key]["per_rank"]) * (1 + 1e-6)
