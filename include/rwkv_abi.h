@@ -24,10 +24,12 @@
 extern "C" {
 #endif
 
-#define RWKV_ABI_VERSION 5   /* 2: rwkv_sample_params gained kind/tau; rwkv_engine_save_prefab
+#define RWKV_ABI_VERSION 6   /* 2: rwkv_sample_params gained kind/tau; rwkv_engine_save_prefab
                               * 3: rwkv_sample_params gained allow (formatter mask); rwkv_host_alloc/free; RWKV_OPTION_NONE
                               * 4: rwkv_engine_token_chunk_size
-                              * 5: rwkv_state_back_layer_async / rwkv_state_sync */
+                              * 5: rwkv_state_back_layer_async / rwkv_state_sync
+                              * 6: no new symbol — rwkv_infer no longer waits for a step that emits no row; rwkv_state_back_layer_async checks
+                              *    that the rows end inside the pinned block that holds `dst` */
 
 typedef int32_t rwkv_status;
 enum {

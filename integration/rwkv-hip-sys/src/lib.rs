@@ -3,7 +3,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_float, c_void};
 
-pub const RWKV_ABI_VERSION: i32 = 5;
+pub const RWKV_ABI_VERSION: i32 = 6;
 
 pub type rwkv_status = i32;
 pub const RWKV_OK: rwkv_status = 0;
