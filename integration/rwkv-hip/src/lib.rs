@@ -228,7 +228,7 @@ impl<'a> PendingRows<'a> {
         let r = self.rt.state_sync();
         self.waited = true;
         // SAFETY: `self` is consumed and its Drop (below) does nothing once `waited`; the reference is re-borrowed for the original lifetime
-        let dst: *mut PinnedLogits = self.dst;
+        let dst: *mut PinnedLogits = &mut *self.dst;                 // a reborrow, not a move out of a `Drop` type
         r.map(|_| unsafe { &mut *dst })
     }
 }
