@@ -192,3 +192,36 @@ def test_committed_roofline_table_is_what_the_script_generates():
         fracs = [float(x) for x in re.findall(r"\| (\d\.\d+) \((?:HBM|MFMA)\) \|", r.stdout)]
         assert fracs and max(fracs) <= 1.0
     assert "ambiguous" not in open(os.path.join(ROOT, "profiles", "r5_roofline_table.md")).read()       # round 5's logs carry the block size
+
+
+def test_roofline_table_never_prices_two_different_launches_as_one_row(tmp_path):
+    """The join of scripts/roofline_table.py on a fixture: two decode launches with the SAME grid and different block sizes (round 4's
+    1.074 row) are priced separately when the launch log carries block sizes, and reported as ambiguous — not priced — when it does not;
+    a row kernel gets its bytes from a `row` log entry; a fraction above 1 makes the script fail instead of printing it."""
+    script = os.path.join(ROOT, "scripts", "roofline_table.py")
+    csv_text = ("kernel,workgroups,threads,calls,total_us,avg_us,min_us,max_us,pct\n"
+                '"gemm_kernel<1, 8, false, true, false>(GemmLaunch)",256,640,100,2000.0,20.00,19.0,21.0,50.0\n'
+                '"gemm_kernel<1, 8, false, true, false>(GemmLaunch)",256,512,100,1000.0,10.00,9.0,11.0,25.0\n'
+                '"ln_shift_kernel<1, 1024>(LnShiftArgs)",8,1024,200,1000.0,5.00,4.0,6.0,25.0\n')
+    big = {"kind": "decode", "variant": 1, "T": 8, "grid": 256, "threads": 640, "ksplit": 1, "rows": 4096, "bytes": 100_000_000, "flops": 1e9, "mats": "blocks.0.ffn.value.weight"}
+    small = dict(big, threads=512, bytes=30_000_000, mats="blocks.0.att.output.weight")
+    row = {"kind": "row", "kernel": "ln_shift_kernel", "T": 8, "grid": 8, "bytes": 1_000_000}
+
+    def run(entries, name="tX"):
+        d = tmp_path / name
+        d.mkdir()
+        (d / f"{name}_kernel_stats_v6-7b_fp16_b8.csv").write_text(csv_text)
+        (d / f"{name}_launch_log_v6-7b_fp16_b8.jsonl").write_text("\n".join(json.dumps(e) for e in entries) + "\n")
+        return subprocess.run([sys.executable, script, name, str(d)], capture_output=True, text=True, timeout=60)
+
+    r = run([big, small, row], "ta")
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("| `")]
+    assert "ffn.value" in lines[0] and "att.output" not in lines[0] and "100.0 MB" in lines[0] and "0.625 (HBM)" in lines[0]      # 100 MB / 20 us = 5 TB/s
+    assert "att.output" in lines[1] and "ffn.value" not in lines[1] and "30.0 MB" in lines[1] and "0.375 (HBM)" in lines[1]
+    assert "1.0 MB" in lines[2] and "(HBM)" in lines[2]
+    legacy = [{k: v for k, v in e.items() if k != "threads"} for e in (big, small)]
+    r = run(legacy, "tb")
+    assert r.returncode == 0 and r.stdout.count("ambiguous") == 2 and "MB |" not in "".join(l for l in r.stdout.splitlines() if "gemm_kernel" in l)
+    r = run([dict(big, bytes=400_000_000), small], "tc")                       # 400 MB in 20 us = 20 TB/s: impossible, the script must refuse
+    assert r.returncode != 0 and "AssertionError" in r.stderr
