@@ -525,6 +525,8 @@ def cpu_leg(R, tensors, ql, qt, first, workload, quant):
            "sample": f"{n_step} lock-step decode steps of {B} slots ({B * n_step} tokens), {how}, {workload} {quant}"}
     if hasattr(ref, "stream_gbps"):
         cpu["effective_weight_stream_GBps"] = ref.stream_gbps(n_step / cdt)
+        cpu["note"] = ("a stated baseline, not a tuned CPU implementation: at this batch the C GEMM (fp16 -> fp32 convert + FMA per slot) is compute-bound, "
+                       "it streams weights well below what the same cores reach at batch 1 (config1_effective_weight_stream_GBps)")
     del ref, st_cpu
     # BASELINE config #1: RWKV-V5-World-0.4B fp16, batch 1, greedy, on the CPU path (the reference has no CPU backend,
     # lib.rs:339-368; this is the port)
