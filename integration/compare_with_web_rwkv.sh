@@ -29,9 +29,9 @@ build_tree () {   # $1 = destination, $2 = "stock" | "hip"
     git -C "$AI00" worktree add --detach "$1" HEAD >/dev/null
     if [ "$2" = hip ]; then
         (cd "$1" && git apply "$HERE/ai00-core.patch" &&
-            sed -i "s#path = \"../../../integration/rwkv-hip\"#path = \"$HERE/rwkv-hip\"#" crates/ai00-core/Cargo.toml)
+            sed -i "s#path = \"../../../integration/rwkv-hip\"#path = \"$HERE/rwkv-hip\"#" crates/ai00-core/Cargo.toml crates/ai00-server/Cargo.toml)
     fi
-    (cd "$1" && cargo build --release -p ai00_server)
+    (cd "$1" && cargo build --release -p ai00-server)
 }
 config () {       # $1 = tree, $2 = port
     mkdir -p "$1/assets/models"
@@ -41,7 +41,7 @@ config () {       # $1 = tree, $2 = port
         -e "s#^max_batch = .*#max_batch = 8#" -e "s#^port = .*#port = $2#" "$1/assets/configs/Config.toml" > "$1/compare.toml"
 }
 serve () {        # $1 = tree, $2 = port
-    (cd "$1" && ./target/release/ai00_server --config compare.toml > "$WORK/server_$2.log" 2>&1) &
+    (cd "$1" && ./target/release/ai00-server --config compare.toml > "$WORK/server_$2.log" 2>&1) &
     for _ in $(seq 1 600); do curl -sf "http://127.0.0.1:$2/api/oai/models" >/dev/null && return 0; sleep 1; done
     echo "server on port $2 did not come up: $WORK/server_$2.log" >&2; tail -20 "$WORK/server_$2.log" >&2; exit 3
 }

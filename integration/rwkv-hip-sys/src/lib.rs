@@ -1,4 +1,4 @@
-//! Raw bindings of `include/rwkv_abi.h` (ABI version 5), one `pub fn` per export, in the header's order.
+//! Raw bindings of `include/rwkv_abi.h` (ABI version 6), one `pub fn` per export, in the header's order.
 //! tests/test_abi_cpu.py diffs this file against the header (names and argument counts) and against the built library.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_float, c_void};

@@ -3,13 +3,15 @@
 //! What is NOT here: `wgpu` adapters (replaced by `list_adapters`), `ContextBuilder::auto_limits`, `v4` (unsupported:
 //! RWKV_ERR_UNSUPPORTED), the CBOR `Seed`/`Prefab` (the prefab image is this library's own; `Engine::load` sniffs it).
 use crate::{Adapter, DeviceState, Engine, Error, LoadDesc, OutputOption, PinnedLogits, Precision, QuantType, SlotInput};
+use serde::{Deserialize, Serialize};
 use std::sync::{Arc, Mutex};
 
 pub type TensorError = Error;
 pub type RuntimeError = Error;
 
-#[derive(Debug, Clone, Copy, PartialEq, Eq)] pub enum ModelVersion { V4, V5, V6, V7 }
-#[derive(Debug, Clone)]
+// serde: `RuntimeInfo` / `FileInfo` / `InfoResponse` carry a `ModelInfo` to the HTTP layer (ai00-server api/model.rs:15, api/file.rs:68)
+#[derive(Debug, Clone, Copy, PartialEq, Eq, Serialize, Deserialize)] pub enum ModelVersion { V4, V5, V6, V7 }
+#[derive(Debug, Clone, Serialize, Deserialize)]
 pub struct ModelInfo { pub version: ModelVersion, pub num_layer: usize, pub num_emb: usize, pub num_hidden: usize,
                        pub num_vocab: usize, pub num_head: usize }
 impl From<crate::RawInfo> for ModelInfo {
@@ -22,10 +24,12 @@ impl From<crate::RawInfo> for ModelInfo {
 pub struct Loader;
 impl Loader { pub fn info(bytes: &[u8]) -> Result<ModelInfo, Error> { crate::model_info(bytes).map(Into::into) } }
 
-#[derive(Debug, Clone, Copy, PartialEq, Eq)] pub enum Quant { None, Int8, NF4, SF4 }
+/// `reload::Model::quant_type` / `ReloadRequest::quant_type` (reload.rs:27, lib.rs:207): read from `Config.toml` and the `/api/models/load` body
+#[derive(Debug, Default, Clone, Copy, PartialEq, Eq, Hash, Serialize, Deserialize)] pub enum Quant { #[default] None, Int8, NF4, SF4 }
 
 /// `TensorCpu<f32>`: shape `[x, y, z, w]` (x fastest) + data, the only form ai00-core uses (run.rs:131, 202, 314, 666-697, 987)
-#[derive(Debug, Clone)]
+/// serde (`Arc` needs serde's `rc` feature, Cargo.toml): `InitState` derives both (lib.rs:294-301; cbor `.state` files, run.rs:406)
+#[derive(Debug, Clone, Serialize, Deserialize)]
 pub struct TensorCpu<T> { shape: [usize; 4], data: Arc<Vec<T>> }
 impl<T: Clone> TensorCpu<T> {
     pub fn from_data(shape: [usize; 4], data: Vec<T>) -> Result<Self, Error> {
@@ -46,7 +50,7 @@ impl<T: Clone> TensorCpu<T> {
 }
 impl<T> std::ops::Deref for TensorCpu<T> { type Target = [T]; fn deref(&self) -> &[T] { &self.data } }
 /// `TensorGpu<f32, ReadWrite>` as ai00-core uses it: an opaque state snapshot (run.rs:351-355, 772-789)
-#[derive(Clone)] pub struct TensorGpu(pub Arc<DeviceState>);
+#[derive(Debug, Clone)] pub struct TensorGpu(pub Arc<DeviceState>);   // Debug: `InferBatch` derives it (run.rs:327)
 
 #[derive(Debug, Clone, Copy, PartialEq, Eq, Default)] pub enum RnnOption { #[default] Last, Full }
 #[derive(Debug, Clone, Default)] pub struct RnnInputBatch { pub tokens: Vec<u32>, pub option: RnnOption }
@@ -60,10 +64,10 @@ impl RnnInput {
 impl RnnOutputBatch { pub fn is_empty(&self) -> bool { self.0.is_empty() } }
 
 /// `Arc<dyn Runtime<Rnn>>` + `Arc<dyn State>` + the `Context` the softmax task holds: all views of one engine
-#[derive(Clone)]
+#[derive(Debug, Clone)]
 pub struct Runtime { engine: Arc<Engine>, logits: Arc<Mutex<PinnedLogits>> }
-#[derive(Clone)] pub struct State { engine: Arc<Engine> }
-#[derive(Clone)] pub struct Context { engine: Arc<Engine> }
+#[derive(Debug, Clone)] pub struct State { engine: Arc<Engine> }
+#[derive(Debug, Clone)] pub struct Context { engine: Arc<Engine> }   // Debug: `CoreRuntime` derives it with a `Context` field (run.rs:365-369)
 
 impl Runtime {
     /// `ModelSerialize::serialize` (lib.rs:131-154): the loaded model as one prefab image

@@ -50,18 +50,21 @@ pub struct LoadDesc<'a> {
 }
 
 /// = Context + Model + vN::Bundle + TokioRuntime<Rnn> + State of the reference (lib.rs:484-516)
+#[derive(Debug)]
 pub struct Engine { raw: *mut sys::rwkv_engine, pub info: RawInfo, pub max_batch: usize, pub token_chunk_size: usize }
 unsafe impl Send for Engine {}
 unsafe impl Sync for Engine {}
 impl Drop for Engine { fn drop(&mut self) { unsafe { sys::rwkv_engine_destroy(self.raw) } } }
 
 /// device-resident state snapshot (`TensorGpu<f32, ReadWrite>` of run.rs:351-355); clone = share the handle
+#[derive(Debug)]
 pub struct DeviceState(*mut sys::rwkv_dstate);
 unsafe impl Send for DeviceState {}
 unsafe impl Sync for DeviceState {}
 impl Drop for DeviceState { fn drop(&mut self) { unsafe { sys::rwkv_dstate_free(self.0) } } }
 
 /// pinned host block for the logits of one `infer` call (rwkv_host_alloc): rows land here in one device-to-host copy
+#[derive(Debug)]
 pub struct PinnedLogits { ptr: *mut f32, floats: usize }
 unsafe impl Send for PinnedLogits {}
 impl PinnedLogits {
@@ -200,11 +203,11 @@ impl Engine {
     }
 }
 
-/// Read-backs in flight into one pinned block (`Runtime::state_back_layer_async`).  Holds the block's mutable borrow until the copy
+/// Read-backs in flight into one pinned block (`Engine::state_back_layer_async`).  Holds the block's mutable borrow until the copy
 /// stream has been waited for: `sync()` gives the block back; `Drop` waits as well, so no path — early return, `?`, panic unwinding —
 /// lets the block be read or freed under the DMA.
 pub struct PendingRows<'a> {
-    rt: &'a Runtime,
+    rt: &'a Engine,
     dst: &'a mut PinnedLogits,
     ranges: Vec<(usize, usize)>,
     waited: bool,
@@ -237,6 +240,7 @@ impl Drop for PendingRows<'_> {
 }
 
 /// `Tokenizer` (lib.rs:375; run.rs:157-168, 856; sampler/bnf.rs:14-27)
+#[derive(Debug)]                       // `RuntimeInfo`, `ThreadRequest` and `CoreRuntime` derive Debug over an `Arc<Tokenizer>` (lib.rs:80, 116; run.rs:374)
 pub struct Tokenizer(*mut sys::rwkv_tokenizer);
 unsafe impl Send for Tokenizer {}
 unsafe impl Sync for Tokenizer {}

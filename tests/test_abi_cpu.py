@@ -252,6 +252,64 @@ def test_reference_patch_still_applies():
     assert r.returncode == 0, r.stderr
 
 
+def test_patched_workspace_names_only_items_the_wrapper_exports(tmp_path):
+    """What can be checked of the patch without rustc: applied to a scratch copy of the reference's `crates/`, (1) no Rust source of the
+    workspace still names `web_rwkv` (round 5 found reload.rs, sampler/bnf.rs and two ai00-server files the patch had not reached — the
+    dependency was gone, the imports were not), (2) every item imported from `rwkv_hip` / `rwkv_hip::compat` is a `pub` item of
+    integration/rwkv-hip, (3) the call of `load_model_state` matches its patched signature, (4) the derives ai00-core's types demand of
+    the wrapper's items are there (serde on TensorCpu / ModelInfo / Quant, Debug on Tokenizer / Context / TensorGpu)."""
+    import re, shutil, subprocess
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "crates", "ai00-core")):
+        pytest.skip("the reference checkout is not on this machine")
+    shutil.copytree(os.path.join(ref, "crates"), tmp_path / "crates")
+    subprocess.run(["patch", "-p1", "-s", "-i", os.path.join(ROOT, "integration", "ai00-core.patch")], cwd=tmp_path, check=True)
+    sources = {}
+    for d, _, files in os.walk(tmp_path / "crates"):
+        for f in files:
+            if f.endswith(".rs"):
+                sources[os.path.relpath(os.path.join(d, f), tmp_path)] = open(os.path.join(d, f)).read()
+    left = [p for p, s in sources.items() if re.search(r"\bweb_rwkv::|use web_rwkv\b", s)]
+    assert not left, f"still importing web_rwkv after the patch: {left}"
+    for toml in ("crates/ai00-core/Cargo.toml", "crates/ai00-server/Cargo.toml"):
+        t = open(tmp_path / toml).read()
+        assert "rwkv-hip = { path" in t and "web-rwkv.workspace" not in t, toml
+    lib = open(os.path.join(ROOT, "integration", "rwkv-hip", "src", "lib.rs")).read()
+    compat = open(os.path.join(ROOT, "integration", "rwkv-hip", "src", "compat.rs")).read()
+    pub = lambda s: set(re.findall(r"\bpub (?:struct|enum|type|fn|use crate::)\s*([A-Za-z_]\w*)", s))
+    exported = {"rwkv_hip": pub(lib) | {"compat"}, "rwkv_hip::compat": pub(compat)}
+    n_imports = 0
+    for path, s in sources.items():
+        for m in re.finditer(r"use (rwkv_hip(?:::compat)?)::(\{[^;]*\}|\w+)\s*;", s):
+            body = m.group(2)
+            # nested groups: `rwkv_hip::{compat::{A, B}, Adapter}`
+            for inner in re.finditer(r"compat::\{([^}]*)\}", body):
+                for name in re.findall(r"(\w+)(?:\s+as\s+\w+)?\s*(?:,|$)", inner.group(1).strip()):
+                    assert name in exported["rwkv_hip::compat"], f"{path}: rwkv_hip::compat::{name} is not exported"
+                    n_imports += 1
+            flat = re.sub(r"compat::\{[^}]*\}", "", body).strip("{} \n")
+            for name in re.findall(r"(\w+)(?:\s+as\s+\w+)?\s*(?:,|$)", flat):
+                assert name in exported[m.group(1)], f"{path}: {m.group(1)}::{name} is not exported"
+                n_imports += 1
+    assert n_imports >= 25, n_imports
+    core_lib, run = sources["crates/ai00-core/src/lib.rs"], sources["crates/ai00-core/src/run.rs"]
+    assert re.search(r"fn load_model_state\(state: &State, data: &\[u8\]\)", core_lib)
+    calls = re.findall(r"load_model_state\(([^)]*)\)", core_lib + run)
+    assert calls and all(c.count(",") == 1 for c in calls), calls               # two arguments everywhere: (&State, bytes)
+    assert "state.len()" not in core_lib and "init_states.len()" in core_lib          # the request's list is not shadowed by the engine's State
+    assert "struct Prefab" not in core_lib and "TensorError" in re.search(r"use rwkv_hip::\{[^;]*\};", core_lib).group(0)
+    for item, needs in (("pub struct TensorCpu", ("Serialize", "Deserialize", "Debug", "Clone")), ("pub struct ModelInfo", ("Serialize", "Deserialize", "Debug", "Clone")),
+                        ("pub enum Quant", ("Serialize", "Deserialize", "Default", "Debug", "Clone")), ("pub struct TensorGpu", ("Debug", "Clone")),
+                        ("pub struct Context", ("Debug", "Clone")), ("pub struct Tokenizer", ("Debug",)), ("pub struct DeviceState", ("Debug",)), ("pub struct Engine", ("Debug",))):
+        src = compat if item in compat else lib
+        head = src[:src.index(item)]
+        derive = head[head.rindex("#[derive("):]
+        assert derive.count("\n") <= 2, item                                        # the derive belongs to this item, not an earlier one
+        for d in needs:
+            assert re.search(r"\b%s\b" % d, derive), f"{item} must derive {d}"
+    assert 'features = ["derive", "rc"]' in open(os.path.join(ROOT, "integration", "rwkv-hip", "Cargo.toml")).read()
+
+
 def test_mutated_inputs_never_abort(built_lib, tmp_path):
     """"Nothing aborts" (include/rwkv_abi.h): tests/cpp/fuzz_cpu_entry_points.cpp throws mutated safetensors headers, truncated files,
     mutated vocabularies, random byte strings / token ids / chunk plans at the entry points that run on a CPU; the process must come

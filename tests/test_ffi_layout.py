@@ -169,3 +169,37 @@ def test_web_rwkv_comparison_script_is_well_formed():
     text = open(path).read()
     for needle in ("/api/oai/", '"completions"', '"states"', '"sampler"', '"top_k": 1', "ai00-core.patch", "cargo build"):
         assert needle in text, needle
+
+
+def _rust_code(path):
+    """a Rust source with comments, string literals and lifetimes blanked out (enough for identifier checks; no raw strings in these files)"""
+    s = open(path).read()
+    s = re.sub(r"//[^\n]*", "", s)
+    s = re.sub(r'"(?:\\.|[^"\\])*"', '""', s)
+    return re.sub(r"'[a-z_]+\b(?!')", "", s)
+
+
+def test_every_type_name_the_safe_wrapper_uses_resolves():
+    """No rustc in this image (integration/check.sh has never run here), so the cheapest class of compile error is checked by hand: every
+    CamelCase identifier of rwkv-hip's two source files must be defined in the file, imported by a `use`, a variant of one of its enums, a
+    generic parameter, or a name of the std prelude / derive set.  (Round 5: `PendingRows` held a `&Runtime` in lib.rs, where the type is
+    `Engine` — `Runtime` only exists in compat.rs.)  The sys crate's version follows RWKV_ABI_VERSION."""
+    std_names = set("""Vec String Option Some None Ok Err Result Self Box Send Sync Drop Default Debug Clone Copy PartialEq Eq From Into FnMut Fn
+                       Arc Mutex CStr CString Deref Target Error Iterator Hash""".split())
+    for name in ("lib.rs", "compat.rs"):
+        s = _rust_code(os.path.join(ROOT, "integration", "rwkv-hip", "src", name))
+        defined = set(re.findall(r"\b(?:struct|enum|type|trait|mod)\s+([A-Z]\w*)", s))
+        for body in re.findall(r"\benum\s+\w+\s*\{([^}]*)\}", s):
+            defined |= set(re.findall(r"\b([A-Z]\w*)\b", body))
+        for group in re.findall(r"\buse\s+([^;]+);", s):
+            defined |= set(re.findall(r"\b([A-Z]\w*)\b", group))
+        defined |= set(re.findall(r"<\s*([A-Z])\s*[:>,]", s)) | set(re.findall(r",\s*([A-Z])\s*>", s)) | set(re.findall(r"<([A-Z])>", s))   # generic parameters T, U
+        used = set(re.findall(r"(?<![\w:.])([A-Z][a-z]\w*)\b", s))                  # CamelCase not behind a path separator (sys::X, crate::X are checked by rustc's import rules above)
+        unknown = sorted(u for u in used - defined - std_names if not u.isupper())
+        assert not unknown, f"{name}: identifiers that resolve to nothing in scope: {unknown}"
+    cargo = open(os.path.join(ROOT, "integration", "rwkv-hip-sys", "Cargo.toml")).read()
+    header = open(os.path.join(ROOT, "include", "rwkv_abi.h")).read()
+    abi = int(re.search(r"#define\s+RWKV_ABI_VERSION\s+(\d+)", header).group(1))
+    assert re.search(r'^version = "0\.(\d+)\.', cargo, re.M).group(1) == str(abi)
+    sys_rs = open(os.path.join(ROOT, "integration", "rwkv-hip-sys", "src", "lib.rs")).read()
+    assert f"(ABI version {abi})" in sys_rs and f"RWKV_ABI_VERSION: i32 = {abi};" in sys_rs
