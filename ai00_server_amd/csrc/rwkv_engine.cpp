@@ -1006,7 +1006,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const ShiftComm
             const bool in_range = big_f16 ? (T > 320 && T <= 768) : (T <= 320 || (!big_not_nf4 && T > 768 && T <= 1280));
             if (ok3 && !linear_launch && in_range) shape = GEMM_TILE3_64;
         }
-        if (f_shape >= 0 && f_shape < GEMM_TILE_SHAPES && ((f_shape != GEMM_TILE3 && f_shape != GEMM_TILE3_64) || ok3)) shape = f_shape;
+        if (f_shape >= 0 && f_shape < GEMM_TILE_SHAPES && (!gemm_tile_pipelined(f_shape) || ok3)) shape = f_shape;
         // K split of a linear launch on the pipelined kernel (Wo, Fv: one `partial` problem whose output the next row kernel sums
         // anyway): a grid of fewer than 512 tiles costs a whole round of the kernel, so the tiles are replicated over `ksb` K ranges
         // until the rounds are full — 3 x 320 tiles (V6-3B at 2048 rows) fill 94 % of two rounds a third as long (tg3_body).
@@ -2051,7 +2051,7 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
                         shape = GEMM_TILE3;
                         for (int sh = 0; sh < GEMM_TILE_SHAPES; ++sh) if (gemm_tile_blocks(sh, rows, T) >= 1024) { shape = sh; break; }
                     }
-                    if ((shape == GEMM_TILE3 || shape == GEMM_TILE3_64) && !gemm_tile3_supported(hilo != 0, K)) throw RwkvError(RWKV_ERR_INVALID, "bench_gemm: shapes 10 / 11 need K % 128 == 0 and no hi/lo operand");
+                    if (gemm_tile_pipelined(shape) && !gemm_tile3_supported(hilo != 0, K)) throw RwkvError(RWKV_ERR_INVALID, "bench_gemm: shapes 10 / 11 need K % 128 == 0 and no hi/lo operand");
                     Lh = GemmLaunch{};
                     Lh.nprob = 1; Lh.T = T;
                     GemmProb &g = Lh.p[0];

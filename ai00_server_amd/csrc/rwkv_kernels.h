@@ -136,6 +136,7 @@ constexpr int GEMM_TILE_SHAPES = 12;                      // 256x128, 128x128, 6
 int gemm_tile_blocks(int shape, int rows, int T);
 constexpr int GEMM_TILE3 = 10;                            // the pipelined 128x128 kernel (non-hi/lo operands, K % 128 == 0)
 constexpr int GEMM_TILE3_64 = 11;                         // the same pipeline on 128 rows x 64 tokens (steps of a few hundred rows)
+inline bool gemm_tile_pipelined(int shape) { return shape == GEMM_TILE3 || shape == GEMM_TILE3_64; }
 bool gemm_tile3_supported(bool hilo, int K);
 void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s);                             // rounds of 256 k a wave can hold at once (single-shot)
 

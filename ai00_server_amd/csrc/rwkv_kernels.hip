@@ -1629,12 +1629,21 @@ constexpr int T3_NB = 4;
 // A register written by such a load is used only after (1) a counted wait that retires the load and (2) t3_arrived(), an empty
 // asm that makes the compiler treat the register as produced at that point, so no use can be scheduled ahead of the wait.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void t3_ld16(u32x4 &d, const void *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
-__device__ __forceinline__ void t3_ld8(u32x2 &d, const void *p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
-__device__ __forceinline__ void t3_dma16(const void *g, unsigned lds_byte) {      // lane l -> LDS byte lds_byte + 16 l; M0 preserved
+// Addresses are SGPR base + 32-bit VGPR byte offset (+ immediate): the lane part (strip, lane) is computed once per block, the part that
+// moves along K is wave-uniform and lives in scalar registers — no 64-bit vector add per load, and nothing of the problem record is
+// re-read inside the loop.  (Round 5, s_memtime stamps: with per-lane 64-bit pointers rebuilt from the GemmProb fields at every weight
+// group — two scalar loads and a wait for them, ~25 scalar and 6 vector address instructions — issuing a stage's loads took 300 cycles
+// of the 1,200 a stage of a block alone on its CU lasts, 600 of 1,780 with two blocks on the CU: profiles/r5_exp_tile3_stage_trace.log.)
+template <int OFF> __device__ __forceinline__ void t3_ld16(u32x4 &d, unsigned voff, const void *sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void t3_ld8(u32x2 &d, unsigned voff, const void *sbase) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void t3_dma16(unsigned voff, const void *sbase, unsigned lds_byte) {      // lane l -> LDS byte lds_byte + 16 l; M0 preserved
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds_byte) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
 }
 template <int N> __device__ __forceinline__ void t3_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -1674,51 +1683,71 @@ __device__ __forceinline__ void t3_tail(f32x4 (&acc)[SPW][NTW], const f16x8 (&a)
         t3_tail<NTW, SPW, NT + 1>(acc, a, x);
     }
 }
-// weight group of 128 k for two strips: tile loads + (quantised) one scale word per strip; NLOAD = VMEM instructions issued
-template <int FMT> struct T3Set {
-    static constexpr int NQ = 4 / Fmt<FMT>::KS, NLOAD = 2 * NQ + (FMT == W_F16 ? 0 : 2);
-    u32x4 q[2][NQ];
-    u32x2 s[2];
+// weight group of 128 k for SPW strips: tile loads + (quantised) one scale word per strip; NLOAD = VMEM instructions issued
+template <int FMT, int SPW> struct T3Set {
+    static constexpr int NQ = 4 / Fmt<FMT>::KS, NLOAD = SPW * NQ + (FMT == W_F16 ? 0 : SPW);
+    u32x4 q[SPW][NQ];
+    u32x2 s[SPW];
 };
-template <int FMT>
-__device__ __forceinline__ void t3_load(T3Set<FMT> &w, const GemmProb &P, int strip, int nstrips, int k0, int lane) {
-    constexpr int SH = Fmt<FMT>::SH;
-    const int KT = P.K >> SH;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int sidx = min(strip + h, nstrips - 1);
-        const u32x4 *base = (const u32x4 *)P.W + ((long)sidx * KT + (k0 >> SH)) * 64 + lane;
-#pragma unroll
-        for (int j = 0; j < T3Set<FMT>::NQ; ++j) t3_ld16(w.q[h][j], base + j * 64);
-        if constexpr (FMT != W_F16) t3_ld8(w.s[h], (const u32x2 *)P.S + ((long)sidx * (P.K >> 8) + (k0 >> 8)) * 16 + (lane & 15));
+// the lane's byte offsets into the weight tiles / scale words of its SPW strips (K-independent), and the group load: wg / sg = the matrix'
+// and scale bases advanced to the group's k (wave-uniform)
+template <int SPW> struct T3Off { unsigned w[SPW], s[SPW]; };
+template <int FMT, int SPW, int J = 0>
+__device__ __forceinline__ void t3_load_tiles(T3Set<FMT, SPW> &w, int h, unsigned voff, const void *wg) {
+    if constexpr (J < T3Set<FMT, SPW>::NQ) {
+        t3_ld16<J * 1024>(w.q[h][J], voff, wg);
+        t3_load_tiles<FMT, SPW, J + 1>(w, h, voff, wg);
     }
 }
-template <int FMT> __device__ __forceinline__ void t3_arrived(T3Set<FMT> &w) {
+template <int FMT, int SPW>
+__device__ __forceinline__ void t3_load(T3Set<FMT, SPW> &w, const T3Off<SPW> &o, const void *wg, const void *sg) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < SPW; ++h) {
+        t3_load_tiles<FMT, SPW>(w, h, o.w[h], wg);
+        if constexpr (FMT != W_F16) t3_ld8(w.s[h], o.s[h], sg);
+    }
+}
+template <int FMT, int SPW> __device__ __forceinline__ void t3_arrived(T3Set<FMT, SPW> &w) {
 #pragma unroll
-        for (int j = 0; j < T3Set<FMT>::NQ; ++j) asm volatile("" : "+v"(w.q[h][j]));
+    for (int h = 0; h < SPW; ++h) {
+#pragma unroll
+        for (int j = 0; j < T3Set<FMT, SPW>::NQ; ++j) asm volatile("" : "+v"(w.q[h][j]));
         if constexpr (FMT != W_F16) asm volatile("" : "+v"(w.s[h]));
     }
 }
 // A fragment of k-step ks (0..3) of the group at k0: same arithmetic as tg_frag, on a T3Set
-template <int FMT>
-__device__ __forceinline__ f16x8 t3_frag(const T3Set<FMT> &w, int h, int ks, int k0, const Nf4Lut &lut) {
+template <int FMT, int SPW>
+__device__ __forceinline__ f16x8 t3_frag(const T3Set<FMT, SPW> &w, int h, int ks, int k0, const Nf4Lut &lut) {
     TRound<FMT, 1, 128> r;
 #pragma unroll
-    for (int j = 0; j < T3Set<FMT>::NQ; ++j) r.q[0][j] = w.q[h][j];
+    for (int j = 0; j < T3Set<FMT, SPW>::NQ; ++j) r.q[0][j] = w.q[h][j];
     r.s[0] = make_uint2(w.s[h].x, w.s[h].y);
     return tg_frag<FMT, 1, 128>(r, 0, ks, k0, lut);
 }
 
+#ifdef RWKV_T3_TRACE
+// dev build (scripts/build_variant.py ... -DRWKV_T3_TRACE): shader-clock stamps at the points of a stage where the LGKM counter is drained
+// anyway (s_memtime answers through it), summed per wave and printed by a few waves — where a stage's cycles go
+__device__ unsigned g_t3_printed = 0;
+#define T3_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define T3_STAMP(var) do { } while (0)
+#endif
 // NTL = token tiles per block: 8 = the 128 x 128 tile; 4 = 128 rows x 64 tokens for steps of a few hundred rows (round 4: at 256 rows
-// the 128-token tile leaves 160 blocks for a 10304-row launch; this one 324, each moving half the operand)
-template <int FMT, int NTL>
+// the 128-token tile leaves 160 blocks for a 10304-row launch; this one 324, each moving half the operand).
+// What a stage costs (round 5, s_memtime stamps, profiles/r5_exp_tile3_stage_trace.log): a wave alone on its SIMD pays the SUM of what its
+// instructions cost to issue — 16 MFMAs 270 cycles, two LDS-DMAs and the weight loads 230, ~40 dequantisation VALU + eight fragment reads +
+// waits 350, the barrier 100: 1,200 per stage — and two waves on a SIMD overlap them (1,780 for a stage of each).  At 256 rows a 10304-row
+// launch is 324 tiles on 256 CUs and takes as long as a CU that got two.  Built on that and measured (profiles/r5_exp_tile3_192x64.log):
+// 192 x 64 tiles, one per CU, three strips per wave (33.3 us against 33.6: a block's time follows its MFMA count), and the same tile in
+// eight waves over two K halves (29.9 against 32.6 isolated, nothing in the model: 49.1 -> 48.8 k tok/s).  Both removed.
+// SPW = strips per wave (2 in every shape the engine uses).
+template <int FMT, int NTL, int SPW = 2>
 __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
-    constexpr int SPW = 2, BT = NTL * 16, STRIPS = 8, NA = T3Set<FMT>::NLOAD, WAVES = 4, NTW = NTL;
+    constexpr int BT = NTL * 16, WAVES = 4, STRIPS = WAVES * SPW, NA = T3Set<FMT, SPW>::NLOAD, NTW = NTL;
     constexpr int DPW = 2 * NTL / WAVES;                          // X tiles (DMAs) per wave per stage: 2 NTL tiles over the block's four waves
     constexpr int STAGE_HALFS = NTL * 2 * 512;                    // [token tile][k-step][lane][8]
-    using Set = T3Set<FMT>;
+    using Set = T3Set<FMT, SPW>;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nstrips = P.rows >> 4;
@@ -1757,18 +1786,40 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
 
     // the DPW X tiles of a stage this wave fetches: i = m*WAVES + wave -> (token tile i >> 1, k-step i & 1); tiles past the step
     // are clamped to its last tile (their columns are never stored)
-    const _Float16 *xsrc[DPW];
+    // (byte offsets of the lane inside the operand, 32-bit: the operand is T x K halfs; the stage's k moves in the scalar base)
+    unsigned xoff[DPW];
 #pragma unroll
     for (int m = 0; m < DPW; ++m) {
         const int i = m * WAVES + wave;
         const int ttile = min((t0 >> 4) + (i >> 1), last_tile);
-        xsrc[m] = P.xhi + ((long)ttile * (P.ldx >> 5) + (kofs >> 5) + (i & 1)) * 512 + lane * 8;
+        xoff[m] = (unsigned)(((ttile * (P.ldx >> 5) + (i & 1)) * 512 + lane * 8) * 2);
     }
+    const char *const xbase = (const char *)(P.xhi + (long)(kofs >> 5) * 512);
     auto dma = [&](int s) {
         const unsigned dst = xs_byte + (unsigned)(((s & (T3_NB - 1)) * STAGE_HALFS + wave * 512) * 2);
+        const char *xs_g = xbase + (long)s * 2048;                  // stage s: 64 k = two k-steps of 1 KiB tiles
 #pragma unroll
-        for (int m = 0; m < DPW; ++m) t3_dma16(xsrc[m] + (long)s * 1024, dst + m * WAVES * 1024);
+        for (int m = 0; m < DPW; ++m) t3_dma16(xoff[m], xs_g, dst + m * WAVES * 1024);
     };
+    // the weights: lane offsets once, the group's k in the scalar bases
+    T3Off<SPW> woff;
+    {
+        constexpr int SH = Fmt<FMT>::SH;
+        const int KT = P.K >> SH, KG = P.K >> 8;
+#pragma unroll
+        for (int h = 0; h < SPW; ++h) {
+            const int sidx = min(strip + h, nstrips - 1);
+            woff.w[h] = (unsigned)(sidx * KT * 64 + lane) * 16u;
+            woff.s[h] = (unsigned)(sidx * KG * 16 + (lane & 15)) * 8u;
+        }
+    }
+    const char *const wbase = (const char *)P.W, *const sbase = (const char *)P.S;
+    auto wload = [&](Set &w, int k0) {                               // weight group at absolute k0 (a multiple of 128)
+        t3_load<FMT, SPW>(w, woff, wbase + (long)(k0 >> Fmt<FMT>::SH) * 1024, sbase + (long)(k0 >> 8) * 128);
+    };
+#ifdef RWKV_T3_TRACE
+    unsigned long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_t3 = 0, tr_issue = 0, tr_stage = 0, tr_wait = 0, tr_begin = 0, tr_head = 0, tr_mid = 0;
+#endif
     auto stage = [&](const Set &w, int s, auto half) {
         constexpr int H = decltype(half)::value;
         const int k0 = kofs + (s >> 1) * 128;
@@ -1783,11 +1834,14 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
         __builtin_amdgcn_sched_barrier(0);
         f16x8 a0[SPW], a1[SPW];
 #pragma unroll
-        for (int h = 0; h < SPW; ++h) a0[h] = t3_frag<FMT>(w, h, H * 2, k0, lut);
+        for (int h = 0; h < SPW; ++h) a0[h] = t3_frag<FMT, SPW>(w, h, H * 2, k0, lut);
         __builtin_amdgcn_sched_barrier(0);
         t3_head<NTW, SPW>(acc, a0, x0, x1, xa);
+#if defined(RWKV_T3_TRACE) && RWKV_T3_TRACE >= 2
+        { unsigned long long m; T3_STAMP(m); tr_head += m - tr_t1; tr_mid = m; }       // (drains the second k-step's reads: a perturbation of its own)
+#endif
 #pragma unroll
-        for (int h = 0; h < SPW; ++h) a1[h] = t3_frag<FMT>(w, h, H * 2 + 1, k0, lut);
+        for (int h = 0; h < SPW; ++h) a1[h] = t3_frag<FMT, SPW>(w, h, H * 2 + 1, k0, lut);
         __builtin_amdgcn_sched_barrier(0);
         t3_tail<NTW, SPW>(acc, a1, x1);
     };
@@ -1798,23 +1852,40 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
         if (s + 4 < nst) t3_wait_barrier<2 * DPW + NA>();
         else if (s + 1 < nst) t3_wait_barrier<0>();
     };
+#ifdef RWKV_T3_TRACE
+    T3_STAMP(tr_begin);
+#endif
     auto super = [&](Set &cur, Set &refill, int sc) {
         int s = 2 * sc;
-        t3_arrived<FMT>(cur);
-        if (sc + 2 < nsc) t3_load<FMT>(refill, P, strip, nstrips, kofs + (sc + 2) * 128, lane);
+        T3_STAMP(tr_t0);
+        t3_arrived<FMT, SPW>(cur);
+        if (sc + 2 < nsc) wload(refill, kofs + (sc + 2) * 128);
         if (s + 3 < nst) dma(s + 3);
+        T3_STAMP(tr_t1);
         stage(cur, s, std::integral_constant<int, 0>{});
+        T3_STAMP(tr_t2);
         publish(s);
+        T3_STAMP(tr_t3);
+#ifdef RWKV_T3_TRACE
+        tr_issue += tr_t1 - tr_t0; tr_stage += tr_t2 - tr_t1; tr_wait += tr_t3 - tr_t2;
+#endif
         s += 1;
+        T3_STAMP(tr_t0);
         if (s + 3 < nst) dma(s + 3);
+        T3_STAMP(tr_t1);
         stage(cur, s, std::integral_constant<int, 1>{});
+        T3_STAMP(tr_t2);
         publish(s);
+        T3_STAMP(tr_t3);
+#ifdef RWKV_T3_TRACE
+        tr_issue += tr_t1 - tr_t0; tr_stage += tr_t2 - tr_t1; tr_wait += tr_t3 - tr_t2;
+#endif
     };
 
     Set a0, a1, a2;
-    t3_load<FMT>(a0, P, strip, nstrips, kofs, lane);
-    t3_load<FMT>(a1, P, strip, nstrips, kofs + (nsc > 1 ? 128 : 0), lane);
-    t3_load<FMT>(a2, P, strip, nstrips, kofs, lane);              // placeholder contents (every register defined); refilled at sc = 0
+    wload(a0, kofs);
+    wload(a1, kofs + (nsc > 1 ? 128 : 0));
+    wload(a2, kofs);              // placeholder contents (every register defined); refilled at sc = 0
     dma(0);
     if (nst > 1) dma(1);
     if (nst > 2) dma(2);
@@ -1824,6 +1895,15 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
         if (sc + 1 < nsc) super(a1, a0, sc + 1);
         if (sc + 2 < nsc) super(a2, a1, sc + 2);
     }
+#ifdef RWKV_T3_TRACE
+    {
+        unsigned long long tr_end;
+        T3_STAMP(tr_end);
+        if (lane == 0 && ((int)blockIdx.x == 0 || (int)blockIdx.x == 100 || (int)blockIdx.x == L.total_blocks - 1) && atomicAdd(&g_t3_printed, 1u) < 24u)
+            printf("t3trace blk %d/%d wave %d fmt %d spw %d nst %d | loop %llu = issue %llu + stage %llu + wait/barrier %llu (cycles; per stage %llu; first k-step of the stages %llu)\n",
+                   (int)blockIdx.x, L.total_blocks, wave, FMT, SPW, nst, tr_end - tr_begin, tr_issue, tr_stage, tr_wait, (tr_end - tr_begin) / (nst > 0 ? nst : 1), tr_head);
+    }
+#endif
     if (P.ksb > 1) {                                              // partial slab kb (host: out_f32 only, linear epilogue)
         GemmProb Q = P;
         Q.out_f32 = P.out_f32 + (long)kb * P.partial_stride;

@@ -6,6 +6,7 @@ for fmt in (1, 0):
     for shape in [int(x) for x in os.environ.get("SHAPES", "11,4,3,10").split(",")]:
         cells = []
         for T in [int(x) for x in os.environ.get("TS", "256,384,512,768,1024,2048").split(",")]:
-            us, blk = rt.bench_gemm(10240, 2560, fmt, T, False, shape, 24 if fmt else 12, 60)
-            cells.append(f"T={T}: {us:6.1f} us ({int(blk)} blk, {2.0 * 10240 * 2560 * T / us / 1e6:4.0f} TF)")
+            rows = int(os.environ.get("ROWS", "10240"))
+            us, blk = rt.bench_gemm(rows, 2560, fmt, T, False, shape, 24 if fmt else 12, 60)
+            cells.append(f"T={T}: {us:6.1f} us ({int(blk)} blk, {2.0 * rows * 2560 * T / us / 1e6:4.0f} TF)")
         print(f"fmt{fmt} shape {shape:2d} | " + " | ".join(cells), flush=True)
