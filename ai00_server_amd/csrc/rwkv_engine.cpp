@@ -232,10 +232,12 @@ struct rwkv_engine {
     int device = 0;
     int max_batch = 8, chunk = 128;
     bool hilo = false;
-    // Operand promotion (Knobs::promote, RWKV_PROMOTE): in Precision::Fp16 the GEMM launches of the classes whose bit is set read hi + lo f16
-    // operands like Precision::Fp32 does everywhere — the price of exactness is paid only where a model's error comes from
-    // (profiles/r5_fp16_error_attribution_*.jsonl: V7's Wr / Wk / Wv inputs carry 4.7e-3 of its 4.9e-3 at 32 layers).
+    // Operand promotion: in Precision::Fp16 the GEMM launches of the classes whose bit is set read hi + lo f16 operands like Precision::Fp32
+    // does everywhere — the price of exactness is paid only where a model's error comes from (profiles/r5_fp16_error_attribution_*.jsonl:
+    // V7's Wr / Wk / Wv inputs carry 4.7e-3 of its 4.9e-3 at 32 layers).  The mask is chosen from the model version (promote_for_version):
+    // that IS RWKV_PRECISION_FP16 since ABI 7; RWKV_PRECISION_FP16_RAW is mask 0; RWKV_PROMOTE=<mask> is a dev override of either.
     enum OpdClass { CLS_ATT = 0, CLS_LORA2 = 1, CLS_WO = 2, CLS_FFN1 = 3, CLS_FV = 4, CLS_HEAD = 5, CLS_NONE = 31 };
+    static int promote_for_version(int version) { return version == 7 ? 7 : 1; }   // V5 / V6: CLS_ATT; V7: CLS_ATT | CLS_LORA2 | CLS_WO
     int promote = 0;
     bool wide(int cls) const { return hilo || (cls < 31 && ((promote >> cls) & 1)); }
     int quant_layers = 0, quant_type = 0;
@@ -495,8 +497,11 @@ void rwkv_engine::load(const rwkv_load_desc &d) {
     chunk = d.token_chunk_size > 0 ? d.token_chunk_size : 128;
     kn = Knobs::from_env();                                  // frozen for the engine's lifetime (and for every graph it captures)
     use_knobs(kn);
+    if (d.precision != RWKV_PRECISION_FP16 && d.precision != RWKV_PRECISION_FP32 && d.precision != RWKV_PRECISION_FP16_RAW)
+        throw RwkvError(RWKV_ERR_INVALID, "precision must be RWKV_PRECISION_FP16, _FP32 or _FP16_RAW");
     hilo = d.precision == RWKV_PRECISION_FP32;
-    promote = hilo ? 0 : (kn.promote & 63);
+    promote = hilo ? 0 : (d.precision == RWKV_PRECISION_FP16 ? promote_for_version(info.version) : 0);
+    if (!hilo && kn.promote >= 0) promote = kn.promote & 63;   // dev override (A/B runs, the error-attribution experiments)
     quant_layers = std::max(0, std::min(d.quant_layers, L));
     quant_type = d.quant_type;
     if (pf) {                                                // a prefab is already quantised / blended: its settings win
@@ -1006,17 +1011,32 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const ShiftComm
             const bool in_range = big_f16 ? (T > 320 && T <= 768) : (T <= 320 || (!big_not_nf4 && T > 768 && T <= 1280));
             if (ok3 && !linear_launch && in_range) shape = GEMM_TILE3_64;
         }
-        if (f_shape >= 0 && f_shape < GEMM_TILE_SHAPES && (!gemm_tile_pipelined(f_shape) || ok3)) shape = f_shape;
+        // hi + lo operands (Precision::Fp32, and the launch classes Precision::Fp16 promotes): the software-pipelined 128 x 64 kernel whenever
+        // every K is a multiple of 128 — it fetches and dequantises a weight once for both operand halves: r/k/v/g Int8 46.8 us against 76.5 on
+        // the 64x64 shape at 256 rows, 262 against 547 at 2048 (profiles/r6_exp_tile4.log).  (V7's second-stage LoRAs, K = 64..320, stay on 64x64.)
+        bool ok4 = hilo;
+        for (auto &sp : ps) ok4 = ok4 && gemm_tile4_supported(hilo, sp.W->K);
+        if (ok4) shape = GEMM_TILE4_HILO;
+        if (f_shape >= 0 && f_shape < GEMM_TILE_SHAPES) {
+            bool okf = true;
+            for (auto &sp : ps) okf = okf && gemm_tile_shape_supported(f_shape, hilo, sp.W->K);
+            if (okf) shape = f_shape;
+            else if (gemm_tile_pipelined(f_shape) && ok4) shape = GEMM_TILE4_HILO;      // a forced pipelined shape means "the pipelined kernel of this operand form"
+            else if (gemm_tile_pipelined(f_shape)) shape = 4;
+        }
+        const bool wide_tile = shape == GEMM_TILE3;                                      // 128 x 128 pipelined tiles
+        const bool narrow_tile = shape == GEMM_TILE3_64 || shape == GEMM_TILE4_HILO;    // 128 x 64
+        const bool okp = ok3 || ok4;
         // K split of a linear launch on the pipelined kernel (Wo, Fv: one `partial` problem whose output the next row kernel sums
         // anyway): a grid of fewer than 512 tiles costs a whole round of the kernel, so the tiles are replicated over `ksb` K ranges
         // until the rounds are full — 3 x 320 tiles (V6-3B at 2048 rows) fill 94 % of two rounds a third as long (tg3_body).
         int ksplit = 1;
-        if (ok3 && kn.tile_ksplit && ps.size() == 1 && ps[0].partial && ps[0].post != POST_MIX && ps[0].act == ACT_NONE && !ps[0].bias &&
-            !ps[0].oh.hi && (f_shape < 0 || f_shape == GEMM_TILE3 || f_shape == GEMM_TILE3_64)) {
+        if (okp && kn.tile_ksplit && ps.size() == 1 && ps[0].partial && ps[0].post != POST_MIX && ps[0].act == ACT_NONE && !ps[0].bias &&
+            !ps[0].oh.hi && (f_shape < 0 || gemm_tile_pipelined(f_shape))) {
             const long t3 = gemm_tile_blocks(GEMM_TILE3, ps[0].W->rows, T);
             const int G = ps[0].W->K / 128;
-            double best = shape == GEMM_TILE3 ? (double)t3 / (((t3 + 511) / 512) * 512) : 0.0;
-            if (t3 >= 128) {
+            double best = wide_tile ? (double)t3 / (((t3 + 511) / 512) * 512) : 0.0;
+            if (t3 >= 128 && ok3) {
                 // a copy must keep >= 2048 k: the pipeline's ramp and the fp32 slab a tile writes are fixed costs per copy — measured
                 // (V6-3B Int8, 2048 rows): Fv (K = 8960) in three copies 200 -> 173 us, Wo (K = 2560) in three copies 67 -> 86 us
                 for (int b = 2; b <= 4 && G / b >= 16; ++b) {
@@ -1024,13 +1044,13 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const ShiftComm
                     if (fill > best + 0.10 && fill >= 0.80) { best = fill; ksplit = b; }
                 }
             }
-            if (shape == GEMM_TILE3_64) {
+            if (narrow_tile) {
                 // copies over K until the launch has about one block per CU, a copy keeping >= 768 k
                 const long t11 = gemm_tile_blocks(GEMM_TILE3_64, ps[0].W->rows, T);
                 ksplit = 1;
                 for (int b = 2; b <= 4 && ps[0].W->K / b >= 768 && t11 * (b - 1) < 224; ++b) ksplit = b;
             } else if (ksplit > 1) shape = GEMM_TILE3;
-            else if (shape != GEMM_TILE3) {
+            else if (!wide_tile) {
                 // the 64x64 shapes on a step of a few hundred rows: Wo / Fv have fewer tiles than the chip has CUs (160 at 256 rows of
                 // the 3 B model); copies over K fill it
                 const long t64 = gemm_tile_blocks(shape, ps[0].W->rows, T);
@@ -2009,16 +2029,38 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
         std::vector<void *> bufs;
         auto dal = [&](size_t n) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, n)); bufs.push_back(p); return p; };
         std::vector<DMat> mats(nmat);
+        // Random operands (round 6): zero or constant fills let the chip clock higher than real data does (the micro-architecture guide measures
+        // +15...21 % on a GEMM), so a zero-filled microbenchmark flatters every number it prints.  Weights: random bytes (fp16: random halfs of
+        // magnitude < 2; quantised: random codes, scale words near 0.01); X: uniform halfs in [-1, 1).
+        uint64_t rs = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+        std::vector<uint16_t> hbuf(std::max(wbytes, sbytes) / 2 + 8);
+        auto fill_halfs = [&](void *dst, size_t bytes, int kind) {      // 0: raw random bytes, 1: fp16 in (-2, 2), 2: fp16 scale ~0.01, 3: fp16 in [-1, 1)
+            const size_t n = (bytes + 1) / 2;
+            if (hbuf.size() < n) hbuf.resize(n);
+            for (size_t j = 0; j < n; ++j) {
+                const uint64_t r = rnd();
+                hbuf[j] = kind == 0 ? (uint16_t)r : kind == 1 ? (uint16_t)((r & 0x8000) | (0x3000 + (r >> 20) % 0x1000))
+                        : kind == 2 ? (uint16_t)(0x2100 + (r >> 20) % 0x100) : (uint16_t)((r & 0x8000) | (0x2C00 + (r >> 20) % 0x1000));
+            }
+            HIP_CHECK(hipMemcpy(dst, hbuf.data(), bytes, hipMemcpyHostToDevice));
+        };
         for (int i = 0; i < nmat; ++i) {
             mats[i].data = dal(wbytes); mats[i].scales = dal(sbytes);
-            HIP_CHECK(hipMemset((void *)mats[i].data, 0x11 + i, wbytes));
-            HIP_CHECK(hipMemset((void *)mats[i].scales, 0x2c, sbytes));
+            if (i == 0) { fill_halfs((void *)mats[i].data, wbytes, fmt == W_F16 ? 1 : 0); fill_halfs((void *)mats[i].scales, sbytes, 2); }
+            else {                                                       // the other copies: the same bytes rotated (device-to-device, cheap)
+                const size_t rot = ((size_t)i * 4099 * 16) % wbytes & ~(size_t)15;
+                HIP_CHECK(hipMemcpy((char *)mats[i].data, (const char *)mats[0].data + rot, wbytes - rot, hipMemcpyDeviceToDevice));
+                if (rot) HIP_CHECK(hipMemcpy((char *)mats[i].data + (wbytes - rot), mats[0].data, rot, hipMemcpyDeviceToDevice));
+                HIP_CHECK(hipMemcpy((void *)mats[i].scales, mats[0].scales, sbytes, hipMemcpyDeviceToDevice));
+            }
             mats[i].fmt = fmt; mats[i].rows = rows; mats[i].K = K;
         }
         Opd x; x.ld = K;
         const size_t xcap = (size_t)((T + 15) / 16 * 16) * x.ld * 2;
         x.hi = (_Float16 *)dal(xcap); x.lo = (_Float16 *)dal(xcap);
-        HIP_CHECK(hipMemset(x.hi, 0, xcap)); HIP_CHECK(hipMemset(x.lo, 0, xcap));
+        fill_halfs(x.hi, xcap, 3);
+        HIP_CHECK(hipMemcpy(x.lo, x.hi, xcap, hipMemcpyDeviceToDevice));
         float *out = (float *)dal((size_t)T * rows * 4);
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
@@ -2051,7 +2093,7 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
                         shape = GEMM_TILE3;
                         for (int sh = 0; sh < GEMM_TILE_SHAPES; ++sh) if (gemm_tile_blocks(sh, rows, T) >= 1024) { shape = sh; break; }
                     }
-                    if (gemm_tile_pipelined(shape) && !gemm_tile3_supported(hilo != 0, K)) throw RwkvError(RWKV_ERR_INVALID, "bench_gemm: shapes 10 / 11 need K % 128 == 0 and no hi/lo operand");
+                    if (!gemm_tile_shape_supported(shape, hilo != 0, K)) throw RwkvError(RWKV_ERR_INVALID, "bench_gemm: the pipelined shapes need K % 128 == 0; shapes 10 / 11 take plain operands, shape 12 hi + lo");
                     Lh = GemmLaunch{};
                     Lh.nprob = 1; Lh.T = T;
                     GemmProb &g = Lh.p[0];

@@ -490,7 +490,7 @@ Knobs Knobs::from_env() {
     k.no_tile = knob_env("RWKV_NO_TILE", 0); k.tile_shape = knob_env("RWKV_TILE_SHAPE", -1);
     k.no_dense = knob_env("RWKV_NO_DENSE", 0);
     k.tile_ksplit = knob_env("RWKV_TILE_KSPLIT", 1);
-    k.promote = knob_env("RWKV_PROMOTE", 0);
+    k.promote = knob_env("RWKV_PROMOTE", -1);
     return k;
 }
 static thread_local Knobs t_knobs;
@@ -1926,9 +1926,279 @@ __global__ __launch_bounds__(256, 2) void gemm_tile3_kernel(const GemmLaunch L) 
 }
 bool gemm_tile3_supported(bool hilo, int K) { return !hilo && K % 128 == 0; }
 
+// =====================================================================================
+// Software-pipelined tile kernel for hi + lo operands (shape 12; round 6): the prefill GEMM of Precision::Fp32 and of the launch classes
+// Precision::Fp16 promotes (rwkv_engine.cpp OpdClass).  Same tile, ring and weight path as gemm_tile3_kernel<4> — 128 rows x 64 tokens, 4 waves,
+// wave w owns strips {2w, 2w+1} x all token tiles, X in a ring of four LDS stages filled by global_load_lds, weights in three register sets
+// loaded two 128-k groups ahead — with a stage that holds the hi AND the lo tiles of its tokens: every A fragment feeds both (the
+// dequantisation is paid once, the weights are fetched once), which is why a hi + lo launch costs 1.35 x a plain one here and 1.85 x on the
+// 64x64 shape (V6-3B r/k/v/g Int8 at 256 rows: 46.8 us against 76.5; at 2048 rows 262 against 547; profiles/r6_exp_tile4.log).
+// The K loop is a software pipeline over K-STEPS (32 k) instead of a sequence of phases per stage: every MFMA of k-step q is followed by one
+// slice of the work for k-step q + 1 and for the stages ahead —
+//   * the ds_read_b128 of one B fragment of k-step q + 1 (slots 0 .. NBT-1), into the other of two fragment register sets;
+//   * its share of the dequantisation of the A fragments of k-step q + 1 (`t4_unit`), into the other of two A register sets;
+//   * in odd k-steps, behind the reads: the LDS-DMAs of stage s + 4 (the slot of stage s, which every wave finished reading before the
+//     barrier in the middle of stage s) and, every second stage, the loads of weight group g + 3 into the set group g just left.
+// `__builtin_amdgcn_sched_barrier(0)` after every slot and volatile-asm pins on the VALU results fix the interleave (checked in the ISA).
+// One barrier per stage, between its two k-steps:   s_waitcnt vmcnt(2 DPW + NA) lgkmcnt(0); s_barrier   publishes stage s + 1 (whose first
+// fragments are read during the stage's second k-step) — the VMEM instructions issued after DMA(s + 1) are DMA(s + 2), DMA(s + 3) and
+// exactly one weight group; the last four stages drain with vmcnt(0).
+// An accumulator receives, per k-step, its hi product and then its lo product, k-steps in order — the order of every other tile kernel's
+// hi + lo form: results are BIT-identical to the 64x64 shape's (tests/test_gpu_bench_paths.py race screen).
+// What the pipelining itself is worth was measured on the plain (non-hi/lo) form of this body against gemm_tile3 (profiles/r6_exp_tile4.log):
+// nothing — 33.6 us against 34.7 (r/k/v/g Int8, 256 rows), 170 against 167 at 2048 rows.  Ablations of the same build: without the MFMAs the
+// loop still takes 29.1 us, without any VMEM instruction inside the loop 25.9 (fp16 weights: 21.8).  A stage is not the sum of a wave's issue
+// slots (round 5's reading) but the VMEM instructions' issue time — each LDS-DMA / tile load holds the in-order wave for 60-185 cycles
+// (MI355X_MICROARCH.md), MFMAs behind it included — plus the LDS reads and waits; re-ordering the same instructions inside the same wave moves
+// nothing.  The plain form was therefore dropped again (gemm_tile3 stays); what would move it is taking the VMEM instructions out of the
+// MFMA waves (loader waves + weights through LDS).
+// =====================================================================================
+template <class F, int... I> __device__ __forceinline__ void t4_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void t4_for(F &&f) { if constexpr (N > 0) t4_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// per-(strip, weight group) dequantisation constants, computed when the pipeline moves on to the group's register set
+template <int FMT> struct T4Scale { u32 v[2][2]; };
+template <int FMT>
+__device__ __forceinline__ void t4_scales(T4Scale<FMT> &sc, const T3Set<FMT, 2> &w, int gabs /* absolute index of the 128-k group */) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if constexpr (FMT == W_INT8) {                              // {a, b} of the 128-block: group parity selects the word of the 256-k scale pair
+            const f16x2 abh = as_h2((gabs & 1) ? w.s[h].y : w.s[h].x);
+            sc.v[h][0] = as_u32((f16x2){abh[0], abh[0]});
+            sc.v[h][1] = as_u32((f16x2){abh[1], abh[1]});
+        } else if constexpr (FMT == W_NF4) {                        // absmax of the group's two 64-blocks
+            const f16x2 sh = as_h2((gabs & 1) ? w.s[h].y : w.s[h].x);
+            sc.v[h][0] = as_u32((f16x2){sh[0], sh[0]});
+            sc.v[h][1] = as_u32((f16x2){sh[1], sh[1]});
+        } else {
+            sc.v[h][0] = sc.v[h][1] = 0;
+        }
+    }
+}
+// One dequantisation unit = two of the four registers of an A fragment (UNITS = 2 per fragment).  Same arithmetic as tg_frag, bit for bit.
+// Every result is passed through a volatile asm: a pure VALU chain has no position of its own — the DAG scheduler sinks it to its use, i.e. into
+// the NEXT k-step in front of the MFMA that reads it, which is the phase structure this kernel exists to avoid.  Volatile asm statements keep
+// their order, so the unit stays between the ds_read / wait statements of its slot.  Int8 is written out as asm: the two registers' chains
+// (v_perm byte -> 0x6400|q, v_pk_add -1024, v_pk_fma a q + b: the instructions hipcc emits for dq8) interleaved, which also removes the wait
+// state the packed ops need between a write and its dependent read (hipcc pads each chain with s_nop when it schedules them one after the other).
+template <int FMT> struct T4Dq { static constexpr int UNITS = 2; };
+__device__ __forceinline__ u32 t4_pin(u32 v) { asm volatile("" : "+v"(v)); return v; }
+template <int FMT, int KS, int U>
+__device__ __forceinline__ void t4_unit(u32x4 &dst, const T3Set<FMT, 2> &w, const T4Scale<FMT> &sc, const Nf4Lut &lut, int h) {
+    if constexpr (FMT == W_F16) {
+        dst[U * 2] = t4_pin(w.q[h][KS][U * 2]);
+        dst[U * 2 + 1] = t4_pin(w.q[h][KS][U * 2 + 1]);
+    } else if constexpr (FMT == W_INT8) {
+        const u32x4 q = w.q[h][KS >> 1];
+        const u32 d = U == 0 ? ((KS & 1) ? q.z : q.x) : ((KS & 1) ? q.w : q.y);
+        u32 r0, r1;
+        asm volatile("v_perm_b32 %0, %3, %2, %4\n\t"
+                     "v_perm_b32 %1, %3, %2, %5\n\t"
+                     "v_pk_add_f16 %0, %0, %6 op_sel_hi:[1,0]\n\t"
+                     "v_pk_add_f16 %1, %1, %6 op_sel_hi:[1,0]\n\t"
+                     "v_pk_fma_f16 %0, %0, %7, %8\n\t"
+                     "v_pk_fma_f16 %1, %1, %7, %8\n\t"
+                     "s_nop 0"
+                     : "=&v"(r0), "=&v"(r1)
+                     : "v"(d), "s"(0x64646464u), "v"(0x04010400u), "v"(0x04030402u), "s"(0xE400u), "v"(sc.v[h][0]), "v"(sc.v[h][1]));
+        dst[U * 2] = r0;
+        dst[U * 2 + 1] = r1;
+    } else {
+        const u32x4 q = w.q[h][0];
+        const u32 d = KS == 0 ? q.x : KS == 1 ? q.y : KS == 2 ? q.z : q.w;
+        const f16x2 am2 = as_h2(sc.v[h][(KS >> 1) & 1]);
+        u32 a, b;
+        nf4_lookup4((U ? (d >> 4) : d) & 0x0F0F0F0Fu, lut, a, b);
+        dst[U * 2] = t4_pin(as_u32(as_h2(a) * am2));
+        dst[U * 2 + 1] = t4_pin(as_u32(as_h2(b) * am2));
+    }
+}
+// VMEM item E (0 .. NA-1) of a weight group load: per strip NQ tile loads, then (quantised) the scale word
+template <int FMT, int E>
+__device__ __forceinline__ void t4_wload_item(T3Set<FMT, 2> &w, const T3Off<2> &o, const void *wg, const void *sg) {
+    constexpr int NQ = T3Set<FMT, 2>::NQ, PER = NQ + (FMT == W_F16 ? 0 : 1), h = E / PER, r = E % PER;
+    if constexpr (r < NQ) t3_ld16<r * 1024>(w.q[h][r], o.w[h], wg);
+    else t3_ld8(w.s[h], o.s[h], sg);
+}
+
+template <int FMT, int NTL, bool HILO>
+__device__ __forceinline__ void tg4_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
+    constexpr int SPW = 2, WAVES = 4, STRIPS = WAVES * SPW, BT = NTL * 16;
+    constexpr int HB = HILO ? 2 : 1, NBT = NTL * HB;              // B fragments per k-step: [hi | lo][token tile]
+    constexpr int M = SPW * NBT;                                  // MFMAs per k-step per wave
+    constexpr int STAGE_TILES = NBT * 2, STAGE_BYTES = STAGE_TILES * 1024, DPW = STAGE_TILES / WAVES;
+    constexpr int NA = T3Set<FMT, SPW>::NLOAD, UNITS = T4Dq<FMT>::UNITS, UT = SPW * UNITS;
+    static_assert(!HILO || NTL == 4, "hi + lo operands: 128 x 64 tiles only");
+    static_assert(M % UT == 0 || UT % M == 0, "dequantisation units spread evenly over the MFMA slots");
+    using Set = T3Set<FMT, SPW>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nstrips = P.rows >> 4;
+    const int ntt = (L.T + BT - 1) / BT;
+    int lb = (int)blockIdx.x - P.block_begin;
+    const int nb = ((nstrips + STRIPS - 1) / STRIPS) * ntt;       // tiles of one K copy (P.ksb > 1: linear epilogues, as in tg3_body)
+    const int kb = lb / nb;
+    lb -= kb * nb;
+    if (L.xcd_map) {                                              // XCD-banded tile numbering, as in tg_body
+        const int k = lb & 7, j = lb >> 3;
+        int start = 0;
+        for (int m = 0; m < k; ++m) start += (nb - m + 7) >> 3;
+        lb = start + j;
+    }
+    const int rb = lb / ntt, tt = lb - rb * ntt;
+    const int strip = rb * STRIPS + wave * SPW;
+    const int t0 = tt * BT;
+    const int G = P.K >> 7, g0 = (int)((long)kb * G / P.ksb), g1 = (int)((long)(kb + 1) * G / P.ksb);
+    const int kofs = g0 * 128;                                    // first k of this copy
+    const int nsc = g1 - g0, nst = nsc * 2;                       // weight groups (128 k) and stages (64 k) of this copy
+    const unsigned xs_byte = (unsigned)(uintptr_t)smem;
+    const int last_tile = (L.T - 1) >> 4;
+    Nf4Lut lut;
+    if constexpr (FMT == W_NF4) lut = make_nf4_lut();
+
+    f32x4 acc[SPW][NTL];
+#pragma unroll
+    for (int h = 0; h < SPW; ++h)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) acc[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // The DPW tiles of a stage this wave fetches: stage tile i = m * WAVES + wave = fragment b = i >> 1 (= part * NTL + token tile) of k-step
+    // i & 1, landing at byte i * 1024 of the stage.  b >> log2(NTL) (hi / lo) depends on m only: (m * 2 + (wave >> 1)) / NTL with wave >> 1 < 2.
+    unsigned xoff[DPW];
+#pragma unroll
+    for (int m = 0; m < DPW; ++m) {
+        const int i = m * WAVES + wave, nt = (i >> 1) % NTL;
+        const int ttile = min((t0 >> 4) + nt, last_tile);
+        xoff[m] = (unsigned)(((ttile * (P.ldx >> 5) + (i & 1)) * 512 + lane * 8) * 2);
+    }
+    const char *const xbase_hi = (const char *)(P.xhi + (long)(kofs >> 5) * 512);
+    const char *const xbase_lo = HILO ? (const char *)(P.xlo + (long)(kofs >> 5) * 512) : xbase_hi;
+    auto dma_item = [&](int s, auto mc) {                            // DMA m of stage s (64 k = two k-steps of 1 KiB tiles per token tile)
+        constexpr int m = decltype(mc)::value;
+        constexpr bool lo = HILO && (m * 2) / NTL == 1;
+        const unsigned dst = xs_byte + (unsigned)((s & (T3_NB - 1)) * STAGE_BYTES + (m * WAVES + wave) * 1024);
+        t3_dma16(xoff[m], (lo ? xbase_lo : xbase_hi) + (long)s * 2048, dst);
+    };
+    T3Off<SPW> woff;
+    {
+        constexpr int SH = Fmt<FMT>::SH;
+        const int KT = P.K >> SH, KG = P.K >> 8;
+#pragma unroll
+        for (int h = 0; h < SPW; ++h) {
+            const int sidx = min(strip + h, nstrips - 1);
+            woff.w[h] = (unsigned)(sidx * KT * 64 + lane) * 16u;
+            woff.s[h] = (unsigned)(sidx * KG * 16 + (lane & 15)) * 8u;
+        }
+    }
+    const char *const wbase = (const char *)P.W + (long)(kofs >> Fmt<FMT>::SH) * 1024, *const sbase = (const char *)P.S;
+    auto wptr = [&](int g) { return wbase + (long)g * (128 >> Fmt<FMT>::SH) * 1024; };               // weight tiles of local group g
+    auto sptr = [&](int g) { return sbase + (long)(((kofs >> 7) + g) >> 1) * 128; };                     // its 256-k scale words
+    const unsigned rd0 = xs_byte + (unsigned)(lane * 16);            // fragment read address inside a stage
+
+    // ---- one k-step: MFMAs on (Ac, Bc), preparation of (An, Bn) for the next one.  KSN = k-step of the NEXT inside its weight group `wn`,
+    // QN = its k-step inside its stage (slot address rdn); VK = VMEM work of this k-step: 0 none, 1 DMA(sd), 2 weight group gw -> wl, then DMA(sd).
+    auto kstep = [&](const u32x4 (&Ac)[SPW], u32x4 (&An)[SPW], f16x8 (&Bc)[NBT], f16x8 (&Bn)[NBT], const Set &wn, const T4Scale<FMT> &sc, unsigned rdn,
+                     auto ksn_c, auto qn_c, auto vk_c, Set &wl, int gw, int sd) {
+        constexpr int KSN = decltype(ksn_c)::value, QN = decltype(qn_c)::value, VK = decltype(vk_c)::value;
+        constexpr int NITEM = VK == 0 ? 0 : (VK == 1 ? DPW : NA + DPW), VSLOTS = M - NBT;
+        const bool have_w = VK == 2 && gw < nsc, have_d = VK != 0 && sd < nst;
+        const void *wg = nullptr, *sg = nullptr;
+        if constexpr (VK == 2) { wg = wptr(gw); sg = sptr(gw); }
+        t4_for<M>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, b = i / SPW, h = i % SPW;
+            if constexpr (h == 0) t3_lgkm_wait<(NBT - 1 - b) + (i < NBT ? i : NBT)>(Bc[b]);
+            acc[h][b % NTL] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ac[h]), Bc[b], acc[h][b % NTL], 0, 0, 0);
+            if constexpr (i < NBT) t3_lds16<(i * 2 + QN) * 1024>(Bn[i], rdn);
+            if constexpr (UT >= M) {
+                t4_for<UT / M>([&](auto jc) { constexpr int j = i * (UT / M) + decltype(jc)::value; t4_unit<FMT, KSN, j % UNITS>(An[j / UNITS], wn, sc, lut, j / UNITS); });
+            } else if constexpr (i % (M / UT) == 0) {
+                constexpr int j = i / (M / UT);
+                t4_unit<FMT, KSN, j % UNITS>(An[j / UNITS], wn, sc, lut, j / UNITS);
+            }
+            if constexpr (NITEM > 0 && i >= NBT) {                   // VMEM items e in [lo, hi) of this slot, behind the reads
+                constexpr int sl = i - NBT, lo = sl * NITEM / VSLOTS, hi = (sl + 1) * NITEM / VSLOTS;
+                t4_for<hi - lo>([&](auto ec) {
+                    constexpr int e = lo + decltype(ec)::value;
+                    if constexpr (VK == 2 && e < NA) { if (have_w) t4_wload_item<FMT, e>(wl, woff, wg, sg); }
+                    else { if (have_d) dma_item(sd, std::integral_constant<int, e - (VK == 2 ? NA : 0)>{}); }
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    // the barrier in the middle of stage s: stage s + 1 complete in LDS for every wave, this wave's reads of stage s retired
+    auto publish = [&](int s) {
+        if (s + 4 < nst) t3_wait_barrier<2 * DPW + NA>(); else t3_wait_barrier<0>();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    u32x4 A0[SPW], A1[SPW];
+    f16x8 B0[NBT], B1[NBT];
+    T4Scale<FMT> sc_cur, sc_nxt;
+    auto slot_rd = [&](int s) { return rd0 + (unsigned)((s & (T3_NB - 1)) * STAGE_BYTES); };
+    // ---- one weight group = four k-steps = stages 2g, 2g + 1.  `cur` holds group g (its scales in sc_cur), `nxt` group g + 1; `cur` is
+    // refilled with group g + 3 during the last k-step (its last dequantisation ran during the third).
+    auto group = [&](Set &cur, Set &nxt, int g) {
+        const int s = 2 * g;
+        kstep(A0, A1, B0, B1, cur, sc_cur, slot_rd(s), I1{}, I1{}, I0{}, cur, 0, 0);                   // k-step 4g:     next = k-step 1 of stage s
+        publish(s);
+        kstep(A1, A0, B1, B0, cur, sc_cur, slot_rd(s + 1), I2{}, I0{}, I1{}, cur, 0, s + 4);          // k-step 4g + 1: next = k-step 0 of stage s + 1; DMA(s + 4)
+        kstep(A0, A1, B0, B1, cur, sc_cur, slot_rd(s + 1), I3{}, I1{}, I0{}, cur, 0, 0);               // k-step 4g + 2
+        publish(s + 1);
+        t3_arrived<FMT, SPW>(nxt);                                                                      // group g + 1 landed (retired by the wait above)
+        t4_scales<FMT>(sc_nxt, nxt, (kofs >> 7) + g + 1);
+        kstep(A1, A0, B1, B0, nxt, sc_nxt, slot_rd(s + 2), I0{}, I0{}, I2{}, cur, g + 3, s + 5);      // k-step 4g + 3: next = first of group g + 1; W(g + 3), DMA(s + 5)
+        sc_cur = sc_nxt;
+    };
+
+    Set a0, a1, a2;
+    t3_load<FMT, SPW>(a0, woff, wptr(0), sptr(0));
+    const int g_second = min(1, nsc - 1);                                      // (s_min: a `nsc > 1 ? 1 : 0` select inside the 64-bit address goes to the VALU)
+    t3_load<FMT, SPW>(a1, woff, wptr(g_second), sptr(g_second));
+    t4_for<DPW>([&](auto mc) { dma_item(0, mc); });
+    if (nst > 1) t4_for<DPW>([&](auto mc) { dma_item(1, mc); });
+    if (nst > 2) t4_for<DPW>([&](auto mc) { dma_item(2, mc); });
+    if (nst > 2) t3_wait_barrier<2 * DPW>(); else t3_wait_barrier<0>();      // W(0), W(1) and DMA(0) have landed
+    t3_arrived<FMT, SPW>(a0);
+    t3_arrived<FMT, SPW>(a1);
+    a2 = a0;                                                                  // every register defined; refilled with group 2 below
+    t4_scales<FMT>(sc_cur, a0, kofs >> 7);
+    // "k-step -1": fragments of k-step 0, W(2), DMA(3)
+    t4_for<NBT>([&](auto bc) { t3_lds16<decltype(bc)::value * 2 * 1024>(B0[decltype(bc)::value], slot_rd(0)); });
+    t4_for<UT>([&](auto jc) { constexpr int j = decltype(jc)::value; t4_unit<FMT, 0, j % UNITS>(A0[j / UNITS], a0, sc_cur, lut, j / UNITS); });
+    if (2 < nsc) t3_load<FMT, SPW>(a2, woff, wptr(2), sptr(2));
+    if (3 < nst) t4_for<DPW>([&](auto mc) { dma_item(3, mc); });
+    __builtin_amdgcn_sched_barrier(0);
+    for (int g = 0; g < nsc; g += 3) {
+        group(a0, a1, g);
+        if (g + 1 < nsc) group(a1, a2, g + 1);
+        if (g + 2 < nsc) group(a2, a0, g + 2);
+    }
+    if (P.ksb > 1) {                                              // partial slab kb (host: out_f32 only, linear epilogue)
+        GemmProb Q = P;
+        Q.out_f32 = P.out_f32 + (long)kb * P.partial_stride;
+        tg_epilogue<SPW, NTL>(L, Q, acc, strip, nstrips, t0, lane);
+    } else {
+        tg_epilogue<SPW, NTL>(L, P, acc, strip, nstrips, t0, lane);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tile4_kernel(const GemmLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int pi = 0;
+    for (int i = 1; i < L.nprob; ++i)
+        if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
+    const GemmProb &P = L.p[pi];
+    if (P.fmt == W_F16) tg4_body<W_F16, 4, true>(L, P, smem);
+    else if (P.fmt == W_INT8) tg4_body<W_INT8, 4, true>(L, P, smem);
+    else tg4_body<W_NF4, 4, true>(L, P, smem);
+}
+bool gemm_tile4_supported(bool hilo, int K) { return hilo && K % 128 == 0; }
+
 // tile shapes, largest first: {waves, strips per wave, n-tiles, k per chunk}
 static const int kTileShapes[GEMM_TILE_SHAPES][5] = {{8, 2, 8, 128, 0}, {8, 1, 8, 128, 0}, {4, 1, 8, 128, 0}, {4, 1, 4, 128, 0}, {4, 1, 4, 256, 0}, {8, 1, 8, 256, 0},
-                                                     {4, 1, 4, 256, 1}, {4, 2, 4, 128, 1}, {4, 2, 8, 128, 1}, {8, 2, 8, 128, 1}, {4, 2, 8, 128, 2}, {4, 2, 4, 128, 2}};
+                                                     {4, 1, 4, 256, 1}, {4, 2, 4, 128, 1}, {4, 2, 8, 128, 1}, {8, 2, 8, 128, 1}, {4, 2, 8, 128, 2}, {4, 2, 4, 128, 2},
+                                                     {4, 2, 4, 128, 3}};
 // (128 rows x 64 tokens with 8 waves, 256-k and 128-k chunks — half the operand re-reads of the 64x64 shapes on steps of a few hundred
 // rows — was built and measured in round 3: slower on every matrix but one, profiles/r3_exp_tile_128x64.log; removed.)
 int gemm_tile_blocks(int shape, int rows, int T) {
@@ -1937,6 +2207,17 @@ int gemm_tile_blocks(int shape, int rows, int T) {
 }
 
 void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s) {
+    if (kTileShapes[shape][4] == 3) {                          // software-pipelined hi + lo kernel (caller checked gemm_tile4_supported)
+        static bool attr4[16] = {false};
+        int dev4 = 0;
+        (void)hipGetDevice(&dev4);
+        if (!attr4[dev4 & 15]) {
+            (void)hipFuncSetAttribute((const void *)gemm_tile4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr4[dev4 & 15] = true;
+        }
+        hipLaunchKernelGGL(gemm_tile4_kernel, dim3(L.total_blocks), dim3(256), (size_t)T3_NB * 4 * 2 * 2 * 1024, s, L);
+        return;
+    }
     if (kTileShapes[shape][4] == 2) {                          // pipelined kernel (caller checked gemm_tile3_supported)
         static bool attr3[16] = {false};
         int dev3 = 0;
@@ -2613,7 +2894,10 @@ __global__ __launch_bounds__(256, CH == 8 ? 5 : (VER == 7 ? 2 : 3)) void wkv_chu
     TRACE_K(3, 7);
 }
 void launch_wkv(const WkvArgs &a, bool multi_row, hipStream_t s) {
-    if (multi_row && a.max_rows > 0 && a.max_rows <= 8) {                  // every sequence of the step has <= 8 rows: the five-blocks-per-CU form
+    // every sequence of the step has <= 8 rows: the five-blocks-per-CU form.  V6's decay LoRA is compiled for Dd = 64 and 128 only (the KS of
+    // its MFMA stage): any other Dd the loader accepts (multiples of 4 up to 128) falls through to the generic per-token kernel below,
+    // like the long form does (a <6, 128, 8> instance would read D2 / td rows with the wrong extent).
+    if (multi_row && a.max_rows > 0 && a.max_rows <= 8 && (a.version != 6 || a.Dd == 64 || a.Dd == 128)) {
         if (a.version == 5) hipLaunchKernelGGL((wkv_chunk_kernel<5, 64, 8>), dim3(a.n_seq, a.H), dim3(256), 0, s, a);
         else if (a.version == 6 && a.Dd == 64) hipLaunchKernelGGL((wkv_chunk_kernel<6, 64, 8>), dim3(a.n_seq, a.H), dim3(256), 0, s, a);
         else if (a.version == 6) hipLaunchKernelGGL((wkv_chunk_kernel<6, 128, 8>), dim3(a.n_seq, a.H), dim3(256), 0, s, a);

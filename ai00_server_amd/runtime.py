@@ -159,9 +159,10 @@ class Quant(enum.IntEnum):       # `Quant` lib.rs:689-704 (SF4 unsupported)
     NF4 = 2
 
 
-class Precision(enum.IntEnum):   # reload.rs:89-94
-    Fp16 = 0
-    Fp32 = 1
+class Precision(enum.IntEnum):   # reload.rs:89-94 (+ the raw mode of ABI 7, include/rwkv_abi.h)
+    Fp16 = 0                     # f16 operands, the error-carrying launches hi + lo: within 1e-3 at 32 layers (the default)
+    Fp32 = 1                     # hi + lo operands everywhere (fp32-class)
+    Fp16Raw = 2                  # f16 operands everywhere: fastest, not tolerance-holding at depth
 
 
 class RnnOption(enum.IntEnum):   # run.rs:716, 819

@@ -24,12 +24,14 @@
 extern "C" {
 #endif
 
-#define RWKV_ABI_VERSION 6   /* 2: rwkv_sample_params gained kind/tau; rwkv_engine_save_prefab
+#define RWKV_ABI_VERSION 7   /* 2: rwkv_sample_params gained kind/tau; rwkv_engine_save_prefab
                               * 3: rwkv_sample_params gained allow (formatter mask); rwkv_host_alloc/free; RWKV_OPTION_NONE
                               * 4: rwkv_engine_token_chunk_size
                               * 5: rwkv_state_back_layer_async / rwkv_state_sync
                               * 6: no new symbol — rwkv_infer no longer waits for a step that emits no row; rwkv_state_back_layer_async checks
-                              *    that the rows end inside the pinned block that holds `dst` */
+                              *    that the rows end inside the pinned block that holds `dst`
+                              * 7: rwkv_load_desc.precision: RWKV_PRECISION_FP16 now holds 1e-3 at depth (the launches that carry a model's f16 operand
+                              *    rounding read hi + lo operands); the old all-f16 behaviour is RWKV_PRECISION_FP16_RAW */
 
 typedef int32_t rwkv_status;
 enum {
@@ -70,7 +72,14 @@ rwkv_status rwkv_model_info_from_st(const uint8_t *st_bytes, size_t st_len, rwkv
 
 /* ---- `create_context` lib.rs:351-368 + `load_runtime` lib.rs:391-516 ---------------------- */
 enum { RWKV_QUANT_NONE = 0, RWKV_QUANT_INT8 = 1, RWKV_QUANT_NF4 = 2 };   /* `Quant` lib.rs:689-704 */
-enum { RWKV_PRECISION_FP16 = 0, RWKV_PRECISION_FP32 = 1 };               /* reload.rs:89-94       */
+/* `Precision` reload.rs:89-94, passed by `load_runtime` lib.rs:503-515.  GEMM operands are f16 with fp32 accumulation in every mode:
+ *   FP16 (the reference's default, and this library's): f16 operands, except that the launches whose input rounding carries a model's
+ *        error at depth read the operand as a hi + lo f16 pair (V5 / V6: the time-mix projections and first-stage LoRAs; V7: those, the
+ *        second-stage LoRAs and the output projection) — logits, state and embeddings within 1e-3 of an fp32 evaluation at 32 layers;
+ *   FP32: every launch reads hi + lo operands (fp32-class: <= 2e-5);
+ *   FP16_RAW: f16 operands everywhere — the fastest mode; relative error ~1e-3 of the row's magnitude, NOT within 1e-3 absolute at 32 layers
+ *        (V7-2.9B NF4 measures 4.7e-3).  For callers that accept that. */
+enum { RWKV_PRECISION_FP16 = 0, RWKV_PRECISION_FP32 = 1, RWKV_PRECISION_FP16_RAW = 2 };
 enum { RWKV_ADAPTER_AUTO = -1, RWKV_ADAPTER_ECONOMICAL = -2 };           /* reload.rs AdapterOption; >=0 = Manual(n) */
 
 typedef struct rwkv_lora_desc {    /* `reload::Lora{path, alpha}` + LoraBlend::full(alpha), lib.rs:466-482 */

@@ -25,7 +25,8 @@ inline void check(rwkv_status s) { if (s != RWKV_OK) throw Error(s); }
 
 enum class RnnOption : int32_t { Last = RWKV_OPTION_LAST, Full = RWKV_OPTION_FULL, None = RWKV_OPTION_NONE };
 enum class Quant : int32_t { None = RWKV_QUANT_NONE, Int8 = RWKV_QUANT_INT8, NF4 = RWKV_QUANT_NF4 };
-enum class Precision : int32_t { Fp16 = RWKV_PRECISION_FP16, Fp32 = RWKV_PRECISION_FP32 };
+// reload.rs:89-94; Fp16Raw is this library's extension (ABI 7): f16 operands on EVERY launch — the fastest mode, outside 1e-3 at 32 layers
+enum class Precision : int32_t { Fp16 = RWKV_PRECISION_FP16, Fp32 = RWKV_PRECISION_FP32, Fp16Raw = RWKV_PRECISION_FP16_RAW };
 using ModelInfo = rwkv_model_info;
 
 struct Loader {

@@ -1,9 +1,9 @@
-//! Raw bindings of `include/rwkv_abi.h` (ABI version 6), one `pub fn` per export, in the header's order.
+//! Raw bindings of `include/rwkv_abi.h` (ABI version 7), one `pub fn` per export, in the header's order.
 //! tests/test_abi_cpu.py diffs this file against the header (names and argument counts) and against the built library.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_float, c_void};
 
-pub const RWKV_ABI_VERSION: i32 = 6;
+pub const RWKV_ABI_VERSION: i32 = 7;
 
 pub type rwkv_status = i32;
 pub const RWKV_OK: rwkv_status = 0;
@@ -19,6 +19,7 @@ pub const RWKV_QUANT_INT8: i32 = 1;
 pub const RWKV_QUANT_NF4: i32 = 2;
 pub const RWKV_PRECISION_FP16: i32 = 0;
 pub const RWKV_PRECISION_FP32: i32 = 1;
+pub const RWKV_PRECISION_FP16_RAW: i32 = 2;
 pub const RWKV_ADAPTER_AUTO: i32 = -1;
 pub const RWKV_ADAPTER_ECONOMICAL: i32 = -2;
 pub const RWKV_OPTION_LAST: i32 = 0;

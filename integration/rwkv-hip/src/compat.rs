@@ -122,6 +122,9 @@ impl<'a> ModelBuilder<'a> {
     }
     /// `LoraBlend::full(alpha)` (lib.rs:466-482)
     pub fn lora(mut self, data: &'a [u8], alpha: f32) -> Self { self.lora.push((data, alpha)); self }
+    /// `fp32` = `matches!(precision, Precision::Fp32)` (lib.rs:503-515).  `false` is the reference's default `Precision::Fp16`, which in this
+    /// backend is the tolerance-holding fp16 mode (RWKV_PRECISION_FP16, ABI 7): nothing for ai00-core to select — the all-f16 raw mode is only
+    /// reachable through `rwkv_hip::LoadDesc { precision: Precision::Fp16Raw, .. }`.
     pub fn build(self, max_batch: usize, token_chunk_size: usize, fp32: bool) -> Result<(Runtime, State, Context, ModelInfo), Error> {
         let engine = Arc::new(Engine::load(&LoadDesc { adapter: self.adapter, quant_layers: self.quant.0, quant_type: self.quant.1,
             precision: if fp32 { Precision::Fp32 } else { Precision::Fp16 }, max_batch, token_chunk_size, model: self.model, lora: self.lora })?);

@@ -40,7 +40,9 @@ pub fn model_info(bytes: &[u8]) -> Result<RawInfo> {
 }
 
 #[derive(Clone, Copy, Debug, PartialEq, Eq)] pub enum QuantType { None = 0, Int8 = 1, NF4 = 2 }
-#[derive(Clone, Copy, Debug, PartialEq, Eq)] pub enum Precision { Fp16 = 0, Fp32 = 1 }
+/// `reload::Precision` (reload.rs:89-94).  `Fp16` holds 1e-3 on logits / state at 32 layers since ABI 7 (the launches that carry a model's
+/// f16 operand rounding read hi + lo operands); `Fp16Raw` is the library's all-f16 extension (fastest, not tolerance-holding at depth).
+#[derive(Clone, Copy, Debug, PartialEq, Eq)] pub enum Precision { Fp16 = 0, Fp32 = 1, Fp16Raw = 2 }
 #[derive(Clone, Copy, Debug, PartialEq, Eq)] pub enum Adapter { Auto, Economical, Manual(usize) }
 #[derive(Clone, Copy, Debug, PartialEq, Eq, Default)] pub enum OutputOption { #[default] Last = 0, Full = 1, None = 2 }
 

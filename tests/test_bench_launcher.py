@@ -147,10 +147,11 @@ def test_real_bench_as_two_ranks_on_one_device():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The line the driver parses (profiles/r5_bench_default.json is the last one measured on the GPU box): every key of the bench
+    """The line the driver parses (profiles/r6_bench_default.json is the last one measured on the GPU box): every key of the bench
     contract, the roofline and cpu_baseline objects with their fields, value = tokens of all ranks / the slowest rank's time."""
     import json
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r5_bench_default.json")).readline())
+    path = os.path.join(ROOT, "profiles", "r6_bench_default.json")
+    line = json.loads(open(path).readline())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in line, k
     assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None and line["data"] == "synthetic"
@@ -170,11 +171,15 @@ def test_committed_bench_line_keeps_the_contract():
     e = line["embeddings"]                                  # 512 documents x 256 tokens per rank at token_chunk_size 256
     assert e["unit"] == "embeddings/s" and e["docs_per_rank"] == 512 and e["doc_tokens"] == 256 and e["token_chunk_size"] == 256
     assert len(e["per_rank_embeddings_per_s"]) == line["n_gpus"] and len(line["pcie_inclusive"]["per_rank"]) == line["n_gpus"]
-    # round 5: the modes that hold north_star's 1e-3 are on the line too, each verified like the headline
-    f = line["precision_fp32"]
-    assert f["tokens_verified"] is True and f["embeddings"]["embeddings_verified"] is True and set(f["decode"]) == {"32", "8", "1"}
-    assert f["fp16_promoted"]["tokens_verified"] is True and f["fp16_promoted"]["RWKV_PROMOTE"] == 1
-    assert line["configs"]["config4_v7-2.9b_nf4"]["fp16_promoted"]["RWKV_PROMOTE"] == 7
+    # round 6: the headline runs in the library's default precision (ABI 7: holds 1e-3 at depth); Precision::Fp32 and the all-f16 opt-in are on the
+    # line too, each verified like the headline; the timed region is repeated and the line carries the median region
+    assert "Precision::Fp16" in line["config"]["precision"]
+    for mode in ("fp32", "fp16raw"):
+        f = line["other_precisions"][mode]
+        assert f["tokens_verified"] is True and f["embeddings"]["embeddings_verified"] is True and set(f["decode"]) == {"32", "8", "1"}
+    assert line["configs"]["config4_v7-2.9b_nf4"]["fp16_raw"]["tokens_verified"] is True
+    tr = line["timed_regions"]
+    assert tr["n"] >= 5 and tr["min"] <= tr["median"] <= tr["max"] and abs(tr["median"] - line["ms_per_step"]) < 1e-9
     assert len(line["per_rank_numa"]) == line["n_gpus"]
 
 

@@ -17,8 +17,10 @@ Reference: `oracle.cpu_backend.CpuBackend` — the compiled restatement, pinned 
 32-layer step is 0.25 s on the GPU box's 16 cores).  Every comparison prints the measured max-abs AND relative error (run with -s),
 and appends them to gpurun_out/full_depth_errors.jsonl when that directory exists, so DESIGN.md quotes measured numbers.
 
-Bounds (DESIGN.md 1): Precision::Fp16 — logits and state max-abs <= 1e-3 * max(1, |ref|_inf) (f16 GEMM operands: the error is
-relative to the operand's magnitude); Precision::Fp32 — absolute 1e-3 on the embedding slice and the state, 2e-5 relative on logits."""
+Bounds (DESIGN.md 1).  `Precision::Fp16` — the engine's DEFAULT mode and the one bench.py quotes (ABI 7: f16 operands, the launches that carry
+a model's operand-rounding error read hi + lo) — logits and state max-abs <= 1e-3 * max(1, |ref|_inf) at scale 1.0 for every model;
+`Precision::Fp32` — absolute 1e-3 on logits, embedding slice and state; `Precision::Fp16Raw` (f16 operands on every launch, an explicitly
+named opt-in) — the same relative bound for V6, 3e-3 for V7-2.9B NF4 (measured 1.9e-3: the reason the raw mode is not the default)."""
 import json
 import os
 
@@ -46,6 +48,13 @@ def report(what, got, want, bound):
     return err
 
 
+def log_record(rec):
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "full_depth_errors.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+
+
 def rel_bound(want):
     return FP16_TOL * max(1.0, float(np.abs(want).max()))
 
@@ -58,20 +67,8 @@ class Model:
         self.qt = qt
         self.cpu = CpuBackend(self.tens, self.info.num_layer, qt)
 
-    def engine(self, B, chunk, prec=rt.Precision.Fp16, promote=0):
-        """`promote`: RWKV_PROMOTE for this engine (operand classes that read hi + lo f16 operands in Precision::Fp16; the switches are
-        frozen per engine at creation, so the variable is dropped again at once)."""
-        old = os.environ.get("RWKV_PROMOTE")
-        if promote:
-            os.environ["RWKV_PROMOTE"] = str(promote)
-        try:
-            return rt.ModelBuilder(self.st).quant(self.info.num_layer, rt.Quant(self.qt)).build(max_batch=B, token_chunk_size=chunk, precision=prec)
-        finally:
-            if promote:
-                if old is None:
-                    os.environ.pop("RWKV_PROMOTE", None)
-                else:
-                    os.environ["RWKV_PROMOTE"] = old
+    def engine(self, B, chunk, prec=rt.Precision.Fp16):
+        return rt.ModelBuilder(self.st).quant(self.info.num_layer, rt.Quant(self.qt)).build(max_batch=B, token_chunk_size=chunk, precision=prec)
 
     def cpu_prefill(self, prompts, states, want_logits=True):
         """Ragged prompts through the lock-step CPU step: at step s the slots that still have a token advance together.
@@ -112,11 +109,11 @@ def feed(eng, prompts, option=rt.RnnOption.Last):
     return rows
 
 
-def decode_case(m, tag, n_steps=12, B=32, prec=rt.Precision.Fp16, tol_scale=1.0, promote=0, abs_bound=None):
-    """`tol_scale` widens the Precision::Fp16 bound where the measured f16-operand noise of a 32-layer model needs it (stated per case);
+def decode_case(m, tag, n_steps=12, B=32, prec=rt.Precision.Fp16, tol_scale=1.0, abs_bound=None):
+    """`tol_scale` is 1.0 in the default mode and in Fp32; only the explicitly named raw-f16 case of V7 states a wider bound.
     Precision::Fp32 is held to north_star's absolute 1e-3 whatever the magnitude."""
     V = m.info.num_vocab
-    eng = m.engine(B, 256, prec, promote)
+    eng = m.engine(B, 256, prec)
 
     def rel_bound(want):                      # shadows the module-level rule for this case
         if abs_bound is not None:
@@ -164,6 +161,8 @@ def decode_case(m, tag, n_steps=12, B=32, prec=rt.Precision.Fp16, tol_scale=1.0,
     print(f"[full-depth] {tag} decode: worst logits error over {n_steps} steps = {worst:.3f} of the bound; smallest top-2 gap of the reference "
           f"{min_margin:.3e}; arg-max flips on near-ties: {[(s, b, f'gap {g:.1e} <= 2 x err {e:.1e}') for s, b, g, e in flips]}")
     assert len(flips) <= max(1, B * n_steps // 100), "too many near-tie flips to call the arg-max stable"
+    log_record({"case": f"{tag} arg-max", "pairs": B * n_steps, "near_tie_flips": len(flips), "smallest_reference_top2_gap": min_margin,
+                "flips": [{"step": s_, "slot": b_, "reference_gap": g_, "row_error": e_} for s_, b_, g_, e_ in flips]})
     back = np.stack([eng.state.back(b) for b in range(B)])
     assert report(f"{tag} state after prefill + {n_steps} decode steps", back, states, rel_bound(states)) <= rel_bound(states)
     # ---- rwkv_decode_greedy (the bench's timed call): ids stay on the device.  A slot is compared until its first near-tie flip (same
@@ -181,50 +180,48 @@ def decode_case(m, tag, n_steps=12, B=32, prec=rt.Precision.Fp16, tol_scale=1.0,
                 alive.discard(b)
                 left.append((s, b, gap))
     print(f"[full-depth] {tag} rwkv_decode_greedy: {len(alive)}/{B} slots identical over {n_steps} steps; left on a near-tie: {left}")
+    log_record({"case": f"{tag} rwkv_decode_greedy ids", "slots_identical": len(alive), "slots": B, "steps": n_steps,
+                "left_on_near_tie": [{"step": s_, "slot": b_, "reference_gap": g_} for s_, b_, g_ in left]})
     assert len(alive) >= B - max(1, B // 10)
     eng.close()
 
 
-@pytest.mark.parametrize("prec", [rt.Precision.Fp16, rt.Precision.Fp32], ids=["Fp16", "Fp32"])
+MODES = [rt.Precision.Fp16, rt.Precision.Fp32]
+
+
+@pytest.mark.parametrize("prec", MODES, ids=[p.name for p in MODES])
 def test_config3_v6_3b_int8_32_layers_32_slots(v6_int8, prec):
-    """BASELINE config #3 as quoted: 32 Int8 layers x 32 slots (lib.rs:465, reload.rs:89-94), in both `Precision`s (reload.rs:89-94)."""
+    """BASELINE config #3 as quoted: 32 Int8 layers x 32 slots (lib.rs:465), in both of the reference's `Precision`s (reload.rs:89-94,
+    lib.rs:503-515).  Fp16 is the engine's default and the bench headline's mode: bound at scale 1.0."""
     decode_case(v6_int8, f"v6-3b int8 x32 layers Precision::{prec.name}", prec=prec)
 
 
-@pytest.mark.parametrize("prec", [rt.Precision.Fp16, rt.Precision.Fp32], ids=["Fp16", "Fp32"])
+@pytest.mark.parametrize("prec", MODES, ids=[p.name for p in MODES])
 def test_config4_engine_v7_2p9b_nf4_32_layers_32_slots(v7_nf4, prec):
-    """Config #4's engine: V7-2.9B shapes, NF4 on all 32 layers, 32 slots.  Precision::Fp16 at this depth measures 2e-3 of |ref|inf on
-    the logits (f16 operand rounding through 32 layers of V7's two-stage LoRA chains and the kappa-normalised state update; the
-    two-layer tests sit at 4e-4), so its bound here is 3e-3 relative — stated, not hidden; Precision::Fp32 keeps the absolute 1e-3."""
-    decode_case(v7_nf4, f"v7-2.9b nf4 x32 layers Precision::{prec.name}", prec=prec, tol_scale=3.0)
+    """Config #4's engine: V7-2.9B shapes, NF4 on all 32 layers, 32 slots, in both `Precision`s at scale 1.0.  (Which operand class carries
+    V7's f16 error was measured on the CPU restatement with its per-class rounding switch — scripts/fp16_error_attribution.py,
+    profiles/r5_fp16_error_attribution_sim_v7-2.9b_nf4.jsonl: the r / k / v projections' inputs alone carry 4.7e-3 of 4.9e-3; with the
+    time-mix launch, the second-stage LoRAs and the output projection reading hi + lo operands 9.7e-4 absolute is left.  That set IS
+    Precision::Fp16 for V7 since ABI 7.)"""
+    decode_case(v7_nf4, f"v7-2.9b nf4 x32 layers Precision::{prec.name}", prec=prec)
 
 
-# Which operand class carries V7's Precision::Fp16 error was measured on the CPU restatement with its per-class rounding switch
-# (scripts/fp16_error_attribution.py -> profiles/r5_fp16_error_attribution_sim_v7-2.9b_nf4.jsonl; all classes rounded reproduces the
-# GPU's 4.7e-3 to 5 %): the r / k / v projections' inputs alone carry 4.7e-3 of the 4.9e-3, every other class 0.5e-3 .. 1.8e-3; with the
-# time-mix launch, the second-stage LoRAs and the output projection reading hi + lo operands (RWKV_PROMOTE = 1 + 2 + 4) the simulation
-# leaves 9.7e-4 ABSOLUTE on the logits and 6.8e-4 on the layer-31 embedding.
-V7_PROMOTE = 7
+def test_raw_f16_mode_v6_3b_int8_32_layers(v6_int8):
+    """RWKV_PRECISION_FP16_RAW (explicit opt-in, not the default): f16 operands on every launch.  V6-3B Int8 stays inside the relative bound
+    (measured 1.35e-3 absolute = 5.4e-4 of |ref|inf)."""
+    decode_case(v6_int8, "v6-3b int8 x32 layers raw f16 (Precision::Fp16Raw)", prec=rt.Precision.Fp16Raw)
 
 
-def test_config4_engine_v7_fp16_with_the_sensitive_launches_promoted(v7_nf4):
-    """Config #4's engine in Precision::Fp16 with RWKV_PROMOTE=7: SURVEY 8(c)'s bound at scale 1.0 — logits and state within
-    1e-3 * max(1, |ref|inf) at 32 layers (the un-promoted mode needs 3e-3, see above)."""
-    decode_case(v7_nf4, f"v7-2.9b nf4 x32 layers Precision::Fp16 RWKV_PROMOTE={V7_PROMOTE}", promote=V7_PROMOTE, tol_scale=1.0)
-
-
-def test_config3_v6_fp16_with_the_time_mix_launch_promoted(v6_int8):
-    """The headline engine in Precision::Fp16 with RWKV_PROMOTE=1 (the r / k / v / g / decay launch reads hi + lo operands; the CPU
-    simulation attributes 1.1e-3 of V6's 1.45e-3 to that class and leaves 8.3e-4 absolute without it,
-    profiles/r5_fp16_error_attribution_sim_v6-3b_int8.jsonl).  Held to the same bound as the plain mode; the measured absolute error is
-    printed and logged."""
-    decode_case(v6_int8, "v6-3b int8 x32 layers Precision::Fp16 RWKV_PROMOTE=1", promote=1, tol_scale=1.0)
+def test_raw_f16_mode_v7_2p9b_nf4_32_layers_states_its_wider_bound(v7_nf4):
+    """The raw mode on V7-2.9B NF4 measures 1.9e-3 of |ref|inf (4.7e-3 absolute) at 32 layers — outside north_star's 1e-3, which is why it is
+    NOT the default.  Its bound here is 3e-3 relative, stated for this named mode only."""
+    decode_case(v7_nf4, "v7-2.9b nf4 x32 layers raw f16 (Precision::Fp16Raw)", prec=rt.Precision.Fp16Raw, tol_scale=3.0)
 
 
 @pytest.mark.parametrize("which", ["v7_nf4", "v6_int8"])
 def test_embeddings_job_at_full_depth(which, request):
     """32 documents x 256 tokens, state-only (`RWKV_OPTION_NONE`), `token_chunk_size` 256 as SURVEY 8(d) names for config #4: the
-    layer-31 embedding slice and the whole slab against the CPU restatement, in both precisions."""
+    layer-31 embedding slice and the whole slab against the CPU restatement, in both precisions (+ V7's raw-f16 mode under its own name)."""
     m = request.getfixturevalue(which)
     V, L, B, T = m.info.num_vocab, m.info.num_layer, 32, 256
     docs = [[t % V for t in R.synth_prompt(1200 + b, T)] for b in range(B)]
@@ -232,9 +229,9 @@ def test_embeddings_job_at_full_depth(which, request):
     m.cpu_prefill(docs, states, want_logits=False)
     # public slab [L][N+2][C]: rows 1..N of a layer are its WKV matrix = the embedding of docs/doc-api/openai.md:376-437
     want_emb = states[:, L - 1, 1:-1, :]
-    for prec, name, promote in ((rt.Precision.Fp16, "Fp16", 0), (rt.Precision.Fp32, "Fp32", 0)) + \
-            (((rt.Precision.Fp16, f"Fp16 RWKV_PROMOTE={V7_PROMOTE}", V7_PROMOTE),) if m.info.version == 7 else ()):
-        eng = m.engine(B, 256, prec, promote)
+    for prec in (rt.Precision.Fp16, rt.Precision.Fp32) + ((rt.Precision.Fp16Raw,) if m.info.version == 7 else ()):
+        name = prec.name
+        eng = m.engine(B, 256, prec)
         feed(eng, docs, rt.RnnOption.NoOutput)
         emb = np.stack([eng.state.embed(L - 1, b).reshape(want_emb.shape[1:]) for b in range(B)])
         back = np.stack([eng.state.back(b) for b in range(B)])
@@ -243,7 +240,7 @@ def test_embeddings_job_at_full_depth(which, request):
             assert report(f"{which} embeddings (layer {L - 1}) Precision::{name}", emb, want_emb, ABS_TOL) <= ABS_TOL
             assert report(f"{which} state slab Precision::{name}", back, states, ABS_TOL) <= ABS_TOL
         else:
-            # Precision::Fp16 at depth 32: V6 Int8 measures 5e-4 of |ref|inf, V7 NF4 1.3e-3 (see the decode test above): 3e-3 for V7
-            k = 3.0 if m.info.version == 7 and not promote else 1.0
+            # scale 1.0 in the default mode; only V7's explicitly named raw mode (measured 1.3e-3 of |ref|inf on the embedding) states 3e-3
+            k = 3.0 if prec == rt.Precision.Fp16Raw else 1.0
             assert report(f"{which} embeddings (layer {L - 1}) Precision::{name}", emb, want_emb, k * rel_bound(want_emb)) <= k * rel_bound(want_emb)
             assert report(f"{which} state slab Precision::{name}", back, states, k * rel_bound(states)) <= k * rel_bound(states)

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 FP16_TOL = 1e-3
 
 SWITCHES = [("RWKV_NO_LN_FUSE", "1"), ("RWKV_NO_V6_FUSE", "1"), ("RWKV_NO_TILE", "1"), ("RWKV_NO_DENSE", "1"), ("RWKV_TILE_SHAPE", "10"),
-            ("RWKV_TILE_SHAPE", "11"), ("RWKV_TILE_KSPLIT", "0"), ("RWKV_PROMOTE", "63"), ("RWKV_PROMOTE", "3"), ("RWKV_PROMOTE", "20")]
+            ("RWKV_TILE_SHAPE", "11"), ("RWKV_TILE_KSPLIT", "0"), ("RWKV_PROMOTE", "63"), ("RWKV_PROMOTE", "3"), ("RWKV_PROMOTE", "20"), ("RWKV_PROMOTE", "0")]
 
 
 def tol(want):

@@ -983,3 +983,27 @@ def test_repeated_dense_steps_reuse_the_plan_and_survive_pattern_changes(name):
         assert np.abs(outs[b][-1] - want).max() <= tol(rt.Precision.Fp32, want)
         assert np.abs(eng.state.back(b) - states[b]).max() <= tol(rt.Precision.Fp32, states[b])
     eng.close()
+
+
+@pytest.mark.parametrize("Dd", [32, 96])
+@pytest.mark.parametrize("chunk", [12, 64], ids=["short-rows", "long-rows"])
+def test_v6_decay_lora_dims_other_than_64_and_128(Dd, chunk):
+    """The loader accepts any decay-LoRA dim Dd <= 128 with Dd % 4 == 0; the chunked WKV kernels are compiled for 64 and 128 only.  Steps whose
+    sequences have <= 8 rows each (chunk 12 over three slots) and longer ones (chunk 64) must both fall back to the generic kernel for other
+    dims (round-5 advisor finding: the short form used to take the <6, 128, 8> instance and read D2 / td rows with the wrong extent)."""
+    t = R.synth_named("v6-small")
+    rng = np.random.default_rng(77 + Dd)
+    C = t["blocks.0.att.time_decay"].shape[-1]
+    for l in range(3):
+        t[f"blocks.{l}.att.time_decay_w1"] = (rng.standard_normal((Dd, C), dtype=np.float32) * np.float32(0.05)).astype(np.float16)
+        t[f"blocks.{l}.att.time_decay_w2"] = (rng.standard_normal((C, Dd), dtype=np.float32) * np.float32(0.05)).astype(np.float16)
+    eng = rt.ModelBuilder(R.st_serialize(t)).build(max_batch=3, token_chunk_size=chunk, precision=rt.Precision.Fp32)
+    ref = R.RwkvRef(t)
+    ps = [prompt(ref, 50 + s, 21 + 4 * s) for s in range(3)]
+    got = run_prompts(eng, ps)
+    for b in range(3):
+        s = ref.init_state()
+        want = ref.forward(ps[b], s)[-1]
+        assert np.abs(got[b][0] - want).max() <= tol(rt.Precision.Fp32, want)
+        assert np.abs(eng.state.back(b) - s).max() <= tol(rt.Precision.Fp32, s)
+    eng.close()
