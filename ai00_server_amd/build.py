@@ -46,7 +46,7 @@ def needs_build() -> bool:
     return open(STAMP).read().strip() != _sources_digest()
 
 
-KERNEL_PARTS = 5      # rwkv_kernels.hip is compiled once per part (-DRWKV_PART=k), in parallel
+KERNEL_PARTS = 6      # rwkv_kernels.hip is compiled once per part (-DRWKV_PART=k), in parallel
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
