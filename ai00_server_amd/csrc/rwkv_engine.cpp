@@ -1024,9 +1024,9 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const ShiftComm
             else if (gemm_tile_pipelined(f_shape) && ok4) shape = GEMM_TILE4_HILO;      // a forced pipelined shape means "the pipelined kernel of this operand form"
             else shape = 4;                                                              // (also shape 5 with hi + lo operands: its LDS image does not fit)
         }
-        const bool wide_tile = shape == GEMM_TILE3 || shape == GEMM_TILE5;                                           // 128 x 128 pipelined tiles
-        const bool narrow_tile = shape == GEMM_TILE3_64 || shape == GEMM_TILE4_HILO || shape == GEMM_TILE5_64;      // 128 x 64
-        const bool okp = ok3 || ok4 || gemm_tile_pipelined(shape);
+        const bool wide_tile = shape == GEMM_TILE3;                                      // 128 x 128 pipelined tiles
+        const bool narrow_tile = shape == GEMM_TILE3_64 || shape == GEMM_TILE4_HILO;    // 128 x 64
+        const bool okp = ok3 || ok4;
         // K split of a linear launch on the pipelined kernel (Wo, Fv: one `partial` problem whose output the next row kernel sums
         // anyway): a grid of fewer than 512 tiles costs a whole round of the kernel, so the tiles are replicated over `ksb` K ranges
         // until the rounds are full — 3 x 320 tiles (V6-3B at 2048 rows) fill 94 % of two rounds a third as long (tg3_body).
@@ -1049,7 +1049,7 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const ShiftComm
                 const long t11 = gemm_tile_blocks(GEMM_TILE3_64, ps[0].W->rows, T);
                 ksplit = 1;
                 for (int b = 2; b <= 4 && ps[0].W->K / b >= 768 && t11 * (b - 1) < 224; ++b) ksplit = b;
-            } else if (ksplit > 1) shape = shape == GEMM_TILE5 ? GEMM_TILE5 : GEMM_TILE3;
+            } else if (ksplit > 1) shape = GEMM_TILE3;
             else if (!wide_tile) {
                 // the 64x64 shapes on a step of a few hundred rows: Wo / Fv have fewer tiles than the chip has CUs (160 at 256 rows of
                 // the 3 B model); copies over K fill it
@@ -1074,28 +1074,16 @@ int rwkv_engine::gemm(std::vector<ProbSpec> &ps, int T, int fam, const ShiftComm
         }
         Lh.total_blocks = blocks;
         Lh.xcd_map = 1;                                             // XCD-banded tile numbering (rwkv_kernels.hip tg_body)
-        {
-            // Which operand an XCD keeps in its 4 MiB L2 (round 6).  Row-tile-major bands: every weight byte is fetched by ONE XCD, and that XCD walks
-            // all token tiles — the whole X of the step — once per row tile.  While X fits in an L2 that costs 8 x X; beyond ~3 MB (640 rows at
-            // C = 2560) X streams from the Infinity Cache once per row tile: V6-3B r/k/v/g at 2048 rows = 81 x 10.5 MB = 850 MB for a 26 MB matrix.
-            // Token-tile-major bands keep an XCD's own token tiles' rows resident and stream the weights past them: X once, the weights once per
-            // XCD that shares a row tile (<= 8 x): 220 MB.  Pick the cheaper by this estimate.
-            int kmax = 0;
-            long rows_total = 0;
-            double wbytes = 0;
-            for (auto &sp : ps) { kmax = std::max(kmax, sp.W->K); wbytes += (double)sp.W->bytes; rows_total += sp.W->rows; }
-            const double xbytes = (double)T * kmax * 2 * (hilo ? 2 : 1);
-            const int bt = (shape == 3 || shape == 4 || shape == 6 || shape == 7 || narrow_tile) ? 64 : 128;
-            const int ntt = (T + bt - 1) / bt;
-            const double nrb = (double)((rows_total + 127) / 128);
-            const double row_major = wbytes + (xbytes <= 3e6 ? 8.0 : std::max(8.0, nrb)) * xbytes;
-            const double tok_major = xbytes + wbytes * std::min(8, ntt);
-            if (const char *e = std::getenv("RWKV_TILE_XCD")) { if (*e) Lh.xcd_map = std::atoi(e); }
-            else if (tok_major < row_major) Lh.xcd_map = 2;
-        }
+        // Order of the XCD bands (round 6, profiles/r6_exp_tile5_and_xcd_order.log).  Row-tile-major (1): every weight byte is fetched by ONE XCD, which walks
+        // all token tiles for it.  Token-tile-major (2): an XCD keeps its own token tiles' X rows in its L2 and streams the weights past them.  An
+        // estimate by bytes says (2) from ~640 rows on; measured, the blocks of an XCD walk K in near lock-step, so X streams through the L2 once either
+        // way: no change for plain operands (r/k/v/g Int8 at 2048 rows 144.5 / 145.8 us), worse with fp16 weights (149 -> 155), and -8 % only where
+        // the operand is doubled — hi + lo launches of 2048-row steps (258 -> 238 us).  RWKV_TILE_XCD overrides (dev).
+        if (hilo && T >= 2048 && shape == GEMM_TILE4_HILO) Lh.xcd_map = 2;
+        if (const char *e = std::getenv("RWKV_TILE_XCD")) { if (*e) Lh.xcd_map = std::atoi(e); }
         {   // block size of the tile shape (rwkv_kernels.hip TG_SH; the pipelined kernel runs 256 threads): the profile joins on it
             static const int waves[10] = {8, 8, 4, 4, 4, 8, 4, 4, 4, 8};
-            log_gemm(ps, T, fam, "tile", shape, blocks, ksplit, shape < 10 ? waves[shape] * 64 : (shape >= GEMM_TILE5 ? 512 : 256));
+            log_gemm(ps, T, fam, "tile", shape, blocks, ksplit, shape < 10 ? waves[shape] * 64 : 256);
         }
         launch(fam, [&] { launch_gemm_tile(Lh, shape, hilo, s_main); });
         return ksplit;
@@ -2112,7 +2100,7 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
                         shape = GEMM_TILE3;
                         for (int sh = 0; sh < GEMM_TILE_SHAPES; ++sh) if (gemm_tile_blocks(sh, rows, T) >= 1024) { shape = sh; break; }
                     }
-                    if (!gemm_tile_shape_supported(shape, hilo != 0, K)) throw RwkvError(RWKV_ERR_INVALID, "bench_gemm: the pipelined shapes need K % 128 == 0; shapes 10 / 11 / 13 take plain operands, 12 hi + lo, 14 both");
+                    if (!gemm_tile_shape_supported(shape, hilo != 0, K)) throw RwkvError(RWKV_ERR_INVALID, "bench_gemm: the pipelined shapes need K % 128 == 0; shapes 10 / 11 take plain operands, shape 12 hi + lo");
                     Lh = GemmLaunch{};
                     Lh.nprob = 1; Lh.T = T;
                     GemmProb &g = Lh.p[0];

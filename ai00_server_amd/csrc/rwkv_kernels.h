@@ -16,7 +16,7 @@ enum Post : int { POST_NONE = 0, POST_MUL = 1, POST_MIX = 2 };
 struct Knobs {
     int no_ln_fuse = 0;              // RWKV_NO_LN_FUSE: the ln_shift row kernel instead of the LayerNorm prologue of the V6 mix on single-token steps
     int no_v6_fuse = 0;              // RWKV_NO_V6_FUSE: the V6 token-shift LoRA as two GEMM launches instead of v6_mix_kernel
-    int no_tile = 0, tile_shape = -1;   // RWKV_NO_TILE: the decode GEMM for every step; RWKV_TILE_SHAPE=0..14: force a prefill tile shape (parity of every shape)
+    int no_tile = 0, tile_shape = -1;   // RWKV_NO_TILE: the decode GEMM for every step; RWKV_TILE_SHAPE=0..12: force a prefill tile shape (parity of every shape)
     int no_dense = 0;                // RWKV_NO_DENSE: general row metadata on dense decode steps
     int tile_ksplit = 1;             // RWKV_TILE_KSPLIT=0: no K copies of linear prefill launches (the race screen compares tile shapes BIT for bit, which needs one summation order)
     int promote = -1;                // RWKV_PROMOTE (dev override; -1 = unset: the precision mode decides): bit mask of GEMM launch classes that read hi + lo
@@ -133,20 +133,16 @@ void launch_smallk(const GemmLaunch &L, bool hilo, hipStream_t s);   // output-s
 int gemm_max_rounds(int fmt, int NT, bool hilo);
 // prefill path (T >= GEMM_TILE_MIN_T): LDS-tiled MFMA GEMM, no K split; uses p[].block_begin and total_blocks only
 constexpr int GEMM_TILE_MIN_T = 193;                     // measured crossover (V6-3B Int8): up to 192 rows the decode kernel's 64-row passes win or tie
-constexpr int GEMM_TILE_SHAPES = 15;                      // 256x128, 128x128, 64x128, 64x64 (rows x tokens, 128-k chunks); 64x64 and 128x128 with 256-k chunks
+constexpr int GEMM_TILE_SHAPES = 13;                      // 256x128, 128x128, 64x128, 64x64 (rows x tokens, 128-k chunks); 64x64 and 128x128 with 256-k chunks
 int gemm_tile_blocks(int shape, int rows, int T);
 constexpr int GEMM_TILE3 = 10;                            // the pipelined 128x128 kernel (non-hi/lo operands, K % 128 == 0)
 constexpr int GEMM_TILE3_64 = 11;                         // the same pipeline on 128 rows x 64 tokens (steps of a few hundred rows)
 constexpr int GEMM_TILE4_HILO = 12;                       // the software-pipelined kernel for hi + lo operands on 128 rows x 64 tokens (round 6; K % 128 == 0)
-constexpr int GEMM_TILE5 = 13;                            // the loader / consumer kernel (round 6) on 128 x 128 tiles (plain operands)
-constexpr int GEMM_TILE5_64 = 14;                         // ... on 128 rows x 64 tokens; also with hi + lo operands
-inline bool gemm_tile_pipelined(int shape) { return shape >= GEMM_TILE3 && shape <= GEMM_TILE5_64; }
+inline bool gemm_tile_pipelined(int shape) { return shape >= GEMM_TILE3 && shape <= GEMM_TILE4_HILO; }
 bool gemm_tile3_supported(bool hilo, int K);
 bool gemm_tile4_supported(bool hilo, int K);
-bool gemm_tile5_supported(int ntl, bool hilo, int K);
 inline bool gemm_tile_shape_supported(int shape, bool hilo, int K) {
     if (shape == 5 && hilo) return false;                // 128 tokens x 256-k chunks, double-buffered, hi + lo: 256 KiB of LDS
-    if (shape >= GEMM_TILE5) return gemm_tile5_supported(shape == GEMM_TILE5 ? 8 : 4, hilo, K);
     return shape == GEMM_TILE4_HILO ? gemm_tile4_supported(hilo, K) : (shape >= GEMM_TILE3 ? gemm_tile3_supported(hilo, K) : true);
 }
 void launch_gemm_tile45(const GemmLaunch &L, int kind, int ntl, bool hilo, hipStream_t s);   // rwkv_kernels.hip part 5

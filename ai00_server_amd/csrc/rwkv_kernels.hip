@@ -1420,7 +1420,7 @@ __device__ __forceinline__ void tg_body(const GemmLaunch &L, const GemmProb &P, 
     }
     // the banded sequence is row-tile major (token tile fastest: an XCD streams its eighth of the weights once and re-reads them from its L2 for every
     // token tile) or, L.xcd_map == 2, token-tile major (row tile fastest: an XCD keeps ITS token tiles' operand rows in its L2 and streams the weights
-    // past them) — the host picks by which operand is too large for a 4 MiB L2 (rwkv_engine.cpp)
+    // past them): measured better only for hi + lo operands at 2048 rows (rwkv_engine.cpp)
     const int nrb_ = nb / ntt;
     const int rb = L.xcd_map == 2 ? lb % nrb_ : lb / ntt, tt = L.xcd_map == 2 ? lb / nrb_ : lb - rb * ntt;
     const int strip = rb * STRIPS + wave * SPW;
@@ -1778,7 +1778,7 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
     }
     // the banded sequence is row-tile major (token tile fastest: an XCD streams its eighth of the weights once and re-reads them from its L2 for every
     // token tile) or, L.xcd_map == 2, token-tile major (row tile fastest: an XCD keeps ITS token tiles' operand rows in its L2 and streams the weights
-    // past them) — the host picks by which operand is too large for a 4 MiB L2 (rwkv_engine.cpp)
+    // past them): measured better only for hi + lo operands at 2048 rows (rwkv_engine.cpp)
     const int nrb_ = nb / ntt;
     const int rb = L.xcd_map == 2 ? lb % nrb_ : lb / ntt, tt = L.xcd_map == 2 ? lb / nrb_ : lb - rb * ntt;
     const int strip = rb * STRIPS + wave * SPW;
@@ -2063,7 +2063,7 @@ __device__ __forceinline__ void tg4_body(const GemmLaunch &L, const GemmProb &P,
     }
     // the banded sequence is row-tile major (token tile fastest: an XCD streams its eighth of the weights once and re-reads them from its L2 for every
     // token tile) or, L.xcd_map == 2, token-tile major (row tile fastest: an XCD keeps ITS token tiles' operand rows in its L2 and streams the weights
-    // past them) — the host picks by which operand is too large for a 4 MiB L2 (rwkv_engine.cpp)
+    // past them): measured better only for hi + lo operands at 2048 rows (rwkv_engine.cpp)
     const int nrb_ = nb / ntt;
     const int rb = L.xcd_map == 2 ? lb % nrb_ : lb / ntt, tt = L.xcd_map == 2 ? lb / nrb_ : lb - rb * ntt;
     const int strip = rb * STRIPS + wave * SPW;
@@ -2216,294 +2216,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tile4_kernel(const GemmLaunch L) 
 bool gemm_tile4_supported(bool hilo, int K) { return hilo && K % 128 == 0; }
 
 
-// =====================================================================================
-// Loader / consumer tile kernel (shapes 13 / 14; round 6).  What bounds gemm_tile3 / tile4 is not the MFMA count and not the order of a
-// wave's instructions (see the ablation above): it is that the waves which multiply also ISSUE the block's VMEM traffic — every LDS-DMA and
-// every weight-tile load holds the in-order wave for 60-185 cycles, MFMAs behind it included.  Here the two jobs are different waves:
-//   * waves 4..7 (one per SIMD) are LOADERS: nothing but `global_load_lds_dwordx4` — the X tiles of stage s + 4 (ring of four 64-k
-//     stages, as before) AND the weight tiles of group g + 3 (ring of three 128-k groups: the block's 8 strips, raw fp16 / Int8 / NF4 tiles,
-//     1 KiB each, already in A-fragment order) — a counted `s_waitcnt vmcnt(2 x + w)` and the stage barrier;
-//   * waves 0..3 are CONSUMERS: wave w owns strips {2w, 2w+1} x all token tiles.  No VMEM instruction except one 8-byte scale load per
-//     strip and group (quantised formats).  Their K loop is tg4_body's software pipeline — every MFMA of k-step q followed by a slice of
-//     the preparation of k-step q + 1: a B-fragment read, a dequantisation unit, and (first three k-steps of a group) the ds_read_b128 of
-//     the NEXT group's raw weight tiles into the other of two raw register sets.
-// One barrier per stage (all eight waves), between its two k-steps.  It publishes X stage s + 1 and, at odd s, weight group (s + 3) / 2 —
-// the group whose raw tiles the consumers start reading one k-step later.  Slots are re-filled one barrier after their last read: the X
-// slot of stage s and (s odd) the W slot of group (s + 1) / 2 - 1 ... see the loader loop.  One block per CU (the rings take up to 160 KiB).
-// HILO as in tg4_body (a stage holds hi and lo tiles; 128 x 64 only).  Same summation order as every tile kernel: bit-identical results.
-// =====================================================================================
-constexpr int T5_DXR = 4, T5_DWR = 3, T5_NL = 4;                  // X ring (stages), W ring (groups), loader waves
-template <int FMT> constexpr int t5_wgroup_bytes() { return 8 * (4 / Fmt<FMT>::KS) * 1024; }      // 8 strips x NQ tiles
-template <int NTL, bool HILO> constexpr int t5_stage_bytes() { return NTL * (HILO ? 2 : 1) * 2 * 1024; }
-template <int NTL, bool HILO> constexpr size_t t5_lds_bytes(int fmt) {
-    return (size_t)T5_DXR * t5_stage_bytes<NTL, HILO>() + (size_t)T5_DWR * (fmt == W_F16 ? t5_wgroup_bytes<W_F16>() : fmt == W_INT8 ? t5_wgroup_bytes<W_INT8>() : t5_wgroup_bytes<W_NF4>());
-}
-template <int N> __device__ __forceinline__ void t5_vm_barrier() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void t5_lgkm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-template <int OFF> __device__ __forceinline__ void t5_lds16u(u32x4 &d, unsigned addr) {             // raw weight tile: completion by the stage barrier's lgkmcnt(0)
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
+// (Round 6 also built the loader / consumer form of this kernel — waves 4..7 issue every LDS-DMA, X stages and raw weight tiles through LDS
+// rings, waves 0..3 only read LDS, dequantise and multiply, one 8-wave block per CU; parity green and bit-identical — and measured it: a block
+// alone on its CU is 25 % faster per stage, but one 8-wave block per CU loses the overlap of two independent 4-wave blocks: r/k/v/g Int8 at 2048
+// rows 173.6 us against 142.5, at 256 rows 35.8-37.5 against 34.6.  profiles/r6_exp_tile5_and_xcd_order.log; the code is in the history at
+// 3bb646c.)
 
-template <int FMT, int NTL, bool HILO>
-__device__ __forceinline__ void tg5_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
-    constexpr int SPW = 2, STRIPS = 8, BT = NTL * 16, NL = T5_NL;
-    constexpr int HB = HILO ? 2 : 1, NBT = NTL * HB, M = SPW * NBT;
-    constexpr int STAGE_TILES = NBT * 2, STAGE_BYTES = STAGE_TILES * 1024, XPL = STAGE_TILES / NL;      // X DMAs per loader per stage
-    constexpr int NQ = 4 / Fmt<FMT>::KS, WG_TILES = STRIPS * NQ, WG_BYTES = WG_TILES * 1024, WPL = WG_TILES / NL;   // W DMAs per loader per group
-    constexpr int UNITS = T4Dq<FMT>::UNITS, UT = SPW * UNITS, NRAW = SPW * NQ;
-    constexpr int W_BASE = T5_DXR * STAGE_BYTES;                  // byte offset of the weight ring
-    static_assert(!HILO || NTL == 4, "hi + lo operands: 128 x 64 tiles only");
-    static_assert(STAGE_TILES % NL == 0 && WG_TILES % NL == 0 && M % UT == 0, "work divides over the loaders / slots");
-    using Set = T3Set<FMT, SPW>;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nstrips = P.rows >> 4;
-    const int ntt = (L.T + BT - 1) / BT;
-    int lb = (int)blockIdx.x - P.block_begin;
-    const int nb = ((nstrips + STRIPS - 1) / STRIPS) * ntt;       // tiles of one K copy
-    const int kb = lb / nb;
-    lb -= kb * nb;
-    if (L.xcd_map) {                                              // XCD-banded tile numbering, as in tg_body
-        const int k = lb & 7, j = lb >> 3;
-        int start = 0;
-        for (int m = 0; m < k; ++m) start += (nb - m + 7) >> 3;
-        lb = start + j;
-    }
-    // the banded sequence is row-tile major (token tile fastest: an XCD streams its eighth of the weights once and re-reads them from its L2 for every
-    // token tile) or, L.xcd_map == 2, token-tile major (row tile fastest: an XCD keeps ITS token tiles' operand rows in its L2 and streams the weights
-    // past them) — the host picks by which operand is too large for a 4 MiB L2 (rwkv_engine.cpp)
-    const int nrb_ = nb / ntt;
-    const int rb = L.xcd_map == 2 ? lb % nrb_ : lb / ntt, tt = L.xcd_map == 2 ? lb / nrb_ : lb - rb * ntt;
-    const int t0 = tt * BT;
-    const int G = P.K >> 7, g0 = (int)((long)kb * G / P.ksb), g1 = (int)((long)(kb + 1) * G / P.ksb);
-    const int kofs = g0 * 128;
-    const int nsc = g1 - g0, nst = nsc * 2;
-    const unsigned xs_byte = (unsigned)(uintptr_t)smem;
-    const int last_tile = (L.T - 1) >> 4;
-
-    if (wave >= 4) {
-        // ------------------------------------------------------------------ loader l: stage tiles i = m NL + l, group tiles j = m NL + l
-        const int l = wave - 4;
-        unsigned xoff[XPL], woff[WPL];
-#pragma unroll
-        for (int m = 0; m < XPL; ++m) {
-            const int i = m * NL + l, nt = (i >> 1) % NTL;
-            const int ttile = min((t0 >> 4) + nt, last_tile);
-            xoff[m] = (unsigned)(((ttile * (P.ldx >> 5) + (i & 1)) * 512 + lane * 8) * 2);
-        }
-        {
-            const int KT = P.K >> Fmt<FMT>::SH;
-#pragma unroll
-            for (int m = 0; m < WPL; ++m) {
-                const int j = m * NL + l, sidx = min(rb * STRIPS + j / NQ, nstrips - 1);
-                woff[m] = (unsigned)((sidx * KT + j % NQ) * 64 + lane) * 16u;
-            }
-        }
-        const char *const xbase_hi = (const char *)(P.xhi + (long)(kofs >> 5) * 512);
-        const char *const xbase_lo = HILO ? (const char *)(P.xlo + (long)(kofs >> 5) * 512) : xbase_hi;
-        const char *const wbase = (const char *)P.W + (long)(kofs >> Fmt<FMT>::SH) * 1024;
-        auto dma_x = [&](int s) {
-            if (s >= nst) return;
-            const unsigned dst = xs_byte + (unsigned)((s & (T5_DXR - 1)) * STAGE_BYTES + l * 1024);
-            t4_for<XPL>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                constexpr bool lo = HILO && (m * NL) / 2 / NTL == 1;             // fragment b = i >> 1 = (m NL + l) >> 1, l < NL: part = (m NL / 2) / NTL
-                t3_dma16(xoff[m], (lo ? xbase_lo : xbase_hi) + (long)s * 2048, dst + m * NL * 1024);
-            });
-        };
-        auto dma_w = [&](int g) {
-            if (g >= nsc) return;
-            const unsigned dst = xs_byte + (unsigned)(W_BASE + (g % T5_DWR) * WG_BYTES + l * 1024);
-            const char *src = wbase + (long)g * NQ * 1024;
-            t4_for<WPL>([&](auto mc) { constexpr int m = decltype(mc)::value; t3_dma16(woff[m], src, dst + m * NL * 1024); });
-        };
-        // prologue: W(0), W(1), X(0) | W(2), X(1), X(2): the first three land before barrier A
-        dma_w(0); dma_w(1); dma_x(0); dma_w(2); dma_x(1); dma_x(2);
-        if (nst > 2 && nsc > 2) t5_vm_barrier<2 * XPL + WPL>(); else t5_vm_barrier<0>();      // barrier A
-        asm volatile("s_barrier" ::: "memory");                                                // barrier B: the consumers have read W(0)'s raw tiles
-        for (int s = 0; s < nst; ++s) {
-            // after barrier(s - 1): the W slot of group s / 2 (s even; its raw tiles were read during the previous group) and the X slot of stage
-            // s - 1 are free.  W first, then X: the count below is then the same at every stage.
-            if ((s & 1) == 0) dma_w((s >> 1) + T5_DWR);
-            dma_x(s + T5_DXR - 1);
-            // barrier(s): X(s + 1) landed (and everything older: at odd s the weight group (s + 3) / 2, requested at iteration s - 3).  Younger:
-            // X(s + 2), X(s + 3) and one weight group.
-            if (s + 6 < nst) t5_vm_barrier<2 * XPL + WPL>(); else t5_vm_barrier<0>();
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- consumer c = wave: strips rb * 8 + {2c, 2c + 1}
-    const int strip = rb * STRIPS + wave * SPW;
-    Nf4Lut lut;
-    if constexpr (FMT == W_NF4) lut = make_nf4_lut();
-    f32x4 acc[SPW][NTL];
-#pragma unroll
-    for (int h = 0; h < SPW; ++h)
-#pragma unroll
-        for (int nt = 0; nt < NTL; ++nt) acc[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // scale words of this wave's strips (one 8-byte word per row and 256 k), straight from L2 / HBM one group ahead
-    unsigned soff[SPW];
-    {
-        const int KG = P.K >> 8;
-#pragma unroll
-        for (int h = 0; h < SPW; ++h) soff[h] = (unsigned)(min(strip + h, nstrips - 1) * KG * 16 + (lane & 15)) * 8u;
-    }
-    const char *const sbase = (const char *)P.S;
-    auto sload = [&](Set &w, int g) {                              // group g of this copy (clamped: a group past the end re-reads the last one)
-        if constexpr (FMT != W_F16) {
-            const char *sg = sbase + (long)(((kofs >> 7) + min(g, nsc - 1)) >> 1) * 128;
-#pragma unroll
-            for (int h = 0; h < SPW; ++h) t3_ld8(w.s[h], soff[h], sg);
-        }
-    };
-    auto s_arrived = [&](Set &w) {
-        if constexpr (FMT != W_F16) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int h = 0; h < SPW; ++h) asm volatile("" : "+v"(w.s[h]));
-        }
-    };
-    auto q_arrived = [&](Set &w) {                                 // raw tiles: retired by the lgkmcnt(0) of the barrier just passed
-#pragma unroll
-        for (int h = 0; h < SPW; ++h)
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) asm volatile("" : "+v"(w.q[h][j]));
-    };
-    const unsigned rd0 = xs_byte + (unsigned)(lane * 16);
-    auto slot_rd = [&](int s) { return rd0 + (unsigned)((s & (T5_DXR - 1)) * STAGE_BYTES); };
-    auto wslot_rd = [&](int g) { return rd0 + (unsigned)(W_BASE + (g % T5_DWR) * WG_BYTES + wave * SPW * NQ * 1024); };
-    // raw tile r (0 .. NRAW-1) = (strip h = r / NQ, tile r % NQ) of a group, from the W ring
-    auto raw_read = [&](Set &w, unsigned wa, auto rc) {
-        constexpr int r = decltype(rc)::value;
-        t5_lds16u<r * 1024>(w.q[r / NQ][r % NQ], wa);
-    };
-
-    // ---- one k-step (tg4_body's): MFMAs on (Ac, Bc); B reads + dequantisation for the next k-step; RP = which third of the next group's raw tiles
-    // this k-step reads (0..2; 3 = none) into `wr` from ring address `wra`
-    auto kstep = [&](const u32x4 (&Ac)[SPW], u32x4 (&An)[SPW], f16x8 (&Bc)[NBT], f16x8 (&Bn)[NBT], const Set &wn, const T4Scale<FMT> &sc, unsigned rdn,
-                     auto ksn_c, auto qn_c, auto rp_c, auto rprev_c, Set &wr, unsigned wra) {
-        constexpr int KSN = decltype(ksn_c)::value, QN = decltype(qn_c)::value, RP = decltype(rp_c)::value, RPREV = decltype(rprev_c)::value;
-        constexpr int R0 = RP < 3 ? RP * NRAW / 3 : 0, R1 = RP < 3 ? (RP + 1) * NRAW / 3 : 0;          // raw reads of this k-step: [R0, R1), slots NBT ..
-        constexpr int RWP = RPREV < 3 ? (RPREV + 1) * NRAW / 3 - RPREV * NRAW / 3 : 0;               // raw reads the previous k-step issued behind its B reads
-        t4_for<M>([&](auto ic) {
-            constexpr int i = decltype(ic)::value, b = i / SPW, h = i % SPW;
-            // LDS returns in order: behind fragment b of this k-step are the rest of the previous k-step's B reads, its raw reads, and whatever this
-            // k-step has issued so far
-            constexpr int RSOFAR = i <= NBT ? 0 : (i - NBT < R1 - R0 ? i - NBT : R1 - R0);
-            if constexpr (h == 0) t3_lgkm_wait<(NBT - 1 - b) + RWP + (i < NBT ? i : NBT) + RSOFAR>(Bc[b]);
-            acc[h][b % NTL] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ac[h]), Bc[b], acc[h][b % NTL], 0, 0, 0);
-            if constexpr (i < NBT) t3_lds16<(i * 2 + QN) * 1024>(Bn[i], rdn);
-            else if constexpr (i - NBT < R1 - R0) raw_read(wr, wra, std::integral_constant<int, R0 + i - NBT>{});
-            if constexpr (i % (M / UT) == 0) {
-                constexpr int j = i / (M / UT);
-                t4_unit<FMT, KSN, j % UNITS>(An[j / UNITS], wn, sc, lut, j / UNITS);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-    static_assert(NBT + (NRAW + 2) / 3 <= M, "the raw reads of a k-step fit behind its B reads");
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    u32x4 A0[SPW], A1[SPW];
-    f16x8 B0[NBT], B1[NBT];
-    T4Scale<FMT> sc_cur, sc_nxt;
-    // ---- one weight group = four k-steps = stages 2g, 2g + 1.  `cur` holds group g's raw tiles, `nxt` receives group g + 1's during the first
-    // three k-steps; the barrier after the third retires them; the fourth dequantises from `nxt` and requests the scale words of group g + 2
-    // into `cur`.
-    auto group = [&](Set &cur, Set &nxt, int g) {
-        const int s = 2 * g;
-        const unsigned wra = wslot_rd(g + 1);
-        kstep(A0, A1, B0, B1, cur, sc_cur, slot_rd(s), I1{}, I1{}, I0{}, I3{}, nxt, wra);            // k-step 4g
-        t5_lgkm_barrier();                                                                            // barrier(s): X(s + 1) published
-        kstep(A1, A0, B1, B0, cur, sc_cur, slot_rd(s + 1), I2{}, I0{}, I1{}, I0{}, nxt, wra);        // k-step 4g + 1
-        kstep(A0, A1, B0, B1, cur, sc_cur, slot_rd(s + 1), I3{}, I1{}, I2{}, I1{}, nxt, wra);        // k-step 4g + 2
-        t5_lgkm_barrier();                                                                            // barrier(s + 1): X(s + 2), W(g + 2) published; nxt's raw tiles retired
-        q_arrived(nxt);
-        s_arrived(nxt);
-        t4_scales<FMT>(sc_nxt, nxt, (kofs >> 7) + g + 1);
-        sload(cur, g + 2);
-        kstep(A1, A0, B1, B0, nxt, sc_nxt, slot_rd(s + 2), I0{}, I0{}, I3{}, I2{}, cur, wra);        // k-step 4g + 3: next = first of group g + 1
-        sc_cur = sc_nxt;
-    };
-    Set r0, r1;
-    sload(r0, 0);
-    sload(r1, 1);
-    t5_lgkm_barrier();                                                                                // barrier A: W(0), W(1), X(0) in LDS
-    {
-        const unsigned wa0 = wslot_rd(0);
-        t4_for<NRAW>([&](auto rc) { raw_read(r0, wa0, rc); });
-        t4_for<NBT>([&](auto bc) { t3_lds16<decltype(bc)::value * 2 * 1024>(B0[decltype(bc)::value], slot_rd(0)); });
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    q_arrived(r0);
-    r1.q[0][0] = r0.q[0][0];                                                                          // (every register of r1 defined before its first conditional use)
-#pragma unroll
-    for (int h = 0; h < SPW; ++h)
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) r1.q[h][j] = r0.q[h][j];
-    s_arrived(r0);
-    s_arrived(r1);
-    t4_for<NBT>([&](auto bc) { t3_lgkm_wait<0>(B0[decltype(bc)::value]); });
-    t4_scales<FMT>(sc_cur, r0, kofs >> 7);
-    t4_for<UT>([&](auto jc) { constexpr int j = decltype(jc)::value; t4_unit<FMT, 0, j % UNITS>(A0[j / UNITS], r0, sc_cur, lut, j / UNITS); });
-    asm volatile("s_barrier" ::: "memory");                                                           // barrier B: W(0)'s slot may be re-filled
-    __builtin_amdgcn_sched_barrier(0);
-    for (int g = 0; g < nsc; g += 2) {
-        group(r0, r1, g);
-        if (g + 1 < nsc) group(r1, r0, g + 1);
-    }
-    if (P.ksb > 1) {
-        GemmProb Q = P;
-        Q.out_f32 = P.out_f32 + (long)kb * P.partial_stride;
-        tg_epilogue<SPW, NTL>(L, Q, acc, strip, nstrips, t0, lane);
-    } else {
-        tg_epilogue<SPW, NTL>(L, P, acc, strip, nstrips, t0, lane);
-    }
-}
-
-template <int NTL, bool HILO>
-__global__ __launch_bounds__(512) void gemm_tile5_kernel(const GemmLaunch L) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int pi = 0;
-    for (int i = 1; i < L.nprob; ++i)
-        if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
-    const GemmProb &P = L.p[pi];
-    if (P.fmt == W_F16) tg5_body<W_F16, NTL, HILO>(L, P, smem);
-    else if (P.fmt == W_INT8) tg5_body<W_INT8, NTL, HILO>(L, P, smem);
-    else tg5_body<W_NF4, NTL, HILO>(L, P, smem);
-}
-bool gemm_tile5_supported(int ntl, bool hilo, int K) { return K % 128 == 0 && (!hilo || ntl == 4); }
-
-// part-5 launcher: kind 3 = tg4 (hi + lo, 128 x 64), kind 4 = tg5 (ntl = 8 / 4; hi + lo on 128 x 64)
+// part-5 launcher (called by launch_gemm_tile in part 2)
 void launch_gemm_tile45(const GemmLaunch &L, int kind, int ntl, bool hilo, hipStream_t s) {
+    (void)kind; (void)ntl; (void)hilo;
     static bool attr[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr[dev & 15]) {
         (void)hipFuncSetAttribute((const void *)gemm_tile4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)gemm_tile5_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)gemm_tile5_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)gemm_tile5_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr[dev & 15] = true;
     }
-    if (kind == 3) {
-        hipLaunchKernelGGL(gemm_tile4_kernel, dim3(L.total_blocks), dim3(256), (size_t)T3_NB * 4 * 2 * 2 * 1024, s, L);
-        return;
-    }
-    int fmt_max = W_NF4;                                       // the widest weight group of the launch sizes the W ring: fp16 > Int8 > NF4
-    for (int i = 0; i < L.nprob; ++i) fmt_max = L.p[i].fmt == W_F16 ? W_F16 : (L.p[i].fmt == W_INT8 && fmt_max != W_F16 ? W_INT8 : fmt_max);
-    const size_t lds8 = t5_lds_bytes<8, false>(fmt_max), lds4h = t5_lds_bytes<4, true>(fmt_max), lds4 = t5_lds_bytes<4, false>(fmt_max);
-    if (ntl == 8) hipLaunchKernelGGL((gemm_tile5_kernel<8, false>), dim3(L.total_blocks), dim3(512), lds8, s, L);
-    else if (hilo) hipLaunchKernelGGL((gemm_tile5_kernel<4, true>), dim3(L.total_blocks), dim3(512), lds4h, s, L);
-    else hipLaunchKernelGGL((gemm_tile5_kernel<4, false>), dim3(L.total_blocks), dim3(512), lds4, s, L);
+    hipLaunchKernelGGL(gemm_tile4_kernel, dim3(L.total_blocks), dim3(256), (size_t)T3_NB * 4 * 2 * 2 * 1024, s, L);
 }
-#endif  // part 5: software-pipelined / loader-consumer tile kernels
+#endif  // part 5: software-pipelined hi + lo tile kernel
 #if RWKV_PART_ON(2)
 // tile shapes, largest first: {waves, strips per wave, n-tiles, k per chunk}
 static const int kTileShapes[GEMM_TILE_SHAPES][5] = {{8, 2, 8, 128, 0}, {8, 1, 8, 128, 0}, {4, 1, 8, 128, 0}, {4, 1, 4, 128, 0}, {4, 1, 4, 256, 0}, {8, 1, 8, 256, 0},
                                                      {4, 1, 4, 256, 1}, {4, 2, 4, 128, 1}, {4, 2, 8, 128, 1}, {8, 2, 8, 128, 1}, {4, 2, 8, 128, 2}, {4, 2, 4, 128, 2},
-                                                     {4, 2, 4, 128, 3}, {4, 2, 8, 128, 4}, {4, 2, 4, 128, 4}};
+                                                     {4, 2, 4, 128, 3}};
 // (128 rows x 64 tokens with 8 waves, 256-k and 128-k chunks — half the operand re-reads of the 64x64 shapes on steps of a few hundred
 // rows — was built and measured in round 3: slower on every matrix but one, profiles/r3_exp_tile_128x64.log; removed.)
 int gemm_tile_blocks(int shape, int rows, int T) {
@@ -2512,7 +2248,7 @@ int gemm_tile_blocks(int shape, int rows, int T) {
 }
 
 void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s) {
-    if (kTileShapes[shape][4] >= 3) {                          // part 5: software-pipelined hi + lo kernel (3), loader / consumer kernel (4)
+    if (kTileShapes[shape][4] >= 3) {                          // part 5: software-pipelined hi + lo kernel
         launch_gemm_tile45(L, kTileShapes[shape][4], kTileShapes[shape][2], hilo, s);
         return;
     }

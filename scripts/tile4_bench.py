@@ -9,7 +9,7 @@ from ai00_server_amd import runtime as rt
 MATS = {"rkvg": (10240, 2560), "fk": (8960, 2560), "fv": (2560, 8960), "wo": (2560, 2560), "rkvg7b": (16384, 4096)}
 fmts = [int(x) for x in os.environ.get("FMTS", "1,0,2").split(",")]
 ts = [int(x) for x in os.environ.get("TS", "256,512,2048").split(",")]
-shapes = [int(x) for x in os.environ.get("SHAPES", "4,11,14,10,13,12").split(",")]
+shapes = [int(x) for x in os.environ.get("SHAPES", "4,11,10,12").split(",")]
 mats = os.environ.get("MATS", "rkvg,fv").split(",")
 hilos = [int(x) for x in os.environ.get("HILO", "0,1").split(",")]
 for mat in mats:
@@ -17,7 +17,7 @@ for mat in mats:
     for fmt in fmts:
         for hilo in hilos:
             for shape in shapes:
-                if (hilo and shape in (10, 11, 13)) or (not hilo and shape == 12):
+                if (hilo and shape in (10, 11)) or (not hilo and shape == 12):
                     continue
                 cells = []
                 for T in ts:

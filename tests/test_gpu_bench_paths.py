@@ -128,7 +128,7 @@ def wide3b():
 
 
 @pytest.mark.parametrize("shape,qt", [(3, 0), (3, 1), (3, 2), (7, 0), (7, 1), (7, 2), (4, 1), (0, 1), (1, 1), (2, 1), (5, 1),
-                                       (6, 1), (8, 1), (9, 1), (9, 0), (10, 0), (10, 1), (10, 2), (11, 0), (11, 1), (11, 2), (12, 0), (12, 1), (12, 2), (13, 0), (13, 1), (13, 2), (14, 0), (14, 1), (14, 2)])
+                                       (6, 1), (8, 1), (9, 1), (9, 0), (10, 0), (10, 1), (10, 2), (11, 0), (11, 1), (11, 2), (12, 0), (12, 1), (12, 2)])
 def test_every_prefill_tile_shape_at_3b_width(wide3b, shape, qt):
     """gemm_tile_kernel in each of its ten shapes, the pipelined kernel on 128x128 (shape 10) and 128x64 tiles (shape 11) and the software-pipelined
     hi + lo kernel (shape 12: the promoted time-mix launch of the default Precision::Fp16; a forced pipelined shape a launch's operand form
@@ -156,7 +156,7 @@ def test_pipelined_tile_kernel_is_bit_identical_to_the_64x64_shape_over_repeated
     st, ps, _ = wide3b
     outs = {}
     os.environ["RWKV_TILE_KSPLIT"] = "0"              # K copies of the linear launches change the summation order, by design
-    for shape in (4, 10, 11, 12, 13, 14):
+    for shape in (4, 10, 11, 12):
         os.environ["RWKV_TILE_SHAPE"] = str(shape)
         try:
             for qt in (0, 1, 2):
@@ -174,7 +174,7 @@ def test_pipelined_tile_kernel_is_bit_identical_to_the_64x64_shape_over_repeated
     os.environ.pop("RWKV_TILE_KSPLIT", None)
     for qt in (0, 1, 2):
         ref_l, ref_s = outs[(4, qt)][0]
-        for shape in (4, 10, 11, 12, 13, 14):
+        for shape in (4, 10, 11, 12):
             for rep, (lg, stt) in enumerate(outs[(shape, qt)]):
                 assert np.array_equal(lg, ref_l), f"logits differ: shape {shape} quant {qt} run {rep}"
                 assert np.array_equal(stt, ref_s), f"state differs: shape {shape} quant {qt} run {rep}"
@@ -183,7 +183,7 @@ def test_pipelined_tile_kernel_is_bit_identical_to_the_64x64_shape_over_repeated
     os.environ["RWKV_TILE_KSPLIT"] = "0"
     res = {}
     try:
-        for shape in (4, 12, 14):
+        for shape in (4, 12):
             os.environ["RWKV_TILE_SHAPE"] = str(shape)
             eng = engine(st, (2, 1), 4, 1024, prec=rt.Precision.Fp32)
             res[shape] = []
@@ -196,7 +196,7 @@ def test_pipelined_tile_kernel_is_bit_identical_to_the_64x64_shape_over_repeated
     finally:
         os.environ.pop("RWKV_TILE_SHAPE", None)
         os.environ.pop("RWKV_TILE_KSPLIT", None)
-    for shape in (12, 14):
+    for shape in (12,):
         for rep, (lg, stt) in enumerate(res[shape]):
             assert np.array_equal(lg, res[4][0][0]) and np.array_equal(stt, res[4][0][1]), f"Precision::Fp32: shape {shape} differs from the 64x64 shape, run {rep}"
 
