@@ -166,33 +166,47 @@ def bind_to_gpu_numa_node(gpu: int, n_gpus: int) -> dict:
 
 def shared_synth_st(R, name: str, job):
     """The synthetic checkpoint ONCE PER NODE: local rank 0 generates the `.st` image and leaves it in /dev/shm, the other ranks map it
-    (8 x 6 GB of numpy synthesis, and 8 private copies of the file image, become one).  Single-rank runs synthesise in place."""
+    (8 x 6 GB of numpy synthesis, and 8 private copies of the file image, become one).  Single-rank runs synthesise in place.
+    The file is created exclusively under an unpredictable name (O_CREAT | O_EXCL | O_NOFOLLOW, mode 0600: nothing pre-planted in /dev/shm is
+    followed or overwritten) and the name travels to the node's other ranks with the gather that doubles as the barrier behind the write; the
+    decision to fall back is taken per NODE (its leader's record), and the leader unlinks the file in a `finally`, whatever a peer does."""
     if job.world == 1:
         return R.synth_st(name, fast=True)
-    path = f"/dev/shm/rwkv_bench_{name}_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}.st"
-    ok, mine = True, None
-    if job.local_rank_env == 0:
+    leader = job.local_rank_env == 0
+    path, mine = None, None
+    if leader:
         mine = R.synth_st(name, fast=True)
+        cand = f"/dev/shm/rwkv_bench_{name}_{os.getuid()}_{os.urandom(8).hex()}.st"
         try:
-            with open(path + ".tmp", "wb") as f:
-                f.write(memoryview(mine[0]))
-            os.replace(path + ".tmp", path)
-        except OSError:                                              # /dev/shm too small (a container's default is 64 MB) or absent
-            ok = False
-            for q in (path + ".tmp", path):
+            fd = os.open(cand, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+            try:
+                with open(fd, "wb", closefd=True) as f:
+                    f.write(memoryview(mine[0]))
+                path = cand
+            except OSError:                                          # /dev/shm too small (a container's default is 64 MB)
                 try:
-                    os.unlink(q)
+                    os.unlink(cand)
                 except OSError:
                     pass
-    ok = all(job.gather_objects(ok))                                 # (doubles as the barrier behind the write)
-    if not ok:                                                       # every rank synthesises its own copy, as before round 5
+        except OSError:                                              # /dev/shm absent / not writable
+            path = None
+    recs = job.gather_objects({"rank": job.rank, "local_rank": job.local_rank_env, "path": path})     # (doubles as the barrier behind the write)
+    node_leader = job.rank - job.local_rank_env                      # ranks of a node are contiguous under torch.distributed.run and under spawn_ranks
+    path = next((r["path"] for r in recs if r["rank"] == node_leader), None)
+    if path is None:                                                 # this node synthesises per rank, as before round 5
+        job.host_barrier()
         return mine if mine is not None else R.synth_st(name, fast=True)
     del mine
-    img = np.memmap(path, dtype=np.uint8, mode="r")
-    tensors = R.st_deserialize(img)
-    job.host_barrier()
-    if job.local_rank_env == 0:
-        os.unlink(path)                                              # the mappings keep the pages; nothing is left behind
+    try:
+        img = np.memmap(path, dtype=np.uint8, mode="r")
+        tensors = R.st_deserialize(img)
+    finally:
+        job.host_barrier()
+        if leader:
+            try:
+                os.unlink(path)                                      # the mappings keep the pages; nothing is left behind
+            except OSError:
+                pass
     return img, tensors
 
 

@@ -62,25 +62,72 @@ static inline __m256 round_f16(__m256 x) {
     x = _mm256_min_ps(_mm256_max_ps(x, _mm256_set1_ps(-65504.0f)), _mm256_set1_ps(65504.0f));
     return _mm256_cvtph_ps(_mm256_cvtps_ph(x, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
 }
+/* Round 6: weight-reusing batched form.  Two rows at a time, K in panels of GEMM_KP: the panel of both rows is converted fp16 -> fp32 ONCE into
+ * an L1-resident buffer and multiplied against all B slots (four slots per pass: 8 accumulators + 2 weight + 4 operand vectors = 14 of the 16
+ * AVX2 registers; 6 loads per 8 FMAs), so a weight is read from memory once and converted once per step whatever the batch.  (Until round 5
+ * every group of 8 slots re-read and re-converted the row, one load per FMA: 27 GB/s of weights at 32 slots on 16 cores.)  The arithmetic of
+ * one (row, slot) dot product is unchanged — eight lane-wise partial sums over k in k order, then the same horizontal sum — so every result
+ * is bit-identical to the old loop nest (tests/test_oracle.py holds the backend against the numpy restatement either way). */
+#define GEMM_KP 1024
+static inline float hsum8(__m256 v) {
+    __m128 s = _mm_add_ps(_mm256_castps256_ps128(v), _mm256_extractf128_ps(v, 1));
+    s = _mm_add_ps(s, _mm_movehl_ps(s, s));
+    s = _mm_add_ss(s, _mm_shuffle_ps(s, s, 1));
+    return _mm_cvtss_f32(s);
+}
 static void gemm_f16(const uint16_t *W, long rows, long K, const float *X, long ldx, float *Y, long ldy, int B, int cls) {
+    if (B > 64) {                                                      /* (the carried partial sums below are sized for 64 slots) */
+        for (int b = 0; b < B; b += 64) gemm_f16(W, rows, K, X + (long)b * ldx, ldx, Y + (long)b * ldy, ldy, B - b < 64 ? B - b : 64, cls);
+        return;
+    }
     const int rnd = (g_f16_mask >> cls) & 1;
+    const long npair = (rows + 1) / 2;
 #pragma omp for schedule(static)
-    for (long r = 0; r < rows; ++r) {
-        const uint16_t *w = W + r * K;
-        for (int b0 = 0; b0 < B; b0 += 8) {
-            const int nb = B - b0 < 8 ? B - b0 : 8;
-            __m256 acc[8];
-            for (int i = 0; i < 8; ++i) acc[i] = _mm256_setzero_ps();
-            for (long k = 0; k < K; k += 8) {
-                const __m256 wv = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(w + k)));
-                if (rnd) for (int i = 0; i < nb; ++i) acc[i] = _mm256_fmadd_ps(wv, round_f16(_mm256_loadu_ps(X + (long)(b0 + i) * ldx + k)), acc[i]);
-                else for (int i = 0; i < nb; ++i) acc[i] = _mm256_fmadd_ps(wv, _mm256_loadu_ps(X + (long)(b0 + i) * ldx + k), acc[i]);
-            }
-            for (int i = 0; i < nb; ++i) {
-                __m128 s = _mm_add_ps(_mm256_castps256_ps128(acc[i]), _mm256_extractf128_ps(acc[i], 1));
-                s = _mm_add_ps(s, _mm_movehl_ps(s, s));
-                s = _mm_add_ss(s, _mm_shuffle_ps(s, s, 1));
-                Y[(long)(b0 + i) * ldy + r] = _mm_cvtss_f32(s);
+    for (long p = 0; p < npair; ++p) {
+        const long r0 = 2 * p;
+        const int nr = rows - r0 < 2 ? 1 : 2;
+        float wf[2][GEMM_KP] __attribute__((aligned(32)));
+        __m256 accb[2][64];                                            /* lane-wise partial sums of (row, slot), carried across the K panels; B <= 64 */
+        for (long k0 = 0; k0 < K; k0 += GEMM_KP) {
+            const long kn = K - k0 < GEMM_KP ? K - k0 : GEMM_KP;
+            for (int i = 0; i < nr; ++i)
+                for (long k = 0; k < kn; k += 8)
+                    _mm256_store_ps(&wf[i][k], _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(W + (r0 + i) * K + k0 + k))));
+            if (nr == 1) for (long k = 0; k < kn; k += 8) _mm256_store_ps(&wf[1][k], _mm256_setzero_ps());
+            for (int b0 = 0; b0 < B; b0 += 4) {
+                const int nb = B - b0 < 4 ? B - b0 : 4;
+                __m256 a00, a01, a02, a03, a10, a11, a12, a13;
+                if (k0 == 0) { a00 = a01 = a02 = a03 = a10 = a11 = a12 = a13 = _mm256_setzero_ps(); }
+                else { a00 = accb[0][b0]; a01 = accb[0][b0 + 1]; a02 = accb[0][b0 + 2]; a03 = accb[0][b0 + 3];
+                       a10 = accb[1][b0]; a11 = accb[1][b0 + 1]; a12 = accb[1][b0 + 2]; a13 = accb[1][b0 + 3]; }
+                const float *x0 = X + (long)b0 * ldx + k0, *x1 = X + (long)(b0 + (nb > 1 ? 1 : 0)) * ldx + k0;      /* (slots past B re-read a valid one; their sums are dropped) */
+                const float *x2 = X + (long)(b0 + (nb > 2 ? 2 : 0)) * ldx + k0, *x3 = X + (long)(b0 + (nb > 3 ? 3 : 0)) * ldx + k0;
+                if (!rnd) {
+                    for (long k = 0; k < kn; k += 8) {
+                        const __m256 w0 = _mm256_load_ps(&wf[0][k]), w1 = _mm256_load_ps(&wf[1][k]);
+                        const __m256 v0 = _mm256_loadu_ps(x0 + k), v1 = _mm256_loadu_ps(x1 + k), v2 = _mm256_loadu_ps(x2 + k), v3 = _mm256_loadu_ps(x3 + k);
+                        a00 = _mm256_fmadd_ps(w0, v0, a00); a01 = _mm256_fmadd_ps(w0, v1, a01); a02 = _mm256_fmadd_ps(w0, v2, a02); a03 = _mm256_fmadd_ps(w0, v3, a03);
+                        a10 = _mm256_fmadd_ps(w1, v0, a10); a11 = _mm256_fmadd_ps(w1, v1, a11); a12 = _mm256_fmadd_ps(w1, v2, a12); a13 = _mm256_fmadd_ps(w1, v3, a13);
+                    }
+                } else {
+                    for (long k = 0; k < kn; k += 8) {
+                        const __m256 w0 = _mm256_load_ps(&wf[0][k]), w1 = _mm256_load_ps(&wf[1][k]);
+                        const __m256 v0 = round_f16(_mm256_loadu_ps(x0 + k)), v1 = round_f16(_mm256_loadu_ps(x1 + k));
+                        const __m256 v2 = round_f16(_mm256_loadu_ps(x2 + k)), v3 = round_f16(_mm256_loadu_ps(x3 + k));
+                        a00 = _mm256_fmadd_ps(w0, v0, a00); a01 = _mm256_fmadd_ps(w0, v1, a01); a02 = _mm256_fmadd_ps(w0, v2, a02); a03 = _mm256_fmadd_ps(w0, v3, a03);
+                        a10 = _mm256_fmadd_ps(w1, v0, a10); a11 = _mm256_fmadd_ps(w1, v1, a11); a12 = _mm256_fmadd_ps(w1, v2, a12); a13 = _mm256_fmadd_ps(w1, v3, a13);
+                    }
+                }
+                if (k0 + kn < K) {
+                    accb[0][b0] = a00; accb[0][b0 + 1] = a01; accb[0][b0 + 2] = a02; accb[0][b0 + 3] = a03;
+                    accb[1][b0] = a10; accb[1][b0 + 1] = a11; accb[1][b0 + 2] = a12; accb[1][b0 + 3] = a13;
+                } else {
+                    const __m256 r0v[4] = {a00, a01, a02, a03}, r1v[4] = {a10, a11, a12, a13};
+                    for (int i = 0; i < nb; ++i) {
+                        Y[(long)(b0 + i) * ldy + r0] = hsum8(r0v[i]);
+                        if (nr == 2) Y[(long)(b0 + i) * ldy + r0 + 1] = hsum8(r1v[i]);
+                    }
+                }
             }
         }
     }

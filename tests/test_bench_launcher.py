@@ -76,12 +76,12 @@ from oracle import rwkv_ref as R
 args = bench.parse_args(["--gpus", "2"])
 job = bench.Job(args)
 if os.environ.get("BREAK_SHM") and job.local_rank_env == 0:
-    real_open = open
+    real_open = os.open
     def broken(path, *a, **k):
         if str(path).startswith("/dev/shm/"):
             raise OSError(28, "No space left on device")
         return real_open(path, *a, **k)
-    bench.open = broken
+    bench.os.open = broken
 img, tens = bench.shared_synth_st(R, "v6-tiny", job)
 own, _ = R.synth_st("v6-tiny", fast=True)
 info = R.model_info(tens)
@@ -102,6 +102,56 @@ job.close()
         assert recs[0]["sha"] == recs[1]["sha"] and all(r["same_as_own"] and r["layers"] > 0 for r in recs)
         assert [r["mapped"] for r in recs] == ([False, False] if broken else [True, True])
         assert not [f for f in os.listdir("/dev/shm") if f.startswith("rwkv_bench_v6-tiny")]
+
+
+def test_world_size_8_the_rank_count_the_metric_names():
+    """BASELINE's metric is quoted at 1 / 2 / 4 / 8 GPUs; no 8-GPU node has been available to any round, so the N = 8 path is exercised here with the
+    stand-in workload: eight ranks spawned by the bench itself on a faked two-node topology (GPUs 0-3 on node 0, 4-7 on node 1), every rank bound
+    to its node's CPUs, one JSON line from rank 0 priced at the slowest rank, every leg of the metric aggregated over eight ranks.  The shared
+    checkpoint at eight ranks is the next test."""
+    cpus = sorted(os.sched_getaffinity(0))
+    half = max(1, len(cpus) // 2)
+    fake = {str(g): [g // 4, (cpus[:half] if g < 4 else cpus[half:] or cpus[:half])] for g in range(8)}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "4", "--selftest-dist"], env=clean_env(BENCH_FAKE_NUMA=json.dumps(fake)),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 8 and len(d["per_rank_tokens_per_s"]) == 8 and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 * min(d["per_rank_tokens_per_s"])) <= 1e-6 * d["value"]            # eight ranks' tokens over the slowest rank's time
+    numa = d["per_rank_numa"]
+    assert [n["rank"] for n in numa] == list(range(8)) and [n["gpu"] for n in numa] == list(range(8))
+    assert [n["numa_node"] for n in numa] == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert all(set(n["affinity"]) <= set(fake[str(n["gpu"])][1]) for n in numa)
+    e = d["embeddings"]
+    assert len(e["per_rank_embeddings_per_s"]) == 8 and e["docs"] == 8 * e["docs_per_rank"]
+    for key in ("pcie_inclusive", "on_device_sampling"):
+        assert len(d[key]["per_rank"]) == 8
+
+
+def test_the_shared_checkpoint_at_eight_ranks(tmp_path):
+    """`shared_synth_st` at the rank count of a full node: one synthesis, eight mappings of the same bytes, nothing left in /dev/shm."""
+    script = tmp_path / "ranks8.py"
+    script.write_text(f"""
+import hashlib, json, os, sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np
+import bench
+from oracle import rwkv_ref as R
+job = bench.Job(bench.parse_args(["--gpus", "8"]))
+img, tens = bench.shared_synth_st(R, "v6-tiny", job)
+print(json.dumps({{"rank": job.rank, "sha": hashlib.sha256(bytes(memoryview(np.ascontiguousarray(img)))).hexdigest(), "mapped": isinstance(img, np.memmap)}}), flush=True)
+job.close()
+""")
+    procs = []
+    for r in range(8):
+        env = clean_env(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="8", LOCAL_WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="29647")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
+    recs = sorted((last_json(o[0]) for o in outs), key=lambda d: d["rank"])
+    assert len({r["sha"] for r in recs}) == 1 and all(r["mapped"] for r in recs)
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("rwkv_bench_v6-tiny")]
 
 
 def test_under_torch_distributed_run_as_the_driver_launches_it():
