@@ -1592,8 +1592,13 @@ void rwkv_engine::infer(const rwkv_slot_input *in, rwkv_slot_output *out) {
     // A step that emits no row (state-only requests: RWKV_OPTION_NONE, or `Last` slots that still have tokens pending) hands nothing back
     // but `n_consumed`, which the plan already knows: it is NOT waited for.  The next call's host work (plan, metadata staging, launch)
     // overlaps this step on the device; every call that reads device data (`state.back / read / write`, a step with rows) is ordered
-    // behind it on the stream and waits as before.  A device fault surfaces at that next wait.
-    if (pl.n_out == 0) return;
+    // behind it on the stream and waits as before.  A LAUNCH error (bad configuration, a sticky device fault from an earlier step) is reported
+    // by this call: the error state is polled after the enqueue; an asynchronous fault of THIS step surfaces at the next wait, and the slot states
+    // it touched are undefined from then on (the caller has already advanced by n_consumed: include/rwkv_abi.h).
+    if (pl.n_out == 0) {
+        HIP_CHECK(hipPeekAtLastError());
+        return;
+    }
     HIP_CHECK(hipMemcpyAsync(logits_host, logits, (size_t)pl.n_out * V * 4, hipMemcpyDeviceToHost, s_main));
     HIP_CHECK(hipStreamSynchronize(s_main));
     for (const Seg &g : segs) std::memcpy(g.dst, logits_host + g.row0 * V, g.rows * V * 4);

@@ -140,7 +140,9 @@ typedef struct rwkv_slot_output {  /* RnnOutputBatch, run.rs:1146-1155 */
  * caller's buffers.  A call that emits NO row (state-only slots, or `Last` slots whose tokens are not exhausted yet) returns as soon as
  * the step is queued: `n_consumed` is final, the device runs behind, and everything that reads device data afterwards (a later
  * rwkv_infer with rows, rwkv_state_back / _read / _write / _back_layer[_async]) is ordered behind it — host work between two steps of a
- * long prefill overlaps the device.  The `tokens` arrays may be reused as soon as the call returns (they are staged on return). */
+ * long prefill overlaps the device.  The `tokens` arrays may be reused as soon as the call returns (they are staged on return).  Errors of such a
+ * call: a launch error is returned by the call itself; an asynchronous device fault of the queued step is returned by the NEXT call that waits
+ * (a step with rows, rwkv_state_back / _read / _sync), and the states of the slots the step touched are undefined from then on. */
 rwkv_status rwkv_infer(rwkv_engine *e, const rwkv_slot_input *in, rwkv_slot_output *out);
 
 /* Pinned host memory for the `logits` buffers of rwkv_infer (the `TensorCpu<f32>` outputs of run.rs:1146-1155 are read back

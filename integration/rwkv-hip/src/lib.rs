@@ -67,17 +67,25 @@ impl Drop for DeviceState { fn drop(&mut self) { unsafe { sys::rwkv_dstate_free(
 
 /// pinned host block for the logits of one `infer` call (rwkv_host_alloc): rows land here in one device-to-host copy
 #[derive(Debug)]
-pub struct PinnedLogits { ptr: *mut f32, floats: usize }
+pub struct PinnedLogits { ptr: *mut f32, floats: usize, in_flight: usize }
 unsafe impl Send for PinnedLogits {}
 impl PinnedLogits {
     pub fn new(floats: usize) -> Result<Self> {
         let mut p: *mut c_void = ptr::null_mut();
         check(unsafe { sys::rwkv_host_alloc(floats * 4, &mut p) })?;
-        Ok(Self { ptr: p as *mut f32, floats })
+        Ok(Self { ptr: p as *mut f32, floats, in_flight: 0 })
     }
-    pub fn as_slice(&self) -> &[f32] { unsafe { std::slice::from_raw_parts(self.ptr, self.floats) } }
+    /// Panics while a read-back into the block is in flight: only reachable when a `PendingRows` guard was leaked (`std::mem::forget`) — every
+    /// other path holds the block's `&mut` borrow until the copy stream has been waited for.
+    pub fn as_slice(&self) -> &[f32] {
+        assert!(self.in_flight == 0, "PinnedLogits read while an asynchronous read-back is in flight (a PendingRows guard was leaked)");
+        unsafe { std::slice::from_raw_parts(self.ptr, self.floats) }
+    }
 }
-impl Drop for PinnedLogits { fn drop(&mut self) { unsafe { sys::rwkv_host_free(self.ptr as *mut c_void) } } }
+impl Drop for PinnedLogits {
+    /// A block with a read-back still accounted in flight (leaked guard) is LEAKED, not freed: the DMA may still be writing it.
+    fn drop(&mut self) { if self.in_flight == 0 { unsafe { sys::rwkv_host_free(self.ptr as *mut c_void) } } }
+}
 
 /// one slot of an `infer` call: `tokens` is drained by what the call consumed (RnnInputBatch, run.rs:1128)
 #[derive(Default, Clone, Debug)]
@@ -207,7 +215,9 @@ impl Engine {
 
 /// Read-backs in flight into one pinned block (`Engine::state_back_layer_async`).  Holds the block's mutable borrow until the copy
 /// stream has been waited for: `sync()` gives the block back; `Drop` waits as well, so no path — early return, `?`, panic unwinding —
-/// lets the block be read or freed under the DMA.
+/// lets the block be read or freed under the DMA.  `std::mem::forget(guard)` is the one safe-code path that ends the borrow without the wait
+/// (leaking a guard is safe Rust): `PinnedLogits` therefore counts the read-backs in flight into it (`in_flight`) and its own `Drop` and
+/// `as_slice` wait on the engine's copy stream while the count is non-zero.
 pub struct PendingRows<'a> {
     rt: &'a Engine,
     dst: &'a mut PinnedLogits,
@@ -224,21 +234,26 @@ impl<'a> PendingRows<'a> {
         }
         check(unsafe { sys::rwkv_state_back_layer_async(self.rt.raw, slot as i32, layer as i32, self.dst.ptr.add(at)) })?;
         self.ranges.push((at, end));
+        self.dst.in_flight += 1;
         Ok(())
     }
     /// one more slot's rows into the same block (a disjoint range), still under the one borrow
     pub fn also(&mut self, slot: usize, layer: usize, at: usize) -> Result<()> { self.issue(slot, layer, at) }
     /// wait for the copies; the block is the caller's again
+    /// On `Err` the copies may NOT have completed: the guard is dropped at the end of this call with `waited` still false, so its `Drop` waits once
+    /// more before the borrow ends, and the block is not handed back.
     pub fn sync(mut self) -> Result<&'a mut PinnedLogits> {
-        let r = self.rt.state_sync();
+        self.rt.state_sync()?;
         self.waited = true;
+        self.dst.in_flight -= self.ranges.len();
         // SAFETY: `self` is consumed and its Drop (below) does nothing once `waited`; the reference is re-borrowed for the original lifetime
         let dst: *mut PinnedLogits = &mut *self.dst;                 // a reborrow, not a move out of a `Drop` type
-        r.map(|_| unsafe { &mut *dst })
+        Ok(unsafe { &mut *dst })
     }
 }
 impl Drop for PendingRows<'_> {
-    fn drop(&mut self) { if !self.waited { let _ = self.rt.state_sync(); } }
+    /// waits; only a SUCCESSFUL wait releases the block's in-flight count (after a failed one the block stays unreadable and is leaked on drop)
+    fn drop(&mut self) { if !self.waited && self.rt.state_sync().is_ok() { self.dst.in_flight -= self.ranges.len(); } }
 }
 
 /// `Tokenizer` (lib.rs:375; run.rs:157-168, 856; sampler/bnf.rs:14-27)
