@@ -851,7 +851,8 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
         if (s.partial) {
             // smallest split that gives >= 1.5 blocks per CU (one strip per block), else the largest valid one <= 8
             int best = 0;
-            for (int b = 1; b <= 8; ++b) {
+            static const int ksb_max = [] { const char *e = std::getenv("RWKV_KSB_MAX"); return e && *e ? std::atoi(e) : 8; }();   // dev experiment
+            for (int b = 1; b <= ksb_max; ++b) {
                 if (!valid(b)) continue;
                 best = b;
                 if ((long)strips * b >= 384) break;
@@ -1549,6 +1550,8 @@ void rwkv_engine::infer_sample(const rwkv_slot_input *in, const rwkv_sample_para
 
 void rwkv_engine::infer(const rwkv_slot_input *in, rwkv_slot_output *out) {
     HIP_CHECK(hipSetDevice(device));
+    (void)hipGetLastError();                                   // start clean: the poll behind a row-less step must only see THIS call's errors
+                                                               // (a handled, non-sticky failure of an earlier call — a probe — stays recorded otherwise)
     for (int b = 0; b < max_batch; ++b) {
         out[b].n_rows = 0;
         out[b].n_consumed = 0;

@@ -23,16 +23,16 @@ run_stats () {   # name, then the command
   echo "stats $name rc=$?"
 }
 BENCH="python $R/bench.py --decode-only --no-cpu-baseline --sweep= --verify-steps 0 --steps 50 --warmup 5"
-# the modes that hold north_star's 1e-3: Precision::Fp32, and Precision::Fp16 with the sensitive launches promoted
-# (ONLY_MODES=1: just these three runs)
-run_stats v6-3b_int8_b32_fp32 $BENCH --workload v6-3b --quant int8 --batch 32 --precision fp32
-RWKV_PROMOTE=1 run_stats v6-3b_int8_b32_promote1 $BENCH --workload v6-3b --quant int8 --batch 32
-RWKV_PROMOTE=7 run_stats v7-2.9b_nf4_b32_promote7 $BENCH --workload v7-2.9b --quant nf4 --batch 32
-if [ -n "${ONLY_MODES:-}" ]; then ls $P; exit 0; fi
+# every engine in the library's default precision (ABI 7: Precision::Fp16 = f16 operands, the error-carrying launches hi + lo); the other two modes of the
+# headline configuration and the raw mode of config #4 beside them
 run_stats v6-3b_int8_b32 $BENCH --workload v6-3b --quant int8 --batch 32
+run_stats v6-3b_int8_b32_fp16raw $BENCH --workload v6-3b --quant int8 --batch 32 --precision fp16raw
+run_stats v6-3b_int8_b32_fp32 $BENCH --workload v6-3b --quant int8 --batch 32 --precision fp32
+if [ -n "${ONLY_MODES:-}" ]; then ls $P; exit 0; fi
 run_stats v6-3b_int8_b1 $BENCH --workload v6-3b --quant int8 --batch 1
 run_stats v6-7b_fp16_b8 $BENCH --workload v6-7b --quant none --batch 8
 run_stats v7-2.9b_nf4_b32 $BENCH --workload v7-2.9b --quant nf4 --batch 32
+run_stats v7-2.9b_nf4_b32_fp16raw $BENCH --workload v7-2.9b --quant nf4 --batch 32 --precision fp16raw
 run_stats v6-3b_fp16_b32 $BENCH --workload v6-3b --quant none --batch 32
 run_stats prefill_v6-3b_int8_32x256 python $R/scripts/prefill_probe.py v6-3b 1 32 256 2048
 DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 run_stats prefill_v6-3b_int8_chunk256 python $R/scripts/prefill_probe.py v6-3b 1 32 256 256
@@ -41,7 +41,7 @@ DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 run_stats prefill_v7-2.9b_nf4_chunk256 python $
 for name in decode_v6-3b_int8_b32 prefill_v6-3b_int8; do
   rm -rf $O/pmc_$name
   if [ $name = decode_v6-3b_int8_b32 ]; then CMD="$BENCH --workload v6-3b --quant int8 --batch 32 --steps 12"; else CMD="python $R/scripts/prefill_probe.py v6-3b 1 32 256 2048"; fi
-  timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_$name -o p -- $CMD > $O/pmc_$name.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_$name -o p -- $CMD > $O/pmc_$name.log 2>&1
   python - $O/pmc_$name $P/${TAG}_pmc_mfma_$name.txt <<'PY'
 import csv, glob, collections, sys
 src, dst = sys.argv[1], sys.argv[2]
@@ -50,12 +50,19 @@ for f in glob.glob(src + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].replace("void rwkv::", "").replace("rwkv::", "")[:64]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        if r["Counter_Name"] == "SQ_BUSY_CYCLES": n[k] += 1
+        if r["Counter_Name"] == "SQ_WAVE_CYCLES": n[k] += 1
+SIMDS = 256 * 4
 with open(dst, "w") as out:
-    out.write("kernel | launches | MFMA busy / SQ busy (matrix-pipe utilisation; SQ_BUSY is per-SE, so the ratio is relative across kernels) | wave cycles parked (SQ_WAIT_ANY / SQ_WAVE_CYCLES)\n")
-    for k, c in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0))[:14]:
-        b = c.get("SQ_BUSY_CYCLES", 0) or 1; w = c.get("SQ_WAVE_CYCLES", 0) or 1
-        out.write(f"{k} | {n[k]} | mfma_busy={c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.4g} sq_busy={b:.4g} ratio={c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / b:.3f} | parked={c.get('SQ_WAIT_ANY', 0) / w:.3f} active={c.get('SQ_ACTIVE_INST_ANY', 0) / w:.3f}\n")
+    out.write("# MFMA utilisation AGAINST THE CHIP'S PEAK (round 6): SQ_VALU_MFMA_BUSY_CYCLES (matrix-pipe busy cycles, summed over the SIMDs) / (GRBM_GUI_ACTIVE (cycles the launch "
+              "kept the GPU busy, at whatever clock it ran) x 1024 SIMDs).  1.0 = every SIMD's matrix pipe busy for the whole launch = the dense f16 peak.\n"
+              "# (GRBM_GUI_ACTIVE is reported once per XCD by this rocprofv3: the sum over a launch's records is divided by 8 when it exceeds 4x the per-record value; "
+              "the per-kernel FLOP / time fractions of the roofline table are the cross-check.)\n")
+    out.write("kernel | launches | mfma_busy_cycles | gui_active_cycles (per launch) | MFMA utilisation of the chip peak | wave cycles parked (SQ_WAIT_ANY / SQ_WAVE_CYCLES) | issuing (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES)\n")
+    for k, c in sorted(acc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))[:16]:
+        w = c.get("SQ_WAVE_CYCLES", 0) or 1
+        gui = c.get("GRBM_GUI_ACTIVE", 0)
+        util = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui * SIMDS) if gui else float("nan")
+        out.write(f"{k} | {n[k]} | {c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.4g} | {gui / max(1, n[k]):.4g} | {util:.4f} | parked={c.get('SQ_WAIT_ANY', 0) / w:.3f} | active={c.get('SQ_ACTIVE_INST_ANY', 0) / w:.3f}\n")
 PY
   echo "pmc $name done"
 done

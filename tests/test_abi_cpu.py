@@ -313,8 +313,8 @@ def test_patched_workspace_names_only_items_the_wrapper_exports(tmp_path):
 def test_mutated_inputs_never_abort(built_lib, tmp_path):
     """"Nothing aborts" (include/rwkv_abi.h): tests/cpp/fuzz_cpu_entry_points.cpp throws mutated safetensors headers, truncated files,
     mutated vocabularies, random byte strings / token ids / chunk plans at the entry points that run on a CPU; the process must come
-    back with statuses only.  (scripts/asan_fuzz.sh runs the same driver, and the C++ host tests, against an AddressSanitizer + UBSan
-    build of the library's host code: 100,000 iterations clean at the time of writing.)"""
+    back with statuses only.  (The sanitizer script under scripts/ — CPU only, see scripts/README.md — runs the same driver, and the C++ host
+    tests, against an instrumented build of the library's host code: 100,000 iterations clean at the time of writing.)"""
     import subprocess
     models = []
     for name in ("v5-tiny", "v6-tiny", "v7-tiny"):
