@@ -851,8 +851,9 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
         if (s.partial) {
             // smallest split that gives >= 1.5 blocks per CU (one strip per block), else the largest valid one <= 8
             int best = 0;
-            static const int ksb_max = [] { const char *e = std::getenv("RWKV_KSB_MAX"); return e && *e ? std::atoi(e) : 8; }();   // dev experiment
-            for (int b = 1; b <= ksb_max; ++b) {
+            // (round 6: capping the split at 1 or 2 — one or two partial slabs for the next row kernel to sum instead of five — costs 5 % of a 32-slot
+            // step: 2.274 -> 2.395 / 2.385 ms, profiles/r6_exp_decode_ab.log)
+            for (int b = 1; b <= 8; ++b) {
                 if (!valid(b)) continue;
                 best = b;
                 if ((long)strips * b >= 384) break;
