@@ -2116,7 +2116,11 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
                     g.W = ps[0].W->data; g.S = ps[0].W->scales; g.fmt = fmt; g.rows = rows; g.K = K;
                     g.xhi = x.hi; g.xlo = x.lo; g.ldx = K; g.ksb = 1; g.block_begin = 0;
                     g.out_f32 = out; g.ldo = rows;
-                    Lh.total_blocks = gemm_tile_blocks(shape, rows, T);
+                    if (const char *e = std::getenv("RWKV_BENCH_KSPLIT")) {      // K copies of the tile grid writing partial slabs (linear launches)
+                        g.ksb = std::max(1, std::min(8, std::atoi(e)));
+                        g.out_f32 = pbuf; g.partial_stride = (long)T * rows;
+                    }
+                    Lh.total_blocks = gemm_tile_blocks(shape, rows, T) * g.ksb;
                     Lh.xcd_map = 1;
                     if (const char *e = std::getenv("RWKV_TILE_XCD")) { if (*e) Lh.xcd_map = std::atoi(e); }     // 2: token-tile-major bands
                     if (lds_kib) *lds_kib = (float)Lh.total_blocks;

@@ -20,7 +20,8 @@ run_stats () {   # name, then the command
   # what the profiled command itself reported: the bench's JSON line, or (prefill_probe.py) its "... prefill tok/s" lines — never an empty file
   if grep -q '"metric"' $O/prof_$name.log; then grep -h '"metric"' $O/prof_$name.log | tail -1 > $P/${TAG}_bench_line_$name.json
   else grep -h "prefill tok/s" $O/prof_$name.log > $P/${TAG}_probe_line_$name.txt; fi
-  echo "stats $name rc=$?"
+  echo "stats $name rc=$? $(wc -c < $P/${TAG}_kernel_stats_$name.csv 2>/dev/null) bytes of summary"
+  rm -rf $O/prof_$name                                     # the raw traces are hundreds of MB; gpurun_out/ is copied back only below 64 MiB
 }
 BENCH="python $R/bench.py --decode-only --no-cpu-baseline --sweep= --verify-steps 0 --steps 50 --warmup 5"
 # every engine in the library's default precision (ABI 7: Precision::Fp16 = f16 operands, the error-carrying launches hi + lo); the other two modes of the
@@ -51,22 +52,24 @@ for f in glob.glob(src + "/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].replace("void rwkv::", "").replace("rwkv::", "")[:64]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "SQ_WAVE_CYCLES": n[k] += 1
-SIMDS = 256 * 4
+SIMDS, XCDS = 256 * 4, 8
 with open(dst, "w") as out:
-    out.write("# MFMA utilisation AGAINST THE CHIP'S PEAK (round 6): SQ_VALU_MFMA_BUSY_CYCLES (matrix-pipe busy cycles, summed over the SIMDs) / (GRBM_GUI_ACTIVE (cycles the launch "
-              "kept the GPU busy, at whatever clock it ran) x 1024 SIMDs).  1.0 = every SIMD's matrix pipe busy for the whole launch = the dense f16 peak.\n"
-              "# (GRBM_GUI_ACTIVE is reported once per XCD by this rocprofv3: the sum over a launch's records is divided by 8 when it exceeds 4x the per-record value; "
-              "the per-kernel FLOP / time fractions of the roofline table are the cross-check.)\n")
-    out.write("kernel | launches | mfma_busy_cycles | gui_active_cycles (per launch) | MFMA utilisation of the chip peak | wave cycles parked (SQ_WAIT_ANY / SQ_WAVE_CYCLES) | issuing (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES)\n")
+    out.write("# MFMA utilisation AGAINST THE CHIP'S PEAK (round 6): SQ_VALU_MFMA_BUSY_CYCLES (matrix-pipe busy cycles, summed over the SIMDs) / (cycles the launch kept the GPU busy x 1024 SIMDs).\n"
+              "# 1.0 = every SIMD's matrix pipe busy for the whole launch = the dense f16 peak at whatever clock the launch ran.  Busy cycles of the launch = GRBM_GUI_ACTIVE / 8: this rocprofv3\n"
+              "# reports the counter once per XCD and the CSV sums the eight (a 150 us launch reads 2.1e6 = 8 x 150 us x ~1.8 GHz).  Cross-check: the pipelined prefill kernel comes out at 0.29 here\n"
+              "# and at 0.26-0.31 as FLOP / time / 2.5 PFLOP/s in the roofline table.\n")
+    out.write("kernel | launches | mfma_busy_cycles (all launches) | GPU-busy cycles per launch | MFMA utilisation of the chip peak | wave cycles parked (SQ_WAIT_ANY / SQ_WAVE_CYCLES) | issuing (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES)\n")
     for k, c in sorted(acc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))[:16]:
         w = c.get("SQ_WAVE_CYCLES", 0) or 1
-        gui = c.get("GRBM_GUI_ACTIVE", 0)
+        gui = c.get("GRBM_GUI_ACTIVE", 0) / XCDS
         util = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui * SIMDS) if gui else float("nan")
         out.write(f"{k} | {n[k]} | {c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.4g} | {gui / max(1, n[k]):.4g} | {util:.4f} | parked={c.get('SQ_WAIT_ANY', 0) / w:.3f} | active={c.get('SQ_ACTIVE_INST_ANY', 0) / w:.3f}\n")
 PY
   echo "pmc $name done"
+  rm -rf $O/pmc_$name
 done
 cd $R
 timeout 400 python scripts/collect_pmc.py --round $TAG --batch 32 > $O/collect_pmc.log 2>&1; echo "traffic rc=$?"
 cp $O/${TAG}_pmc_traffic_v6-3b_int8_b32.json $P/ 2>/dev/null
-ls $P
+rm -rf $O/pmc_fetch $O/pmc_write
+ls -la $P; du -sh $O
