@@ -1307,6 +1307,9 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
                 m.zhi = aZ.hi; m.zlo = aZ.lo; m.ldz = C;
                 m.xx = xx; m.dx = dx; m.ldh = C; m.T = T; m.C = C; m.Dm = Dm;
                 m.mg_hi = aM.hi; m.mg_lo = aM.lo;               // scratch of the two-launch form (T x 5 Dm halves, like the unfused path's operand)
+                // fp32 partials of the K-sliced first stage: the partial-slab buffer, free between the ln_shift that summed the previous layer's
+                // Fv slabs and this layer's Wo launch (<= 16 slices x 5 x T x Dm floats of its 8 x T x C)
+                if ((long)16 * 5 * Dm <= (long)8 * C) { m.mp = P; m.ksp_max = kn.v6_ksp_max; m.ksp_blocks = kn.v6_ksp_blocks; m.ksp_min_t = kn.v6_ksp_min_t; }
                 if (att_fused) { m.lnp = ln_pro(a, lnp_xx_att); m.mu_x = w.mu[0]; }
                 launch(FAM_GEMM, [&] { launch_v6_mix(m, hilo, s_main); });
                 // LoRA matrices once, z / xx / dx in, five operands out (+ the LayerNorm prologue's row traffic on single-token steps)

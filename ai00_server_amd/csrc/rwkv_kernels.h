@@ -22,6 +22,8 @@ struct Knobs {
     int promote = -1;                // RWKV_PROMOTE (dev override; -1 = unset: the precision mode decides): bit mask of GEMM launch classes that read hi + lo
                                      // operands in the fp16 modes (1 att r/k/v(/g) + first-stage LoRAs, 2 V7 second-stage LoRAs, 4 Wo, 8 Fk / Fr, 16 Fv,
                                      // 32 head); rwkv_engine.cpp OpdClass
+    int v6_ksp_max = 16;             // RWKV_V6_KSP_MAX=1: the V6 token-shift LoRA's first stage never sliced over K (steps of 192 .. 511 rows; launch_v6_mix)
+    int v6_ksp_blocks = 160, v6_ksp_min_t = 192;   // (dev) RWKV_V6_KSP_BLOCKS / RWKV_V6_KSP_MIN_T: blocks the slicing aims for, smallest step it applies to
     static Knobs from_env();
 };
 const Knobs &knobs();                // the calling thread's current set
@@ -161,6 +163,8 @@ struct V6MixArgs {
     LnProArgs lnp;                  // lnp.x_in set: LayerNorm + shift computed in the kernel (z, xx, dx unused)
     const float *mu_x;              // with lnp: z = xx + dx * mu_x
     _Float16 *mg_hi = nullptr, *mg_lo = nullptr;   // scratch for the two-launch form (>= 512 rows): m_c tiles [5][T/32][32][Dm]
+    float *mp = nullptr;                           // fp32 partials of phase 1 sliced over K (192 .. 511 rows): [ksp][5][T][Dm]
+    int ksp = 1, ksp_min_t = 192, ksp_blocks = 160, ksp_max = 16;   // slices (set by launch_v6_mix); rule parameters (engine knobs)
 };
 bool v6_mix_supported(int T, int C, int Dm);
 bool v6_mix_wide_supported(int T, int C, int Dm);                   // steps with more than 32 rows: block = (mix, 32-token tile), all strips

@@ -491,6 +491,7 @@ Knobs Knobs::from_env() {
     k.no_dense = knob_env("RWKV_NO_DENSE", 0);
     k.tile_ksplit = knob_env("RWKV_TILE_KSPLIT", 1);
     k.promote = knob_env("RWKV_PROMOTE", -1);
+    k.v6_ksp_max = knob_env("RWKV_V6_KSP_MAX", 16); k.v6_ksp_blocks = knob_env("RWKV_V6_KSP_BLOCKS", 160); k.v6_ksp_min_t = knob_env("RWKV_V6_KSP_MIN_T", 192);
     return k;
 }
 static thread_local Knobs t_knobs;
@@ -855,7 +856,12 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
     const int t0 = tz * NT * 16;                                  // first token of this block's tile (decode form: 17..32 rows run two NT = 1 tiles)
     // DS = Dm/16 strips of W1_c (2 or 4)
     const int KT1 = C >> 5;                                       // k-tiles of W1 per strip
-    const int kst = KT1 >> 3;                                     // k-steps per wave in phase 1 (C/8/32)
+    // P1ONLY with a.ksp > 1 (round 6, steps of a few hundred rows): blockIdx.x = K slice — the (mix, token tile) pairs of such a step are fewer
+    // than the chip's CUs, and as whole-K blocks each of them pulls W1_c and its z tile (328 KB) through one CU; sliced over K, a.ksp blocks
+    // share that, write fp32 partials (a.mp) and v6_mix_apply_kernel sums them in slice order before the tanh
+    const int ksp = P1ONLY ? a.ksp : 1, kq = P1ONLY ? (int)blockIdx.x : 0;
+    const int kst = (KT1 >> 3) / ksp;                             // k-steps per wave in phase 1 (C/8/32 over the K slices)
+    const int kw0 = (kq * 8 + wave) * kst;                        // first k-tile of this wave
     f32x4 *red = (f32x4 *)smem;                                   // [8 waves][DS][NT][64]
     const int mstride = Dm + 8;                                   // halfs per token row of m_c
     _Float16 *m_hi = (_Float16 *)(smem + (size_t)8 * 4 * NT * 64 * 16);
@@ -890,7 +896,7 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             if (k0 + j < kst) {                                    // wave-uniform
-                const int kt = wave * kst + k0 + j;
+                const int kt = kw0 + k0 + j;
 #pragma unroll
                 for (int d = 0; d < DS; ++d) wt[j][d] = w1[((long)(c * DS + d) * KT1 + kt) * 64 + lane];
             }
@@ -935,7 +941,7 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             if (k0 + j < kst) {                                    // wave-uniform
-                const int kt = wave * kst + k0 + j;
+                const int kt = kw0 + k0 + j;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int tile = min((t0 >> 4) + nt, (T - 1) >> 4);
@@ -979,6 +985,13 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
         f32x4 v = red[((0 * 4 + d) * NT + nt) * 64 + lane];
         for (int w2 = 1; w2 < 8; ++w2) v += red[((w2 * 4 + d) * NT + nt) * 64 + lane];
         const int t = nt * 16 + (lane & 15);
+        if constexpr (P1ONLY) {
+            if (ksp > 1) {                                         // this K slice's partial, fp32, [slice][mix][token][Dm]
+                const long po = (((long)kq * 5 + c) * ((long)gridDim.z * NT * 16) + t0 + t) * Dm + d * 16 + (lane >> 4) * 4;
+                *(f32x4 *)(a.mp + po) = v;
+                continue;
+            }
+        }
         f16x4 hh, ll;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { _Float16 x, y; split_hilo(tanhf(v[r]), x, y); hh[r] = x; ll[r] = y; }
@@ -1086,11 +1099,38 @@ __global__ __launch_bounds__(512) void v6_mix_apply_kernel(const V6MixArgs a) {
     }
     // m_c tiles of this token tile: 5 x 32 x Dm halves, 16-byte pieces
     constexpr int PPR = Dm / 8, NP = 5 * NT * 16 * PPR;                    // pieces per token row, pieces in all
-    for (int i = tid; i < NP; i += 512) {
-        const int c = i / (NT * 16 * PPR), rem = i - c * (NT * 16 * PPR), t = rem / PPR, d8 = rem - t * PPR;
-        const long go = (((long)c * ntile + tz) * (NT * 16) + t) * Dm + d8 * 8;
-        *(u32x4 *)(m_hi + (c * NT * 16 + t) * mstride + d8 * 8) = *(const u32x4 *)(a.mg_hi + go);
-        if constexpr (HILO) *(u32x4 *)(m_lo + (c * NT * 16 + t) * mstride + d8 * 8) = *(const u32x4 *)(a.mg_lo + go);
+    const int ksp = a.ksp;
+    if (ksp > 1) {
+        // phase 1 ran sliced over K: the slices' fp32 partials are summed in slice order, then tanh.  Five slices' loads are in flight at once
+        // (a rolled loop over the slices is one L2 round trip per slice: 10.5 us for this kernel at 256 rows against 5.2 for phase 1)
+        const long Tp = (long)ntile * NT * 16, qstride = 5 * Tp * Dm;
+        for (int i = tid; i < NP; i += 512) {
+            const int c = i / (NT * 16 * PPR), rem = i - c * (NT * 16 * PPR), t = rem / PPR, d8 = rem - t * PPR;
+            const float *pp = a.mp + ((long)c * Tp + t0 + t) * Dm + d8 * 8;
+            f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
+            for (int q0 = 0; q0 < ksp; q0 += 5) {
+                f32x4 v0[5], v1[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const float *pq = pp + (long)min(q0 + j, ksp - 1) * qstride;          // clamped, not predicated: straight-line loads
+                    v0[j] = *(const f32x4 *)pq; v1[j] = *(const f32x4 *)(pq + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 5; ++j) if (q0 + j < ksp) { s0 += v0[j]; s1 += v1[j]; }
+            }
+            f16x8 hh, ll;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { _Float16 x, y; split_hilo(tanhf(e < 4 ? s0[e] : s1[e - 4]), x, y); hh[e] = x; ll[e] = y; }
+            *(f16x8 *)(m_hi + (c * NT * 16 + t) * mstride + d8 * 8) = hh;
+            if constexpr (HILO) *(f16x8 *)(m_lo + (c * NT * 16 + t) * mstride + d8 * 8) = ll;
+        }
+    } else {
+        for (int i = tid; i < NP; i += 512) {
+            const int c = i / (NT * 16 * PPR), rem = i - c * (NT * 16 * PPR), t = rem / PPR, d8 = rem - t * PPR;
+            const long go = (((long)c * ntile + tz) * (NT * 16) + t) * Dm + d8 * 8;
+            *(u32x4 *)(m_hi + (c * NT * 16 + t) * mstride + d8 * 8) = *(const u32x4 *)(a.mg_hi + go);
+            if constexpr (HILO) *(u32x4 *)(m_lo + (c * NT * 16 + t) * mstride + d8 * 8) = *(const u32x4 *)(a.mg_lo + go);
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -1143,8 +1183,24 @@ void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
     if (wide) {
         const int ntile = (a.T + 31) / 32;
         grid = dim3(std::max(1, std::min(8, 256 / (5 * ntile))), 5, ntile);   // fill the chip when the step has few token tiles
-        if (a.T >= V6_SPLIT_MIN_T && a.T % 32 == 0 && a.mg_hi && (!hilo || a.mg_lo)) {
-            grid = dim3(1, 5, ntile);
+        // Steps of 192 .. 511 rows (round 6): phase 1 sliced over K — the smallest slice count (a divisor of the k-steps per wave) that gives the
+        // launch >= 160 blocks; partials in a.mp.  V6-3B at 256 rows: one launch of 240 blocks 16.4 us -> 200 slice blocks 5.2 us + 160 apply blocks
+        // 9.0 us (rocprofv3, profiles/r6_exp_v6mix_kslices.log); at 512 rows even, at 128 rows slower: the rule's range.
+        V6MixArgs b = a;
+        b.ksp = 1;
+        if (a.mp && a.T % 32 == 0 && a.T >= a.ksp_min_t && a.T < V6_SPLIT_MIN_T) {
+            const int per_wave = (a.C >> 5) >> 3;
+            int best = 1;
+            for (int q = 1; q <= per_wave && q <= a.ksp_max; ++q) {
+                if (per_wave % q) continue;
+                best = q;
+                if (5 * ntile * q >= a.ksp_blocks) break;
+            }
+            b.ksp = best;
+        }
+        if (((a.T >= V6_SPLIT_MIN_T && a.mg_hi && (!hilo || a.mg_lo)) || b.ksp > 1) && a.T % 32 == 0) {
+            const V6MixArgs &a = b;                             // (shadows: the launches below take the slice count)
+            grid = dim3(a.ksp, 5, ntile);
             const dim3 g2((a.C / 16 + 7) / 8, ntile);
             if (a.Dm == 32) {
                 if (hilo) { hipLaunchKernelGGL((v6_mix_kernel<2, true, 2, false, true, true>), grid, block, lds, s, a); hipLaunchKernelGGL((v6_mix_apply_kernel<true, 2>), g2, block, 0, s, a); }
@@ -2240,6 +2296,9 @@ void launch_gemm_tile45(const GemmLaunch &L, int kind, int ntl, bool hilo, hipSt
 static const int kTileShapes[GEMM_TILE_SHAPES][5] = {{8, 2, 8, 128, 0}, {8, 1, 8, 128, 0}, {4, 1, 8, 128, 0}, {4, 1, 4, 128, 0}, {4, 1, 4, 256, 0}, {8, 1, 8, 256, 0},
                                                      {4, 1, 4, 256, 1}, {4, 2, 4, 128, 1}, {4, 2, 8, 128, 1}, {8, 2, 8, 128, 1}, {4, 2, 8, 128, 2}, {4, 2, 4, 128, 2},
                                                      {4, 2, 4, 128, 3}};
+// (Round 6 re-measured the 256 x 128 tile on FOUR waves — 64 rows x 128 tokens per wave, 128 accumulators in AGPRs, one block per CU, a third fewer LDS
+// and L2-port bytes per flop — in this file's plain chunked body: 537 TFLOP/s on the 7 B r/k/v/g launch against 488 for the same body on 128 x 128 and
+// 860 for the pipelined 128 x 128 kernel; round 3 had measured its pipelined form at 395-563.  profiles/r6_exp_tile_256x128_4waves.log; removed.)
 // (128 rows x 64 tokens with 8 waves, 256-k and 128-k chunks — half the operand re-reads of the 64x64 shapes on steps of a few hundred
 // rows — was built and measured in round 3: slower on every matrix but one, profiles/r3_exp_tile_128x64.log; removed.)
 int gemm_tile_blocks(int shape, int rows, int T) {
@@ -2716,8 +2775,34 @@ __global__ __launch_bounds__(256, CH == 8 ? 5 : (VER == 7 ? 2 : 3)) void wkv_chu
     if (VER == 7) { kk_p = a.k_k[cb + lane]; ka_p = a.k_a[cb + lane]; }
     if (VER == 5) wconst = a.wdec_or_decay[cb + lane];
 
+    // V6: this wave's rows of D2 and its decay constants do not depend on the chunk — requested here, behind the state, so that phase A2 finds them
+    // in registers instead of starting an L2 round trip of its own after A1 (round 6: the phase trace showed A1 -> A2 -> C each opening with one)
+    constexpr int KS6 = DD / 32, NTILE6 = WKV_CH >= 16 ? WKV_CH / 16 : 1;
+    f16x8 af[VER == 6 ? KS6 : 1];
+    float4 dec4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (not in the short-chunk form: its 96 registers per lane spill under the extra live ranges — measured 18.7 -> 22.6 us at 256 rows, where the long
+    // form went 63.9 -> 59.1 at 2048; the short form keeps its loads inside the phases)
+    constexpr bool AHEAD = CH != 8;
+    auto load_d2 = [&]() {
+        const _Float16 *d2 = a.D2 + (long)(cb + wave * 16 + (lane & 15)) * Dd + (lane >> 4) * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS6; ++ks) af[ks] = *(const f16x8 *)(d2 + ks * 32);
+        dec4 = *(const float4 *)(a.wdec_or_decay + cb + wave * 16 + (lane >> 4) * 4);
+    };
+    if (VER == 6 && AHEAD) load_d2();
+
     for (int c0 = 0; c0 < nrow; c0 += WKV_CH) {
         const int n = min(WKV_CH, nrow - c0);
+        // V6: the chunk's first-stage decay rows (td) for the MFMA of A2, requested with the chunk's other loads
+        float4 td0[VER == 6 ? NTILE6 : 1][VER == 6 ? KS6 : 1], td1[VER == 6 ? NTILE6 : 1][VER == 6 ? KS6 : 1];
+        auto load_td = [&]() {
+#pragma unroll
+            for (int tile = 0; tile < NTILE6; ++tile) {
+                const float *tdp = a.td + (long)(row0 + c0 + min(tile * 16 + (lane & 15), n - 1)) * Dd + (lane >> 4) * 8;
+#pragma unroll
+                for (int ks = 0; ks < KS6; ++ks) { td0[tile][ks] = *(const float4 *)(tdp + ks * 32); td1[tile][ks] = *(const float4 *)(tdp + ks * 32 + 4); }
+            }
+        };
         // ---- phase A: wave w prepares tokens w, w+4, ... (lane = channel).  A1: every global load of the chunk is issued
         //      back to back and parked RAW in the LDS rows (a lane only touches its own elements: no barrier);
         //      A2: a rolled loop transforms the rows in place.
@@ -2732,6 +2817,7 @@ __global__ __launch_bounds__(256, CH == 8 ? 5 : (VER == 7 ? 2 : 3)) void wkv_chu
                     if (a.layer != 0) { q5[i] = a.v_first[rb]; q6[i] = a.vg7[rb]; }
                 }
             }
+            if (VER == 6 && AHEAD) load_td();
             if (VER == 7) {
                 // V7's per-token transforms on the eight tokens of this wave AT ONCE, in the registers the loads landed in (kappa =
                 // normalised k * k_k, k <- k (1 + (a - 1) k_a), v <- v + (v_first - v) gate): eight independent L2-norm reductions
@@ -2775,22 +2861,15 @@ __global__ __launch_bounds__(256, CH == 8 ? 5 : (VER == 7 ? 2 : 3)) void wkv_chu
             // the decode kernel's four partial sums, which the oracle's tolerance covers.  (The VALU form — every lane 64 FMAs +
             // 64 converts per token over LDS broadcasts — was 4 us of a chunk's 15, profiles/r3_trace_wkv_chunk.log.)
             constexpr int KS = DD / 32;
-            const _Float16 *d2 = a.D2 + (long)(cb + wave * 16 + (lane & 15)) * Dd + (lane >> 4) * 8;
-            f16x8 af[KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) af[ks] = *(const f16x8 *)(d2 + ks * 32);
-            const float4 dec4 = *(const float4 *)(a.wdec_or_decay + cb + wave * 16 + (lane >> 4) * 4);
+            if (!AHEAD) { load_d2(); load_td(); }
 #pragma unroll
             for (int tile = 0; tile < (WKV_CH >= 16 ? WKV_CH / 16 : 1); ++tile) {
                 const int tt = tile * 16 + (lane & 15);
-                const float *tdp = a.td + (long)(row0 + c0 + min(tt, n - 1)) * Dd + (lane >> 4) * 8;
-                float4 t0[KS], t1[KS];
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) { t0[ks] = *(const float4 *)(tdp + ks * 32); t1[ks] = *(const float4 *)(tdp + ks * 32 + 4); }
                 f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const float tv[8] = {t0[ks].x, t0[ks].y, t0[ks].z, t0[ks].w, t1[ks].x, t1[ks].y, t1[ks].z, t1[ks].w};
+                    const float4 t0k = td0[tile][ks], t1k = td1[tile][ks];
+                    const float tv[8] = {t0k.x, t0k.y, t0k.z, t0k.w, t1k.x, t1k.y, t1k.z, t1k.w};
                     f16x8 bh, bl;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { _Float16 hh, ll; split_hilo(tv[e], hh, ll); bh[e] = hh; bl[e] = ll; }
@@ -2807,6 +2886,16 @@ __global__ __launch_bounds__(256, CH == 8 ? 5 : (VER == 7 ? 2 : 3)) void wkv_chu
         }
         if (VER == 5) {
             for (int tt = wave; tt < n; tt += 4) s_w[tt][lane] = wconst;
+        }
+        // phase C's gate values (thread = (token tid>>3, 8 channels)): requested here, a recurrence ahead of their use
+        float4 gpre0 = make_float4(0.f, 0.f, 0.f, 0.f), gpre1 = gpre0;
+        constexpr bool GATE_AHEAD = AHEAD;
+        if (GATE_AHEAD) {
+            const int ttc = tid >> 3;
+            if (ttc < n) {
+                const float *gp = a.g + (long)(row0 + c0 + ttc) * C + cb + (tid & 7) * 8;
+                gpre0 = *(const float4 *)gp; gpre1 = *(const float4 *)(gp + 4);
+            }
         }
         if (c0 == 0) TRACE_K(3, 2);
         __syncthreads();
@@ -2885,7 +2974,8 @@ __global__ __launch_bounds__(256, CH == 8 ? 5 : (VER == 7 ? 2 : 3)) void wkv_chu
             };
             if (tt < n) {                                         // the 8 lanes of a token take the branch together
                 const int t = row0 + c0 + tt;
-                const float4 g0 = *(const float4 *)(a.g + (long)t * C + cb + c8), g1 = *(const float4 *)(a.g + (long)t * C + cb + c8 + 4);
+                float4 g0 = gpre0, g1 = gpre1;
+                if (!GATE_AHEAD) { g0 = *(const float4 *)(a.g + (long)t * C + cb + c8); g1 = *(const float4 *)(a.g + (long)t * C + cb + c8 + 4); }
                 const float4 o0 = *(const float4 *)(&s_o[tt][c8]), o1 = *(const float4 *)(&s_o[tt][c8 + 4]);
                 float o[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
                 const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};

@@ -118,6 +118,38 @@ def test_wide_mix_split_form_on_a_1024_row_step(models):
         assert np.array_equal(res[0], res[1])
 
 
+def test_wide_mix_k_sliced_first_stage_on_a_256_row_step(models):
+    """Steps of 192 .. 511 rows (a multiple of 32) run the first stage of the V6 token-shift LoRA sliced over K (v6_mix_kernel<..., P1ONLY> with
+    a.ksp > 1, fp32 partials summed by v6_mix_apply_kernel): the oracle's logits in fp16 and in the hi/lo operand form, the same bits on a second
+    engine, and the same tolerance with the slicing turned off (RWKV_V6_KSP_MAX=1: the single-launch wide form) and forced to its maximum."""
+    tens, st = models[6]
+    B, L = 8, 32
+    ps = [[t % 1024 for t in R.synth_prompt(190 + b, L)] for b in range(B)]
+    rb = R.RwkvRefBatch(tens, 0, 0)
+    want = rb.prefill(ps, rb.init_states(B))
+
+    def run(prec):
+        eng = rt.ModelBuilder(st).build(max_batch=B, token_chunk_size=256, precision=prec)
+        inp = rt.RnnInput([rt.RnnInputBatch(list(p), rt.RnnOption.Last) for p in ps])
+        inp, outs = eng.infer(inp)
+        assert inp.num_token() == 0                                      # one 256-row step
+        got = np.stack([o[-1] for o in outs])
+        eng.close()
+        for b in range(B):
+            assert float(np.abs(got[b] - want[b]).max()) <= tol(want[b])
+        return got
+    for prec in (rt.Precision.Fp16, rt.Precision.Fp32):
+        a, b = run(prec), run(prec)
+        assert np.array_equal(a, b)
+        for k, v in (("RWKV_V6_KSP_MAX", "1"), ("RWKV_V6_KSP_BLOCKS", "100000")):
+            os.environ[k] = v
+            try:
+                c = run(prec)
+            finally:
+                os.environ.pop(k, None)
+            assert float(np.abs(c - a).max()) <= 2e-3 * max(1.0, float(np.abs(a).max()))   # another summation order of the same sums
+
+
 def test_switches_are_frozen_per_engine(models):
     """An engine keeps the choices it was created with: flipping the environment afterwards changes nothing for it (its captured
     graphs stay valid), while the next engine picks the new value up."""
