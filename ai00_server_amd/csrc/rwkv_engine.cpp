@@ -2099,12 +2099,6 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
             pbuf2 = (float *)dal((size_t)8 * T * rows * 4);
         }
         hipStream_t run_st = st;
-        int bench_sk = 0;                                              // RWKV_BENCH_SK=<blocks> (dev): the tile launch dealt out by plan_streamk
-        if (const char *e = std::getenv("RWKV_BENCH_SK")) bench_sk = std::atoi(e);
-        float *bench_out = nullptr;
-        float *sk_part_b = (float *)dal((size_t)SK_MAX_BLOCKS * SK_PART_BYTES_PER_BLOCK);
-        unsigned *sk_flag_b = (unsigned *)dal((size_t)(SK_MAX_BLOCKS + 16) * 4);
-        HIP_CHECK(hipMemset(sk_flag_b, 0, (size_t)(SK_MAX_BLOCKS + 16) * 4));
         auto run = [&](int n) {
             const bool second = run_st != st;
             for (int i = 0; i < n; ++i) {
@@ -2132,9 +2126,6 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
                     Lh.total_blocks = gemm_tile_blocks(shape, rows, T) * g.ksb;
                     Lh.xcd_map = 1;
                     if (const char *e = std::getenv("RWKV_TILE_XCD")) { if (*e) Lh.xcd_map = std::atoi(e); }     // 2: token-tile-major bands
-                    if (bench_out) g.out_f32 = bench_out;
-                    if (bench_sk > 0 && g.ksb == 1) plan_streamk(Lh, shape, bench_sk, 1, sk_part_b, sk_flag_b);   // RWKV_BENCH_SK=<blocks>: stream-K
-                    if (Lh.sk) if (const char *e = std::getenv("RWKV_BENCH_SK_DBG")) Lh.sk = std::atoi(e);
                     if (lds_kib) *lds_kib = (float)Lh.total_blocks;
                     launch_gemm_tile(Lh, shape, hilo != 0, run_st);
                     continue;
@@ -2146,27 +2137,6 @@ rwkv_status rwkv_bench_gemm(int32_t rows, int32_t K, int32_t fmt, int32_t T, int
         };
         run(nmat);
         HIP_CHECK(hipStreamSynchronize(st));
-        if (bench_sk > 0 && T >= GEMM_TILE_MIN_T) {
-            // the dealt-out launch against the classic one on the same operands: same sums in another order (fp32), no timeouts, flags back at zero
-            const size_t n = (size_t)T * rows;
-            float *o_sk = (float *)dal(n * 4), *o_cl = (float *)dal(n * 4);
-            std::vector<float> h_sk(n), h_cl(n);
-            std::vector<unsigned> hf(SK_MAX_BLOCKS + 16);
-            const int keep = bench_sk;
-            HIP_CHECK(hipMemset(o_sk, 0, n * 4)); HIP_CHECK(hipMemset(o_cl, 0, n * 4));
-            bench_out = o_sk; run(1);
-            bench_sk = 0; bench_out = o_cl; run(1);
-            bench_sk = keep; bench_out = nullptr;
-            HIP_CHECK(hipStreamSynchronize(st));
-            HIP_CHECK(hipMemcpy(h_sk.data(), o_sk, n * 4, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(h_cl.data(), o_cl, n * 4, hipMemcpyDeviceToHost));
-            HIP_CHECK(hipMemcpy(hf.data(), sk_flag_b, hf.size() * 4, hipMemcpyDeviceToHost));
-            double md = 0, mx = 0;
-            for (size_t i = 0; i < n; ++i) { md = std::max(md, (double)std::fabs(h_sk[i] - h_cl[i])); mx = std::max(mx, (double)std::fabs(h_cl[i])); }
-            unsigned left = 0;
-            for (int i = 0; i < SK_MAX_BLOCKS; ++i) left += hf[i] != 0;
-            std::fprintf(stderr, "stream-K check rows %d K %d T %d fmt %d hilo %d blocks %d: max|diff| %.3g of max|out| %.3g, timeouts %u, flags left %u\n",
-                         rows, K, T, fmt, hilo, bench_sk, md, mx, hf[SK_MAX_BLOCKS], left);
-        }
         hipEvent_t ev_fork = nullptr, ev_join = nullptr;
         if (dual) { HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); }
         hipGraph_t g = nullptr;

@@ -124,22 +124,8 @@ struct GemmLaunch {
     int tail;                       // some fp16 problem has a K range that is not a multiple of 256: predicated variant
     int total_blocks;
     int xcd_map;                    // prefill tile GEMM: XCD-banded tile numbering (rwkv_kernels.hip tg_body)
-    // stream-K over the pipelined tile kernels (round 6; plan_streamk): the launch's work units — (tile, 128-k group), problems back to back, a
-    // problem's tiles row-tile major — are dealt evenly to `total_blocks` co-resident blocks; XCD x (blocks x, x + 8, ...) owns the units
-    // [sk_band[x], sk_band[x + 1]) (whole tiles) and its block j of nbx takes the j-th nbx-th of them.  A block that stops inside a tile leaves its
-    // accumulators in sk_part[block] and raises sk_flag[block]; the block that reaches the tile's last group adds them and runs the epilogue.
-    int sk;                         // 0: one tile (or K copy of a tile) per block
-    int sk_unit_begin[GEMM_MAXP + 1];
-    int sk_band[9];
-    float *sk_part;                 // [block][acc register][256 threads] float4
-    unsigned *sk_flag;              // [block], zero between launches
     ShiftCommit commit;             // grid = total_blocks + 1 when commit.src is set
 };
-// stream-K plan of a pipelined-shape launch whose problems (p[].rows, p[].K) are filled in: units, XCD bands, total_blocks = nblocks.  False (and
-// L untouched) when the launch is too small to deal out (fewer than `min_units` groups per block).
-bool plan_streamk(GemmLaunch &L, int shape, int nblocks, int min_units, float *part, unsigned *flag);
-constexpr size_t SK_PART_BYTES_PER_BLOCK = 16 * 256 * 16;   // the 128 x 128 tile's 16 accumulator float4 per thread
-constexpr int SK_MAX_BLOCKS = 512;
 
 void gemm_variant(int T, bool hilo, int &NT, int &KSW);   // tile variant used for T rows
 size_t lnp_lds_bytes(int T, int C, bool hilo);                       // extra dynamic LDS of an LN-prologue launch

@@ -1448,109 +1448,6 @@ __device__ __forceinline__ void tg_epilogue(const GemmLaunch &L, const GemmProb 
     }
 }
 
-
-// =====================================================================================
-// Stream-K over the pipelined tile kernels (round 6).  A launch of 324 tiles on 512 block slots takes as long as a CU that got two tiles while
-// 188 CUs hold one; 1,296 tiles are 2.53 rounds and cost 3.  Here the launch's work units — (tile, 128-k weight group) — are dealt EVENLY to a
-// grid that is resident at once (GemmLaunch::sk, plan_streamk): a block walks a contiguous run of units, i.e. the tail of one tile, whole tiles,
-// the head of another.  A block that stops inside a tile (a "producer") writes its fp32 accumulators, in register order, to its own 64 KiB of
-// sk_part with write-through stores and raises its flag; the block that reaches the tile's last group (the "finisher") polls the flags of the
-// blocks before it — positions j-1, j-2, ... of its XCD band, i.e. blocks blockIdx - 8, - 16, ... on the same XCD, dispatched before it, which computed those parts FIRST (a block walks its units from the end): a
-// finisher only ever waits for lower block indices, so the scheme does not rely on the whole grid being resident — adds their partials in that
-// fixed order (deterministic bits) and runs the ordinary epilogue.  Flags are cleared by the finisher: the array is zero again when the launch
-// ends.  The hand-off protocol is the one scripts/runahead_bench.hip measured and checked word by word in round 5 (write-through sc0 sc1 stores,
-// s_waitcnt, barrier, relaxed agent-scope flag store; relaxed poll, barrier, sc1 loads); every poll is bounded, a timeout counts in sk_flag[512].
-// =====================================================================================
-struct SkSeg {
-    int on;                  // 0: the classic mapping (one tile or K copy per block, from blockIdx)
-    int again;               // not this block's first segment: LDS ring and VMEM counters are drained first
-    int tile, g0, g1;        // tile of the problem (row-tile major), weight groups [g0, g1) of its K
-    int tile_u;              // unit index of the tile's group 0
-    int x, j, nbx, U0, U1;   // XCD band, position in the band, blocks per band, the band's unit range
-};
-__device__ __forceinline__ int sk_begin_of(const SkSeg &s, int q) { return s.U0 + (int)((long)q * (s.U1 - s.U0) / s.nbx); }
-// (scalar base + 32-bit lane offset: with per-lane 64-bit pointers hipcc hoists the sixteen block-invariant addresses out of the segment loop
-// and keeps 32 registers live across the K loop)
-// s_nop 4: the base may reach the asm through a v_readlane (an SGPR the register allocator spilled to a VGPR lane), and a VMEM instruction that
-// reads an SGPR a VALU instruction wrote needs five wait states — the hazard recogniser does not look inside an asm statement (seen: the sixteen
-// block-invariant store bases were hoisted out of the segment loop, spilled, read back in front of each store, and the stores faulted)
-__device__ __forceinline__ void sk_st16(unsigned voff, const void *sbase, f32x4 v) { asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory"); }
-__device__ __forceinline__ void sk_ld16(f32x4 &d, unsigned voff, const void *sbase) { asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "=v"(d) : "v"(voff), "s"(sbase) : "memory"); }
-__device__ __forceinline__ int sk_here(int v) { asm volatile("" : "+s"(v)); return v; }     // a value the optimiser cannot move across this point
-// the segment's end: hand the accumulators over, or collect the earlier parts of the tile and finish it
-template <int SPW, int NTL>
-__device__ __forceinline__ void sk_finish(const GemmLaunch &L, const GemmProb &P, f32x4 (&acc)[SPW][NTL], int strip, int nstrips, int t0, int lane, const SkSeg &sg, int G) {
-    constexpr int NJ = SPW * NTL;
-    const int tid = threadIdx.x;
-    const int bid = sk_here((int)blockIdx.x);                        // (block-invariant addresses stay HERE: hoisted, they live across the K loop)
-    if (sg.g1 < G) {                                                   // producer
-        const char *dst = (const char *)(L.sk_part + (long)bid * 16 * 1024);
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) if (L.sk != 2 && L.sk != 4) sk_st16((unsigned)tid * 16u, dst + jj * 4096, acc[jj / NTL][jj % NTL]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(L.sk_flag + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    if (sg.g0 > 0 && L.sk != 5) {                                      // finisher: parts of positions j-1, j-2, ... back to the tile's first group
-        for (int q = sg.j - 1; q >= 0; --q) {
-            if (sk_begin_of(sg, q) == sk_begin_of(sg, q + 1)) continue;        // a block without units (a band shorter than its blocks) raises no flag
-            const int bq = (q << 3) | sg.x;
-            if (tid == 0) {
-                int it = 0;
-                while (__hip_atomic_load(L.sk_flag + bq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++it < (1 << 16)) __builtin_amdgcn_s_sleep(2);
-                if (it >= (1 << 16)) atomicAdd(L.sk_flag + SK_MAX_BLOCKS, 1u);
-            }
-            __syncthreads();
-            const char *src = (const char *)(L.sk_part + (long)bq * 16 * 1024);
-#pragma unroll
-            for (int j0 = 0; j0 < NJ; j0 += 4) {
-                f32x4 v[4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) { v[jj] = (f32x4){0.f, 0.f, 0.f, 0.f}; if (L.sk != 3 && L.sk != 4) sk_ld16(v[jj], (unsigned)tid * 16u, src + (j0 + jj) * 4096); }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) { asm volatile("" : "+v"(v[jj])); acc[(j0 + jj) / NTL][(j0 + jj) % NTL] += v[jj]; }
-            }
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(L.sk_flag + bq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (sk_begin_of(sg, q) <= sg.tile_u) break;
-        }
-    }
-    tg_epilogue<SPW, NTL>(L, P, acc, strip, nstrips, t0, lane);
-}
-// the block's segments, in order: f(problem, segment) — ONE call site for both mappings (the body is inlined once per weight format); a launch
-// without stream-K is the single segment `on = 0` of the block's own problem
-template <class F>
-__device__ __forceinline__ void sk_walk(const GemmLaunch &L, F &&f) {
-    SkSeg sg;
-    sg.on = L.sk; sg.again = 0;
-    sg.x = (int)blockIdx.x & 7; sg.j = (int)blockIdx.x >> 3; sg.nbx = (int)gridDim.x >> 3;
-    sg.U0 = sg.U1 = 0; sg.tile = sg.g0 = sg.g1 = sg.tile_u = 0;
-    // The block's unit range [lo, hi) is walked from its END: the head of the last tile first (a producer part, handed over early), the tail of the
-    // first tile last — where this block is the finisher and the parts it needs were the FIRST thing the blocks before it computed.  (Walked
-    // forwards, every finisher waits for its predecessor's last segment: a chain through the whole band, 78 us for a 34 us launch.)
-    int lo = 0, hi = 1;
-    if (sg.on) {
-        sg.U0 = L.sk_band[sg.x]; sg.U1 = L.sk_band[sg.x + 1];
-        lo = sk_begin_of(sg, sg.j); hi = sk_begin_of(sg, sg.j + 1);
-    }
-    while (hi > lo) {
-        int pi = 0, seg_lo = lo;
-        if (sg.on) {
-            for (int i = 1; i < L.nprob; ++i) if (hi - 1 >= L.sk_unit_begin[i]) pi = i;
-            const int G = L.p[pi].K >> 7, local = hi - 1 - L.sk_unit_begin[pi];
-            sg.tile = local / G; sg.tile_u = L.sk_unit_begin[pi] + sg.tile * G;
-            seg_lo = max(lo, sg.tile_u);
-            sg.g0 = seg_lo - sg.tile_u; sg.g1 = hi - sg.tile_u;
-        } else {
-            for (int i = 1; i < L.nprob; ++i) if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
-        }
-        f(L.p[pi], sg);
-        hi = seg_lo;
-        sg.again = 1;
-    }
-}
 #endif
 #if RWKV_PART_ON(2)
 template <bool HILO, int WAVES, int SPW, int NTL, int KC, int FMT, bool GLDS>
@@ -1912,7 +1809,7 @@ __device__ unsigned g_t3_printed = 0;
 // eight waves over two K halves (29.9 against 32.6 isolated, nothing in the model: 49.1 -> 48.8 k tok/s).  Both removed.
 // SPW = strips per wave (2 in every shape the engine uses).
 template <int FMT, int NTL, int SPW = 2>
-__device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem, const SkSeg &sg) {
+__device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
     constexpr int BT = NTL * 16, WAVES = 4, STRIPS = WAVES * SPW, NA = T3Set<FMT, SPW>::NLOAD, NTW = NTL;
     constexpr int DPW = 2 * NTL / WAVES;                          // X tiles (DMAs) per wave per stage: 2 NTL tiles over the block's four waves
     constexpr int STAGE_HALFS = NTL * 2 * 512;                    // [token tile][k-step][lane][8]
@@ -1939,15 +1836,10 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
     // token tile) or, L.xcd_map == 2, token-tile major (row tile fastest: an XCD keeps ITS token tiles' operand rows in its L2 and streams the weights
     // past them): measured better only for hi + lo operands at 2048 rows (rwkv_engine.cpp)
     const int nrb_ = nb / ntt;
-    int rb = L.xcd_map == 2 ? lb % nrb_ : lb / ntt, tt = L.xcd_map == 2 ? lb / nrb_ : lb - rb * ntt;
-    const int G = P.K >> 7;
-    int g0 = (int)((long)kb * G / P.ksb), g1 = (int)((long)(kb + 1) * G / P.ksb);
-    if (sg.on) {                                                  // stream-K: the segment names the tile and its groups
-        rb = sg.tile / ntt; tt = sg.tile - rb * ntt; g0 = sg.g0; g1 = sg.g1;
-        if (sg.again) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); }   // the previous segment's ring reads and stores
-    }
+    const int rb = L.xcd_map == 2 ? lb % nrb_ : lb / ntt, tt = L.xcd_map == 2 ? lb / nrb_ : lb - rb * ntt;
     const int strip = rb * STRIPS + wave * SPW;
     const int t0 = tt * BT;
+    const int G = P.K >> 7, g0 = (int)((long)kb * G / P.ksb), g1 = (int)((long)(kb + 1) * G / P.ksb);
     const int kofs = g0 * 128;                                    // first k of this copy
     const int nsc = g1 - g0, nst = nsc * 2;
     const _Float16 *xs = (const _Float16 *)smem;                  // [T3_NB][token tile 0..7][k-step 0..1][lane][8]
@@ -2082,9 +1974,7 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
                    (int)blockIdx.x, L.total_blocks, wave, FMT, SPW, nst, tr_end - tr_begin, tr_issue, tr_stage, tr_wait, (tr_end - tr_begin) / (nst > 0 ? nst : 1), tr_head);
     }
 #endif
-    if (sg.on) {
-        sk_finish<SPW, NTW>(L, P, acc, strip, nstrips, t0, lane, sg, G);
-    } else if (P.ksb > 1) {                                       // partial slab kb (host: out_f32 only, linear epilogue)
+    if (P.ksb > 1) {                                              // partial slab kb (host: out_f32 only, linear epilogue)
         GemmProb Q = P;
         Q.out_f32 = P.out_f32 + (long)kb * P.partial_stride;
         tg_epilogue<SPW, NTW>(L, Q, acc, strip, nstrips, t0, lane);
@@ -2096,12 +1986,13 @@ __device__ __forceinline__ void tg3_body(const GemmLaunch &L, const GemmProb &P,
 template <int NTL>
 __global__ __launch_bounds__(256, 2) void gemm_tile3_kernel(const GemmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    auto run = [&](const GemmProb &P, const SkSeg &sg) {
-        if (P.fmt == W_F16) tg3_body<W_F16, NTL>(L, P, smem, sg);
-        else if (P.fmt == W_INT8) tg3_body<W_INT8, NTL>(L, P, smem, sg);
-        else tg3_body<W_NF4, NTL>(L, P, smem, sg);
-    };
-    sk_walk(L, run);
+    int pi = 0;
+    for (int i = 1; i < L.nprob; ++i)
+        if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
+    const GemmProb &P = L.p[pi];
+    if (P.fmt == W_F16) tg3_body<W_F16, NTL>(L, P, smem);
+    else if (P.fmt == W_INT8) tg3_body<W_INT8, NTL>(L, P, smem);
+    else tg3_body<W_NF4, NTL>(L, P, smem);
 }
 bool gemm_tile3_supported(bool hilo, int K) { return !hilo && K % 128 == 0; }
 
@@ -2203,7 +2094,7 @@ __device__ __forceinline__ void t4_wload_item(T3Set<FMT, 2> &w, const T3Off<2> &
 }
 
 template <int FMT, int NTL, bool HILO>
-__device__ __forceinline__ void tg4_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem, const SkSeg &sg) {
+__device__ __forceinline__ void tg4_body(const GemmLaunch &L, const GemmProb &P, unsigned char *smem) {
     constexpr int SPW = 2, WAVES = 4, STRIPS = WAVES * SPW, BT = NTL * 16;
     constexpr int HB = HILO ? 2 : 1, NBT = NTL * HB;              // B fragments per k-step: [hi | lo][token tile]
     constexpr int M = SPW * NBT;                                  // MFMAs per k-step per wave
@@ -2230,15 +2121,10 @@ __device__ __forceinline__ void tg4_body(const GemmLaunch &L, const GemmProb &P,
     // token tile) or, L.xcd_map == 2, token-tile major (row tile fastest: an XCD keeps ITS token tiles' operand rows in its L2 and streams the weights
     // past them): measured better only for hi + lo operands at 2048 rows (rwkv_engine.cpp)
     const int nrb_ = nb / ntt;
-    int rb = L.xcd_map == 2 ? lb % nrb_ : lb / ntt, tt = L.xcd_map == 2 ? lb / nrb_ : lb - rb * ntt;
-    const int G = P.K >> 7;
-    int g0 = (int)((long)kb * G / P.ksb), g1 = (int)((long)(kb + 1) * G / P.ksb);
-    if (sg.on) {                                                  // stream-K: the segment names the tile and its groups
-        rb = sg.tile / ntt; tt = sg.tile - rb * ntt; g0 = sg.g0; g1 = sg.g1;
-        if (sg.again) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); }   // the previous segment's ring reads and stores
-    }
+    const int rb = L.xcd_map == 2 ? lb % nrb_ : lb / ntt, tt = L.xcd_map == 2 ? lb / nrb_ : lb - rb * ntt;
     const int strip = rb * STRIPS + wave * SPW;
     const int t0 = tt * BT;
+    const int G = P.K >> 7, g0 = (int)((long)kb * G / P.ksb), g1 = (int)((long)(kb + 1) * G / P.ksb);
     const int kofs = g0 * 128;                                    // first k of this copy
     const int nsc = g1 - g0, nst = nsc * 2;                       // weight groups (128 k) and stages (64 k) of this copy
     const unsigned xs_byte = (unsigned)(uintptr_t)smem;
@@ -2364,9 +2250,7 @@ __device__ __forceinline__ void tg4_body(const GemmLaunch &L, const GemmProb &P,
         if (g + 1 < nsc) group(a1, a2, g + 1);
         if (g + 2 < nsc) group(a2, a0, g + 2);
     }
-    if (sg.on) {
-        sk_finish<SPW, NTL>(L, P, acc, strip, nstrips, t0, lane, sg, G);
-    } else if (P.ksb > 1) {                                       // partial slab kb (host: out_f32 only, linear epilogue)
+    if (P.ksb > 1) {                                              // partial slab kb (host: out_f32 only, linear epilogue)
         GemmProb Q = P;
         Q.out_f32 = P.out_f32 + (long)kb * P.partial_stride;
         tg_epilogue<SPW, NTL>(L, Q, acc, strip, nstrips, t0, lane);
@@ -2377,16 +2261,24 @@ __device__ __forceinline__ void tg4_body(const GemmLaunch &L, const GemmProb &P,
 
 __global__ __launch_bounds__(256, 2) void gemm_tile4_kernel(const GemmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    auto run = [&](const GemmProb &P, const SkSeg &sg) {
-        if (P.fmt == W_F16) tg4_body<W_F16, 4, true>(L, P, smem, sg);
-        else if (P.fmt == W_INT8) tg4_body<W_INT8, 4, true>(L, P, smem, sg);
-        else tg4_body<W_NF4, 4, true>(L, P, smem, sg);
-    };
-    sk_walk(L, run);
+    int pi = 0;
+    for (int i = 1; i < L.nprob; ++i)
+        if ((int)blockIdx.x >= L.p[i].block_begin) pi = i;
+    const GemmProb &P = L.p[pi];
+    if (P.fmt == W_F16) tg4_body<W_F16, 4, true>(L, P, smem);
+    else if (P.fmt == W_INT8) tg4_body<W_INT8, 4, true>(L, P, smem);
+    else tg4_body<W_NF4, 4, true>(L, P, smem);
 }
 bool gemm_tile4_supported(bool hilo, int K) { return hilo && K % 128 == 0; }
 
 
+// (Round 6 also built STREAM-K over this kernel and gemm_tile3: a grid of 512 resident blocks, the launch's (tile, 128-k group) units dealt evenly per
+// XCD band, a block walking its run from the end, partial accumulators handed to the block that reaches the tile's last group through write-through
+// stores and flags — correct on 24 configurations (same sums in another order, no timeouts) and no faster: r/k/v/g Int8 at 256 rows 34.1 -> 34.3 us
+// (324 tiles on 512 slots), at 2048 rows 150 -> 166 (1,296 tiles: the dispatcher's own refilling beats a persistent grid); Fv without K copies
+// 65 -> 40 at 256 rows, where its K copies already reach 30.  A launch's time is not the slowest CU's: profiles/r6_exp_stream_k.log; code at 0a1ea2f.
+// What that experiment left behind: scripts/check_sgpr_hazard.py — an inline-asm VMEM instruction whose scalar base reaches it through a v_readlane
+// (a spilled SGPR) needs five wait states hipcc does not insert inside asm statements; the hand-off stores faulted on it.)
 // (Round 6 also built the loader / consumer form of this kernel — waves 4..7 issue every LDS-DMA, X stages and raw weight tiles through LDS
 // rings, waves 0..3 only read LDS, dequantise and multiply, one 8-wave block per CU; parity green and bit-identical — and measured it: a block
 // alone on its CU is 25 % faster per stage, but one 8-wave block per CU loses the overlap of two independent 4-wave blocks: r/k/v/g Int8 at 2048
@@ -2419,41 +2311,6 @@ static const int kTileShapes[GEMM_TILE_SHAPES][5] = {{8, 2, 8, 128, 0}, {8, 1, 8
 int gemm_tile_blocks(int shape, int rows, int T) {
     const int strips = kTileShapes[shape][0] * kTileShapes[shape][1], bt = kTileShapes[shape][2] * 16;
     return ((rows / 16 + strips - 1) / strips) * ((T + bt - 1) / bt);
-}
-
-bool plan_streamk(GemmLaunch &L, int shape, int nblocks, int min_units, float *part, unsigned *flag) {
-    if (!gemm_tile_pipelined(shape) || nblocks < 8 || nblocks % 8 || nblocks > SK_MAX_BLOCKS || !part || !flag || L.nprob < 1) return false;
-    const int strips = kTileShapes[shape][0] * kTileShapes[shape][1], bt = kTileShapes[shape][2] * 16;
-    const int ntt = (L.T + bt - 1) / bt;
-    long units = 0;
-    int ub[GEMM_MAXP + 1];
-    for (int i = 0; i < L.nprob; ++i) {
-        const GemmProb &g = L.p[i];
-        if (g.ksb != 1 || g.K % 128 || g.K < 128) return false;
-        ub[i] = (int)units;
-        units += (long)((g.rows / 16 + strips - 1) / strips) * ntt * (g.K >> 7);
-        if (units > (1L << 30)) return false;
-    }
-    for (int i = L.nprob; i <= GEMM_MAXP; ++i) ub[i] = (int)units;
-    if (units < (long)nblocks * std::max(1, min_units)) return false;
-    // XCD bands: the units' eighths, moved to the nearest tile boundary (a tile's groups never straddle two XCDs: a finisher's producers are
-    // blocks of its own XCD with lower indices)
-    int band[9];
-    for (int x = 0; x <= 8; ++x) {
-        const long target = units * x / 8;
-        int pi = 0;
-        for (int i = 1; i < L.nprob; ++i) if (target >= ub[i]) pi = i;
-        const long G = L.p[pi].K >> 7, local = target - ub[pi];
-        band[x] = (int)std::min(units, ub[pi] + (local + G / 2) / G * G);
-    }
-    band[0] = 0; band[8] = (int)units;
-    for (int x = 1; x <= 8; ++x) band[x] = std::max(band[x], band[x - 1]);
-    L.sk = 1;
-    for (int i = 0; i <= GEMM_MAXP; ++i) L.sk_unit_begin[i] = ub[i];
-    for (int x = 0; x <= 8; ++x) L.sk_band[x] = band[x];
-    L.sk_part = part; L.sk_flag = flag;
-    L.total_blocks = nblocks;
-    return true;
 }
 
 void launch_gemm_tile(const GemmLaunch &L, int shape, bool hilo, hipStream_t s) {

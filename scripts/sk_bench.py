@@ -1,4 +1,4 @@
-"""Round 6 (GPU box): stream-K over the pipelined tile kernels (RWKV_BENCH_SK=<blocks>) against the classic grids, isolated launches of the 3 B / 7 B layer's
+"""(Needs the library of commit 0a1ea2f: the stream-K code was measured and removed.)  Round 6 (GPU box): stream-K over the pipelined tile kernels (RWKV_BENCH_SK=<blocks>) against the classic grids, isolated launches of the 3 B / 7 B layer's
 matrices; the engine library prints a check line per configuration on stderr (dealt-out against classic on the same operands)."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
