@@ -1313,6 +1313,12 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
                 if (att_fused) { m.lnp = ln_pro(a, lnp_xx_att); m.mu_x = w.mu[0]; }
                 launch(FAM_GEMM, [&] { launch_v6_mix(m, hilo, s_main); });
                 // LoRA matrices once, z / xx / dx in, five operands out (+ the LayerNorm prologue's row traffic on single-token steps)
+                if (const int nsl = v6_mix_split(m, hilo)) {
+                    // two launches: phase 1 reads W1 and z and leaves m (f16, or fp32 partials per K slice); the apply launch reads m, W2, xx / dx, mu
+                    const double mbytes = nsl > 1 ? (double)nsl * 5 * T * Dm * 4 : (double)5 * T * Dm * 2 * (m.mg_lo ? 2 : 1);
+                    log_row("v6_mix_kernel", T, nsl * 5 * (T / 32), 5.0 * Dm * C * 2 + (double)T * C * 2.0 + mbytes);
+                    log_row("v6_mix_apply_kernel", T, ((C / 16 + 7) / 8) * (T / 32), 5.0 * Dm * C * 2 + mbytes + (double)T * C * (8.0 + 10.0 * (m.olo[0] ? 2 : 1)) + 20.0 * C);
+                } else
                 log_row("v6_mix_kernel", T, 0, 2.0 * (5.0 * Dm * C * 2) + (double)T * C * (2.0 + 8.0 + 10.0 * (m.olo[0] ? 2 : 1)) + 20.0 * C +
                                                    (att_fused ? (double)T * C * 4.0 * (4 + np) : 0.0));
             } else {

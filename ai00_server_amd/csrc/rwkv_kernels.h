@@ -169,6 +169,7 @@ struct V6MixArgs {
 bool v6_mix_supported(int T, int C, int Dm);
 bool v6_mix_wide_supported(int T, int C, int Dm);                   // steps with more than 32 rows: block = (mix, 32-token tile), all strips
 bool v6_mix_ln_supported(int T, int C, int Dm, bool hilo, int np);   // the LayerNorm-prologue form (lnp set)
+int v6_mix_split(const V6MixArgs &a, bool hilo);      // 0: one launch; n >= 1: phase 1 (in n K slices) + v6_mix_apply_kernel
 void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s);
 
 

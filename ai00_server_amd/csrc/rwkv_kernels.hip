@@ -1168,6 +1168,28 @@ __global__ __launch_bounds__(512) void v6_mix_apply_kernel(const V6MixArgs a) {
 bool v6_mix_supported(int T, int C, int Dm) { return T <= 32 && C % 256 == 0 && (Dm == 32 || Dm == 64); }
 bool v6_mix_wide_supported(int T, int C, int Dm) { return T > 32 && C % 256 == 0 && (Dm == 32 || Dm == 64); }
 
+// Two launches (phase 1 + v6_mix_apply_kernel) for this step?  0: one launch; n >= 1: two, phase 1 in n K slices.
+//  * >= 512 rows (a multiple of 32): one slice (round 3);
+//  * 192 .. 511 rows (round 6): phase 1 sliced over K — the smallest slice count (a divisor of the k-steps per wave) that gives the launch >= 160
+//    blocks; partials in a.mp.  V6-3B at 256 rows: one launch of 240 blocks 16.4 us -> 200 slice blocks 5.2 us + 160 apply blocks 9.0 us (rocprofv3,
+//    profiles/r6_exp_v6mix_kslices.log); at 512 rows even, at 128 rows slower: the rule's range.
+int v6_mix_split(const V6MixArgs &a, bool hilo) {
+    constexpr int V6_SPLIT_MIN_T = 512;
+    if (a.T <= 32 || a.T % 32) return 0;
+    const int ntile = a.T / 32;
+    if (a.mp && a.T >= a.ksp_min_t && a.T < V6_SPLIT_MIN_T) {
+        const int per_wave = (a.C >> 5) >> 3;
+        int best = 1;
+        for (int q = 1; q <= per_wave && q <= a.ksp_max; ++q) {
+            if (per_wave % q) continue;
+            best = q;
+            if (5 * ntile * q >= a.ksp_blocks) break;
+        }
+        if (best > 1) return best;
+    }
+    return (a.T >= V6_SPLIT_MIN_T && a.mg_hi && (!hilo || a.mg_lo)) ? 1 : 0;
+}
+
 void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
     // (the wide form — 40 blocks that each walk every strip — for 17..32 rows too: 2.250 -> 2.36 ms per 32-slot step,
     // profiles/r3_exp_ab_v6mix_wide_for_32_rows.log; 100 blocks of 8 strips is the measured optimum between that and the 200-block split)
@@ -1175,7 +1197,6 @@ void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
     // (17..32 rows as two NT = 1 token tiles — 200 workgroups that each pull W1_c + half of z — was measured and dropped: every
     // workgroup still pulls all of W1_c, so the launch's L2 traffic grows by half: 2.250 -> 2.267 ms per 32-slot step,
     // profiles/r3_exp_ab_v6mix_ksw8.log.)
-    constexpr int V6_SPLIT_MIN_T = 512;                        // rows from which the wide form runs as two launches (v6_mix_apply_kernel)
     const int NT = (a.T <= 16 && !wide) ? 1 : 2;
     const bool lnp = a.lnp.x_in != nullptr;                    // host: T <= LNP_MAX_T, !hilo, C <= 4096 (v6_mix_ln_supported)
     const size_t lds = (size_t)8 * 4 * NT * 64 * 16 + (size_t)2 * NT * 16 * (a.Dm + 8) * 2 + (lnp ? lnp_lds_bytes(LNP_MAX_T, a.C, hilo) : 0);
@@ -1183,22 +1204,9 @@ void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
     if (wide) {
         const int ntile = (a.T + 31) / 32;
         grid = dim3(std::max(1, std::min(8, 256 / (5 * ntile))), 5, ntile);   // fill the chip when the step has few token tiles
-        // Steps of 192 .. 511 rows (round 6): phase 1 sliced over K — the smallest slice count (a divisor of the k-steps per wave) that gives the
-        // launch >= 160 blocks; partials in a.mp.  V6-3B at 256 rows: one launch of 240 blocks 16.4 us -> 200 slice blocks 5.2 us + 160 apply blocks
-        // 9.0 us (rocprofv3, profiles/r6_exp_v6mix_kslices.log); at 512 rows even, at 128 rows slower: the rule's range.
         V6MixArgs b = a;
-        b.ksp = 1;
-        if (a.mp && a.T % 32 == 0 && a.T >= a.ksp_min_t && a.T < V6_SPLIT_MIN_T) {
-            const int per_wave = (a.C >> 5) >> 3;
-            int best = 1;
-            for (int q = 1; q <= per_wave && q <= a.ksp_max; ++q) {
-                if (per_wave % q) continue;
-                best = q;
-                if (5 * ntile * q >= a.ksp_blocks) break;
-            }
-            b.ksp = best;
-        }
-        if (((a.T >= V6_SPLIT_MIN_T && a.mg_hi && (!hilo || a.mg_lo)) || b.ksp > 1) && a.T % 32 == 0) {
+        b.ksp = std::max(1, v6_mix_split(a, hilo));
+        if (v6_mix_split(a, hilo) > 0) {
             const V6MixArgs &a = b;                             // (shadows: the launches below take the slice count)
             grid = dim3(a.ksp, 5, ntile);
             const dim3 g2((a.C / 16 + 7) / 8, ntile);

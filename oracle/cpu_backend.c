@@ -55,7 +55,9 @@ static void master_leave(void);
 /* Error-attribution switch (scripts/fp16_error_attribution.py; off = 0 in every parity test and in the bench): bit `cls` set ->
  * the X operand of the GEMMs of that class is rounded to fp16 on the way in, which is what `Precision::Fp16` does on the GPU
  * (reload.rs:89-94: f16 operands, fp32 accumulate).  Lets the CPU say WHICH operand class carries a model's Fp16 error. */
-enum { CLS_ATT = 0, CLS_LORA1 = 1, CLS_LORA2 = 2, CLS_WO = 3, CLS_FFN1 = 4, CLS_FV = 5, CLS_MIX1 = 6, CLS_MIX2 = 7, CLS_DECAY2 = 8, CLS_HEAD = 9 };
+enum { CLS_ATT = 0, CLS_LORA1 = 1, CLS_LORA2 = 2, CLS_WO = 3, CLS_FFN1 = 4, CLS_FV = 5, CLS_MIX1 = 6, CLS_MIX2 = 7, CLS_DECAY2 = 8, CLS_HEAD = 9,
+       /* round 6: V6's time-mix projections one by one (bit CLS_ATT rounds all five; bits 10..14 round one each) — which of them must read hi + lo */
+       CLS_ATT_R = 10, CLS_ATT_K = 11, CLS_ATT_V = 12, CLS_ATT_G = 13, CLS_ATT_W = 14 };
 static int g_f16_mask = 0;
 void rwkv_cpu_set_operand_rounding(int mask) { g_f16_mask = mask; }
 static inline __m256 round_f16(__m256 x) {
@@ -80,7 +82,7 @@ static void gemm_f16(const uint16_t *W, long rows, long K, const float *X, long 
         for (int b = 0; b < B; b += 64) gemm_f16(W, rows, K, X + (long)b * ldx, ldx, Y + (long)b * ldy, ldy, B - b < 64 ? B - b : 64, cls);
         return;
     }
-    const int rnd = (g_f16_mask >> cls) & 1;
+    const int rnd = ((g_f16_mask >> cls) & 1) | ((cls >= CLS_ATT_R && cls <= CLS_ATT_W) ? (g_f16_mask & 1) : 0);
     const long npair = (rows + 1) / 2;
 #pragma omp for schedule(static)
     for (long p = 0; p < npair; ++p) {
@@ -302,17 +304,17 @@ int rwkv_cpu_step(const CpuModel *m, const int32_t *tokens, int B, float *states
                     }
             }
         }
-        gemm_f16(p->Wr, C, C, xr, C, r, C, B, CLS_ATT);
-        gemm_f16(p->Wk, C, C, xk, C, k, C, B, CLS_ATT);
-        gemm_f16(p->Wv, C, C, xv, C, v, C, B, CLS_ATT);
-        gemm_f16(p->Wg, C, C, xg, C, g, C, B, CLS_ATT);
+        gemm_f16(p->Wr, C, C, xr, C, r, C, B, m->version == 6 ? CLS_ATT_R : CLS_ATT);
+        gemm_f16(p->Wk, C, C, xk, C, k, C, B, m->version == 6 ? CLS_ATT_K : CLS_ATT);
+        gemm_f16(p->Wv, C, C, xv, C, v, C, B, m->version == 6 ? CLS_ATT_V : CLS_ATT);
+        gemm_f16(p->Wg, C, C, xg, C, g, C, B, m->version == 6 ? CLS_ATT_G : CLS_ATT);
         float *wdec = hid2;                                         /* [B][C] */
         if (m->version == 5) {
 #pragma omp for
             for (int b = 0; b < B; ++b)
                 for (int c = 0; c < C; ++c) wdec[(long)b * C + c] = expf(-expf(p->decay[c]));
         } else {
-            gemm_f16(p->decay_w1, Dd, C, xw, C, td, Dd, B, CLS_ATT);
+            gemm_f16(p->decay_w1, Dd, C, xw, C, td, Dd, B, CLS_ATT_W);
 #pragma omp for
             for (long i = 0; i < (long)B * Dd; ++i) td[i] = tanhf(td[i]);
             gemm_f16(p->decay_w2, C, Dd, td, Dd, wdec, C, B, CLS_DECAY2);

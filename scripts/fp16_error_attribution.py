@@ -66,6 +66,16 @@ def main():
     full = sum(1 << i for i in used)
     cases = [("all (= Precision::Fp16)", full)] + [(f"only {classes[i]}", 1 << i) for i in used] + \
             [(f"all but {classes[i]}", full & ~(1 << i)) for i in used]
+    if len(sys.argv) > 3 and sys.argv[3] == "att-split" and info.version == 6:
+        # round 6: which of V6's five time-mix projections (bits 10..14: r, k, v, g, decay LoRA stage 1) must read hi + lo operands?  `rest` = every
+        # other class rounded (what Precision::Fp16 leaves f16 anyway); a listed projection is ROUNDED (not promoted), the others are exact
+        rest = full & ~1
+        names = {"r": 10, "k": 11, "v": 12, "g": 13, "w": 14}
+        import itertools
+        cases = [("all (= raw f16)", full), ("att promoted (= Precision::Fp16 today)", rest)]
+        for n in (1, 2, 3):
+            for sub in itertools.combinations("rkvgw", n):
+                cases.append(("rounded: " + "+".join(sub) + " (promoted: " + "+".join(c for c in "rkvgw" if c not in sub) + ")", rest | sum(1 << names[c] for c in sub)))
     if info.version == 7:
         cases += [("all but lora1+lora2", full & ~0b110), ("all but lora2+wo", full & ~0b1100), ("all but att+lora1", full & ~0b11),
                   ("all but att+lora1+lora2", full & ~0b111)]
