@@ -234,19 +234,21 @@ def test_committed_bench_line_keeps_the_contract():
 
 
 def test_committed_roofline_table_is_what_the_script_generates():
-    """profiles/r5_roofline_table.md (and round 4's) is GENERATED from the committed rocprofv3 summaries and launch logs
+    """profiles/r6_roofline_table.md (and rounds 5 and 4's) is GENERATED from the committed rocprofv3 summaries and launch logs
     (scripts/roofline_table.py): the per-launch fractions DESIGN.md quotes cannot drift from the evidence without this test noticing.  The
     script asserts every fraction <= 1 and never prices two launches that differ in kernel, grid or block size as one row (round 4's table
     had a 1.074: two 256-workgroup launches of different block sizes joined on the grid alone)."""
     import re
-    for rnd in ("r5", "r4"):
+    for rnd in ("r6", "r5", "r4"):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "roofline_table.py"), rnd], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr[-2000:]
         assert r.stdout == open(os.path.join(ROOT, "profiles", f"{rnd}_roofline_table.md")).read()
         assert "(HBM)" in r.stdout and "(MFMA)" in r.stdout
         fracs = [float(x) for x in re.findall(r"\| (\d\.\d+) \((?:HBM|MFMA)\) \|", r.stdout)]
         assert fracs and max(fracs) <= 1.0
-    assert "ambiguous" not in open(os.path.join(ROOT, "profiles", "r5_roofline_table.md")).read()       # round 5's logs carry the block size
+    for rnd in ("r6", "r5"):                                                                           # since round 5 the logs carry the block size
+        assert "ambiguous" not in open(os.path.join(ROOT, "profiles", f"{rnd}_roofline_table.md")).read()
+    assert "v6_mix_apply_kernel" in open(os.path.join(ROOT, "profiles", "r6_roofline_table.md")).read()     # both launches of the split mix are priced
 
 
 def test_roofline_table_never_prices_two_different_launches_as_one_row(tmp_path):
