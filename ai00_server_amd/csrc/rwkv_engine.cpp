@@ -1317,7 +1317,8 @@ void rwkv_engine::run_layers(int T, int n_seq, int n_out, const int *d_token, bo
                     // two launches: phase 1 reads W1 and z and leaves m (f16, or fp32 partials per K slice); the apply launch reads m, W2, xx / dx, mu
                     const double mbytes = nsl > 1 ? (double)nsl * 5 * T * Dm * 4 : (double)5 * T * Dm * 2 * (m.mg_lo ? 2 : 1);
                     log_row("v6_mix_kernel", T, nsl * 5 * (T / 32), 5.0 * Dm * C * 2 + (double)T * C * 2.0 + mbytes);
-                    log_row("v6_mix_apply_kernel", T, ((C / 16 + 7) / 8) * (T / 32), 5.0 * Dm * C * 2 + mbytes + (double)T * C * (8.0 + 10.0 * (m.olo[0] ? 2 : 1)) + 20.0 * C);
+                    const long ag = (long)((C / 16 + 7) / 8) * (T / 32);                // (launch_v6_mix: 16-token tiles below one block per CU)
+                    log_row("v6_mix_apply_kernel", T, ag < 256 ? (long)((C / 16 + 7) / 8) * ((T + 15) / 16) : ag, 5.0 * Dm * C * 2 + mbytes + (double)T * C * (8.0 + 10.0 * (m.olo[0] ? 2 : 1)) + 20.0 * C);
                 } else
                 log_row("v6_mix_kernel", T, 0, 2.0 * (5.0 * Dm * C * 2) + (double)T * C * (2.0 + 8.0 + 10.0 * (m.olo[0] ? 2 : 1)) + 20.0 * C +
                                                    (att_fused ? (double)T * C * 4.0 * (4 + np) : 0.0));

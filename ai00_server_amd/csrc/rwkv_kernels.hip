@@ -1072,9 +1072,9 @@ __global__ __launch_bounds__(512) void v6_mix_kernel(const V6MixArgs a) {
 }
 
 // Phase 2 of the split form: block = (8 strips of the C rows, one 32-token tile), wave = one strip, all five mixes.
-template <bool HILO, int DS>
+template <bool HILO, int DS, int NT = 2>
 __global__ __launch_bounds__(512) void v6_mix_apply_kernel(const V6MixArgs a) {
-    constexpr int NT = 2, Dm = DS * 16, mstride = Dm + 8;
+    constexpr int Dm = DS * 16, mstride = Dm + 8;
     __shared__ __attribute__((aligned(16))) _Float16 m_hi[5 * NT * 16 * mstride], m_lo[HILO ? 5 * NT * 16 * mstride : 8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1210,13 +1210,16 @@ void launch_v6_mix(const V6MixArgs &a, bool hilo, hipStream_t s) {
             const V6MixArgs &a = b;                             // (shadows: the launches below take the slice count)
             grid = dim3(a.ksp, 5, ntile);
             const dim3 g2((a.C / 16 + 7) / 8, ntile);
-            if (a.Dm == 32) {
-                if (hilo) { hipLaunchKernelGGL((v6_mix_kernel<2, true, 2, false, true, true>), grid, block, lds, s, a); hipLaunchKernelGGL((v6_mix_apply_kernel<true, 2>), g2, block, 0, s, a); }
-                else { hipLaunchKernelGGL((v6_mix_kernel<2, false, 2, false, true, true>), grid, block, lds, s, a); hipLaunchKernelGGL((v6_mix_apply_kernel<false, 2>), g2, block, 0, s, a); }
-            } else {
-                if (hilo) { hipLaunchKernelGGL((v6_mix_kernel<2, true, 4, false, true, true>), grid, block, lds, s, a); hipLaunchKernelGGL((v6_mix_apply_kernel<true, 4>), g2, block, 0, s, a); }
-                else { hipLaunchKernelGGL((v6_mix_kernel<2, false, 4, false, true, true>), grid, block, lds, s, a); hipLaunchKernelGGL((v6_mix_apply_kernel<false, 4>), g2, block, 0, s, a); }
-            }
+            // the apply launch on 16-token tiles when 32-token tiles leave it fewer blocks than the chip has CUs (256-row steps: 160 -> 320 blocks,
+            // 9.07 -> 8.57 us; profiles/r6_exp_v6mix_kslices.log)
+            const bool nt1 = (long)g2.x * g2.y < 256;
+            const dim3 g1((a.C / 16 + 7) / 8, (a.T + 15) / 16);
+#define V6P1(h, ds) hipLaunchKernelGGL((v6_mix_kernel<2, h, ds, false, true, true>), grid, block, lds, s, a)
+#define V6AP(h, ds) do { if (nt1) hipLaunchKernelGGL((v6_mix_apply_kernel<h, ds, 1>), g1, block, 0, s, a); else hipLaunchKernelGGL((v6_mix_apply_kernel<h, ds, 2>), g2, block, 0, s, a); } while (0)
+            if (a.Dm == 32) { if (hilo) { V6P1(true, 2); V6AP(true, 2); } else { V6P1(false, 2); V6AP(false, 2); } }
+            else { if (hilo) { V6P1(true, 4); V6AP(true, 4); } else { V6P1(false, 4); V6AP(false, 4); } }
+#undef V6P1
+#undef V6AP
             return;
         }
         if (a.Dm == 32) { if (hilo) hipLaunchKernelGGL((v6_mix_kernel<2, true, 2, false, true>), grid, block, lds, s, a); else hipLaunchKernelGGL((v6_mix_kernel<2, false, 2, false, true>), grid, block, lds, s, a); }
