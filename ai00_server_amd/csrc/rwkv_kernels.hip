@@ -2429,6 +2429,8 @@ __device__ __forceinline__ void row_layernorm(float4 (&v)[PT], int C, const floa
 }
 
 
+// (Round 6: the two LayerNorms of a prefill row — its own and its predecessor's — under two barriers instead of four, both rows' statistics in one
+// block reduction, bit-identical: 8.40 -> 8.39 us at 256 rows.  The barriers are not where the kernel's time is; not kept.)
 // (Four consecutive rows per block on prefill-shaped steps — a row whose predecessor the block has just normalised takes it from
 // registers instead of loading and normalising it again — was built and measured in round 3: slower everywhere, 70.2 -> 69.1 k tok/s at
 // 2048 rows and 37.2 -> 35.1 k at 256, where it leaves 64 blocks for 256 CUs; profiles/r3_exp_ln_rows.log.  One row per block stays.)
