@@ -56,7 +56,7 @@ SIMDS, XCDS = 256 * 4, 8
 with open(dst, "w") as out:
     out.write("# MFMA utilisation AGAINST THE CHIP'S PEAK (round 6): SQ_VALU_MFMA_BUSY_CYCLES (matrix-pipe busy cycles, summed over the SIMDs) / (cycles the launch kept the GPU busy x 1024 SIMDs).\n"
               "# 1.0 = every SIMD's matrix pipe busy for the whole launch = the dense f16 peak at whatever clock the launch ran.  Busy cycles of the launch = GRBM_GUI_ACTIVE / 8: this rocprofv3\n"
-              "# reports the counter once per XCD and the CSV sums the eight (a 150 us launch reads 2.1e6 = 8 x 150 us x ~1.8 GHz).  Cross-check: the pipelined prefill kernel comes out at 0.29 here\n"
+              "# reports the counter once per XCD and the CSV sums the eight (a 150 us launch reads 2.1e6 = 8 x 150 us x ~1.8 GHz: the counter window of a profiled launch is a little longer than the kernel; scripts/clock_probe.hip measures 2.1 GHz during these launches).  Cross-check: the pipelined prefill kernel comes out at 0.29 here\n"
               "# and at 0.26-0.31 as FLOP / time / 2.5 PFLOP/s in the roofline table.\n")
     out.write("kernel | launches | mfma_busy_cycles (all launches) | GPU-busy cycles per launch | MFMA utilisation of the chip peak | wave cycles parked (SQ_WAIT_ANY / SQ_WAVE_CYCLES) | issuing (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES)\n")
     for k, c in sorted(acc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))[:16]:
