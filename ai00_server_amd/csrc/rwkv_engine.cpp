@@ -869,6 +869,9 @@ static int plan_gemm(GemmLaunch &Lh, std::vector<ProbSpec> &ps, int T, bool hilo
         // pulls from HBM grows with its waves — eight waves, two of them with a second slice, stream the first 80 % of the block's bytes at once
         // (Precision::Fp32 at 32 slots 2.587 -> 2.490 ms per step, Fp16 + RWKV_PROMOTE=1 2.307 -> 2.256)
         if (hilo && NT == 2 && per_wave > 1) nw = std::min(maxw, nslice);
+        // (Round 6: the two slices beyond the eight waves dealt out as six (slice, strip) items — one strip of a slice per wave instead of two waves
+        // walking a whole second slice — is SLOWER: every item pulls its slice's whole operand for a third of the work; 32-slot step 2.274 -> 2.30 ms,
+        // Fp32 2.51 -> 2.59, V7 2.38 -> 2.41; profiles/r6_exp_hilo_ragged_items.log.  Not kept.)
         // strips per block: the whole grid should be resident at once (~164 VGPRs -> 12 waves per CU), and a wave's
         // rounds should fit in registers so that every load is issued up-front (single shot); the head matrix is too
         // big for that and runs 8 strips per block, software-pipelined.
