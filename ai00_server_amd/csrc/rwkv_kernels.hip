@@ -101,7 +101,8 @@ __device__ __forceinline__ void store_operand4(_Float16 *__restrict__ hi, _Float
 // both sides) with in-kernel completion counters was built to overlap consecutive launches on two streams and measured:
 // the polling of a few hundred waiting workgroups on one counter costs more than the launch boundary it replaces
 // (scripts/chain_bench.hip: 10.8-30 us per dependent phase against 6.2 us for plain graph launches), so launches stay
-// stream-ordered.
+// stream-ordered.  (Round 6, stream-ordered launches as they are: write-through stores — sc0 sc1, nothing left for the end-of-kernel L2 write-back —
+// cost +1 % per decode step at 32 slots and +2 % at one; non-temporal stores +7 % / +1 %: profiles/r6_exp_activation_store_policy.log.  Policy 0 stays.)
 // =====================================================================================
 typedef __amdgpu_buffer_rsrc_t act_t;                              // buffer descriptor of one activation array (4 SGPRs)
 constexpr int ACT_SC1 = 0;                                        // cache policy of activation accesses (0: default; 16 would be sc1)
